@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""bench.py -- ADMM inner iterations/sec of the MI355X-native ACOPF two-level ADMM inner loop.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one inner ADMM iteration (generator + branch TRON + bus + z/l/residual) over the
+whole grid resident in HBM.  Workload at N=1: BASELINE.json configs[2], case13659pegase
+(rho_pq=5e1 rho_va=5e3 scale=1e-4).  The real MATPOWER file is looked up in $MATPOWER_DATA
+and ./data; when absent (no network in this environment) a seeded size-matched synthetic grid
+(ngen 4092 / nline 20467 / nbus 13659) is used and the JSON says so.
+
+For N>1 (launched by torch.distributed.run) the grid is N areas of that size joined by tie
+lines, one area per GPU (weak scaling); see exaadmm.jl_amd/distributed.py and DESIGN.md.
+
+Prints ONE JSON line (rank 0).  `roofline` refers to the dominant kernel (k_branch):
+achieved = algorithmic bytes per launch / mean launch duration from HIP events on the launch
+stream.  `cpu_baseline` = the C oracle (serial port of the reference CPU path) timed on a
+bounded sample of the same workload on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+# algorithmic HBM bytes (SURVEY.md §8d, FP64 values, int32 indices)
+BYTES_PER_BRANCH_SOLVE = 568.0
+BYTES_PER_ITER = lambda G, L, B: 340.0 * G + 1408.0 * L + 44.0 * B
+
+CASE = "case13659pegase"
+CASE_PARAMS = {"case13659pegase": dict(rho_pq=5e1, rho_va=5e3, scale=1e-4),
+               "case1354pegase": dict(rho_pq=1e1, rho_va=1e3, scale=1e-4),
+               "case_ACTIVSg70k": dict(rho_pq=3e4, rho_va=3e5, scale=1e-5),
+               "synthetic1M": dict(rho_pq=5e1, rho_va=5e3, scale=1e-4)}
+
+
+def find_case_file(name):
+    for d in (os.environ.get("MATPOWER_DATA", ""), os.path.join(ROOT, "data")):
+        if d:
+            p = os.path.join(d, name + ".m")
+            if os.path.exists(p):
+                return p
+    return None
+
+
+def cpu_baseline(grid, params, budget_s=15.0):
+    """Time the oracle (kind=port) single-threaded on a bounded number of inner iterations."""
+    from oracle import oracle as O
+    m = O.OracleModel(grid, params["rho_pq"], params["rho_va"], scale=params["scale"])
+    m.info.outer = 1
+    # same phase of the algorithm as the GPU run: warm up a few iterations first
+    n_done, t_used = 0, 0.0
+    it = 0
+    for _ in range(2):
+        it += 1
+        m.inner_prestep(); m.update_x(it); m.update_xbar(); m.update_z(); m.update_l(); m.update_residual()
+    while t_used < budget_s and n_done < 200:
+        it += 1
+        t0 = time.perf_counter()
+        m.inner_prestep(); m.update_x(it); m.update_xbar(); m.update_z(); m.update_l(); m.update_residual()
+        t_used += time.perf_counter() - t0
+        n_done += 1
+    return {"value": n_done / t_used, "unit": "ADMM inner iterations/s", "cores": 1, "kind": "port",
+            "sample": "%d inner iterations (after 2 warm-up) of the same grid, serial C oracle, %.1f s" % (n_done, t_used)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--case", default=CASE)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 or world > 1:
+        import exaadmm_loader
+        dist_mod = exaadmm_loader.load_submodule("distributed")
+        return dist_mod.bench_main(args, rank, world, local_rank)
+
+    import torch
+    import exaadmm_loader
+    pkg = exaadmm_loader.load_package()
+    syn = exaadmm_loader.load_submodule("synthetic")
+    pkg.library()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; the product has no CPU path")
+
+    params = CASE_PARAMS[args.case]
+    path = find_case_file(args.case)
+    if path:
+        grid = pkg.opf_loaddata(path, tight_factor=0.99)
+        workload, data = args.case, "real MATPOWER file"
+    else:
+        grid = syn.sized_like(args.case, seed=0)
+        workload, data = "synthetic-%s-sized" % args.case, "synthetic"
+    G, L, B = int(grid["ngen"]), int(grid["nline"]), int(grid["nbus"])
+
+    env = pkg.AdmmEnv(args.case, params["rho_pq"], params["rho_va"], tight_factor=0.99, gpu_no=0, verbose=0, grid=grid)
+    mod = pkg.ModelAcopf(env)
+    env.params.scale = params["scale"]
+    mod.sync_params()
+    beta = env.params.initial_beta
+
+    # warm-up (untimed): first W inner iterations of outer iteration 1
+    if args.warmup > 0:
+        mod.run_fixed(args.warmup, first_major_iter=1, beta=beta)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    norms, ms_total, ms_branch = mod.run_fixed(args.steps, first_major_iter=args.warmup + 1, beta=beta, time_branch=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+
+    its = args.steps / dt
+    a_it, m_it = mod.branch_stats()
+    branch_bytes = BYTES_PER_BRANCH_SOLVE * L
+    achieved = branch_bytes / (ms_branch * 1e-3) / 1e9
+    out = {
+        "metric": "ADMM inner iterations/sec", "value": its, "unit": "iterations/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": data,
+        "config": {"workload": workload, "ngen": G, "nline": L, "nbus": B, "rho_pq": params["rho_pq"],
+                   "rho_va": params["rho_va"], "scale": params["scale"], "tight_factor": 0.99,
+                   "mode": "fixed-count inner iterations, no early break", "parallelism": "1 GPU"},
+        "roofline": {"bound": "hbm", "kernel": "k_branch", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": branch_bytes, "kernel_ms": ms_branch,
+                     "iteration_bytes": BYTES_PER_ITER(G, L, B),
+                     "iteration_frac": BYTES_PER_ITER(G, L, B) * its / 1e9 / HBM_PEAK_GBS,
+                     "note": "latency/FP64-issue bound: state is Infinity-Cache resident; see DESIGN.md"},
+        "solver": {"avg_auglag_it": a_it, "avg_tron_minor_it": m_it, "primres": float(norms[0]),
+                   "device_ms_total": ms_total},
+    }
+    if not args.no_cpu_baseline:
+        cb = cpu_baseline(grid, params)
+        out["cpu_baseline"] = cb
+        out["speedup_vs_cpu_baseline"] = its / cb["value"]
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

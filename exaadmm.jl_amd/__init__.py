@@ -1,0 +1,450 @@
+"""exaadmm.jl_amd -- MI355X-native backend for ExaAdmm.jl's two-level ADMM ACOPF inner loop.
+
+Host-side mirror, over the C ABI of libexaadmm_hip.so (include/exaadmm_hip.h), of the
+reference's plugin surface for this path, same names and argument meaning:
+
+    solve_acopf(case; kwargs) -> (env, mod)        /root/reference/src/interface/solve_acopf.jl:1-46
+    admm_two_level(env, mod)                       /root/reference/src/algorithms/admm_two_level.jl:1-88
+    AdmmEnv, ModelAcopf, Parameters, mod.info      /root/reference/src/utils/environment.jl
+    admm_increment_outer ... admm_poststep         /root/reference/docs/src/dev.md:65-155
+
+The reference's host language is Julia, which does not exist in the build image; the Julia
+binding a maintainer would add is shipped as source in julia/ExaAdmmHip.jl.
+All compute goes through the HIP library; if it is missing or no gfx950 device is visible the
+calls raise -- there is no CPU path in this package.
+
+The directory name contains a dot, so import it with `load_package()` from the repo-root
+helper `exaadmm_loader.py` (or importlib, as that helper does).
+"""
+import ctypes as C
+import math
+import os
+import time
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libexaadmm_hip.so")
+
+c_double_p = C.POINTER(C.c_double)
+c_i64_p = C.POINTER(C.c_int64)
+
+
+class ExaAdmmError(RuntimeError):
+    pass
+
+
+class Grid(C.Structure):
+    """exaadmm_grid"""
+    _F64 = ("pgmin", "pgmax", "qgmin", "qgmax", "c2", "c1", "c0",
+            "YffR", "YffI", "YftR", "YftI", "YttR", "YttI", "YtfR", "YtfI",
+            "FrVmBound", "ToVmBound", "FrVaBound", "ToVaBound", "rateA")
+    _BUS = ("Pd", "Qd", "Vmin", "Vmax", "YshR", "YshI")
+    _IDX = ("FrStart", "FrIdx", "ToStart", "ToIdx", "GenStart", "GenIdx")
+    _fields_ = ([("ngen", C.c_int64), ("nline", C.c_int64), ("nbus", C.c_int64),
+                 ("index_base", C.c_int32), ("baseMVA", C.c_double)] +
+                [(n, c_double_p) for n in _F64] + [("brBusIdx", c_i64_p)] +
+                [(n, c_double_p) for n in _BUS] + [(n, c_i64_p) for n in _IDX])
+
+
+class Parameters(C.Structure):
+    """exaadmm_params == Parameters of the reference (utils/environment.jl:6-76)"""
+    _fields_ = [("mu_max", C.c_double), ("max_auglag", C.c_int32), ("initial_beta", C.c_double),
+                ("beta", C.c_double), ("inc_c", C.c_double), ("theta", C.c_double),
+                ("outer_eps", C.c_double), ("MAX_MULTIPLIER", C.c_double),
+                ("outer_iterlim", C.c_int32), ("inner_iterlim", C.c_int32), ("scale", C.c_double),
+                ("verbose", C.c_int32), ("check_every", C.c_int32)]
+
+
+class Info(C.Structure):
+    """exaadmm_info == IterationInformation (utils/environment.jl:328-358)"""
+    _fields_ = [("status_code", C.c_int32), ("inner", C.c_int32), ("outer", C.c_int32),
+                ("cumul", C.c_int32), ("objval", C.c_double), ("primres", C.c_double),
+                ("dualres", C.c_double), ("mismatch", C.c_double), ("norm_z_curr", C.c_double),
+                ("norm_z_prev", C.c_double), ("eps_pri", C.c_double), ("time_overall", C.c_double),
+                ("time_x_update", C.c_double), ("time_xbar_update", C.c_double),
+                ("time_zl_update", C.c_double), ("avg_auglag_it", C.c_double),
+                ("avg_minor_it", C.c_double)]
+
+    @property
+    def status(self):
+        return "Solved" if self.status_code == 1 else "IterationLimit"
+
+
+VECTORS = {"u_curr": 0, "v_curr": 1, "l_curr": 2, "rho": 3, "rd": 4, "rp": 5, "z_curr": 6,
+           "z_prev": 7, "lz": 8, "Ax_plus_By": 9}
+
+_LIB = None
+
+
+def library():
+    """Load libexaadmm_hip.so.  Raises if it has not been built: no fallback."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise ExaAdmmError("HIP extension %s is missing; run __graft_entry__.build() "
+                           "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    H = C.c_void_p
+    L.exaadmm_version.restype = C.c_char_p
+    L.exaadmm_last_error.restype = C.c_char_p
+    L.exaadmm_io_error.restype = C.c_char_p
+    L.exaadmm_default_params.argtypes = [C.POINTER(Parameters)]
+    L.exaadmm_default_params.restype = None
+    L.exaadmm_create.argtypes = [C.POINTER(Grid), C.POINTER(Parameters), C.c_int, C.POINTER(H)]
+    L.exaadmm_destroy.argtypes = [H]
+    L.exaadmm_set_params.argtypes = [H, C.POINTER(Parameters)]
+    L.exaadmm_get_params.argtypes = [H, C.POINTER(Parameters)]
+    L.exaadmm_nvar.argtypes = [H]
+    L.exaadmm_nvar.restype = C.c_int64
+    L.exaadmm_init_solution.argtypes = [H, C.c_double, C.c_double]
+    L.exaadmm_upload_solution.argtypes = [H, C.c_int, c_double_p, C.c_int64]
+    L.exaadmm_download_solution.argtypes = [H, C.c_int, c_double_p, C.c_int64]
+    L.exaadmm_upload_membuf.argtypes = [H, c_double_p, C.c_int64, C.c_int64]
+    L.exaadmm_download_membuf.argtypes = [H, c_double_p, C.c_int64, C.c_int64]
+    L.exaadmm_set_load.argtypes = [H, c_double_p, c_double_p, C.c_int64]
+    L.exaadmm_set_pg_bounds.argtypes = [H, c_double_p, c_double_p, C.c_int64]
+    L.exaadmm_inner_prestep.argtypes = [H]
+    L.exaadmm_update_x.argtypes = [H, C.c_int]
+    L.exaadmm_update_x_gen.argtypes = [H]
+    L.exaadmm_update_x_line.argtypes = [H, C.c_int]
+    L.exaadmm_update_xbar.argtypes = [H]
+    L.exaadmm_update_z.argtypes = [H, C.c_double]
+    L.exaadmm_update_l.argtypes = [H, C.c_double]
+    L.exaadmm_update_residual.argtypes = [H, c_double_p]
+    L.exaadmm_update_lz.argtypes = [H, C.c_double]
+    L.exaadmm_norm_z.argtypes = [H, c_double_p]
+    L.exaadmm_objective.argtypes = [H, c_double_p]
+    L.exaadmm_branch_stats.argtypes = [H, c_double_p, c_double_p]
+    L.exaadmm_run_inner.argtypes = [H, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int), c_double_p]
+    L.exaadmm_solve_two_level.argtypes = [H, C.POINTER(Info)]
+    L.exaadmm_run_fixed.argtypes = [H, C.c_int, C.c_int, C.c_double, c_double_p, c_double_p, c_double_p]
+    L.exaadmm_set_stream.argtypes = [H, C.c_void_p]
+    L.exaadmm_residual_partial_sums.argtypes = [H, C.POINTER(C.c_void_p)]
+    L.exaadmm_set_halo_index.argtypes = [H, C.c_int, c_i64_p, C.c_int64]
+    L.exaadmm_halo_pack.argtypes = [H, C.c_int, C.c_int, C.c_void_p]
+    L.exaadmm_halo_unpack.argtypes = [H, C.c_int, C.c_int, C.c_void_p]
+    L.exaadmm_set_owned_mask.argtypes = [H, C.POINTER(C.c_uint8), C.c_int64]
+    L.exaadmm_update_zl_partial.argtypes = [H, C.c_double, C.POINTER(C.c_void_p)]
+    L.exaadmm_load_matpower.argtypes = [C.c_char_p, C.c_double, C.c_char_p, C.POINTER(C.c_void_p)]
+    L.exaadmm_case_grid.argtypes = [C.c_void_p, C.POINTER(Grid)]
+    L.exaadmm_case_free.argtypes = [C.c_void_p]
+    _LIB = L
+    return L
+
+
+def _check(rc, what):
+    if rc != 0:
+        L = library()
+        msg = L.exaadmm_last_error().decode() or L.exaadmm_io_error().decode()
+        raise ExaAdmmError("%s failed (status %d): %s" % (what, rc, msg))
+
+
+def _dp(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+# --------------------------------------------------------------------------- grid data
+def _as_grid_arrays(g):
+    """normalise a dict of arrays (zero-based indices) to contiguous f64 / i64 numpy arrays"""
+    out = {}
+    for k in Grid._F64 + Grid._BUS:
+        out[k] = np.ascontiguousarray(g[k], dtype=np.float64)
+    for k in Grid._IDX + ("brBusIdx",):
+        out[k] = np.ascontiguousarray(g[k], dtype=np.int64)
+    out["ngen"], out["nline"], out["nbus"] = int(g["ngen"]), int(g["nline"]), int(g["nbus"])
+    out["baseMVA"] = float(g["baseMVA"])
+    return out
+
+
+def opf_loaddata(case, tight_factor=1.0, case_format="matpower"):
+    """MATPOWER file -> grid dict through the native loader (exaadmm_load_matpower).
+    Counterpart of opf_loaddata + GridData (utils/opfdata.jl:408-415, utils/grid_data.jl:61-83)."""
+    L = library()
+    handle = C.c_void_p()
+    _check(L.exaadmm_load_matpower(os.fsencode(case), float(tight_factor), case_format.encode(),
+                                   C.byref(handle)), "exaadmm_load_matpower(%s)" % case)
+    try:
+        cg = Grid()
+        _check(L.exaadmm_case_grid(handle, C.byref(cg)), "exaadmm_case_grid")
+        G, Ln, B = cg.ngen, cg.nline, cg.nbus
+        sizes = {k: G for k in ("pgmin", "pgmax", "qgmin", "qgmax", "c2", "c1", "c0")}
+        sizes.update({k: Ln for k in ("YffR", "YffI", "YftR", "YftI", "YttR", "YttI", "YtfR", "YtfI", "rateA")})
+        sizes.update({k: 2 * Ln for k in ("FrVmBound", "ToVmBound", "FrVaBound", "ToVaBound", "brBusIdx")})
+        sizes.update({k: B for k in Grid._BUS})
+        sizes.update({"FrStart": B + 1, "ToStart": B + 1, "GenStart": B + 1, "FrIdx": Ln, "ToIdx": Ln, "GenIdx": G})
+        g = {"ngen": G, "nline": Ln, "nbus": B, "baseMVA": cg.baseMVA}
+        for k, n in sizes.items():
+            p = getattr(cg, k)
+            g[k] = np.ctypeslib.as_array(p, shape=(n,)).copy() if n > 0 else np.zeros(
+                0, dtype=np.int64 if k in Grid._IDX + ("brBusIdx",) else np.float64)
+        return g
+    finally:
+        L.exaadmm_case_free(handle)
+
+
+# --------------------------------------------------------------------------- env / model
+class AdmmEnv:
+    """AdmmEnv (utils/environment.jl:85-158): case data + ADMM parameters."""
+
+    def __init__(self, case, rho_pq, rho_va, case_format="matpower", use_linelimit=True,
+                 use_projection=False, tight_factor=1.0, gpu_no=0, verbose=1, grid=None):
+        if not use_linelimit:
+            raise ExaAdmmError("use_linelimit=false is a dead option in the reference "
+                               "(polar_kernel_two_level_alternative is undefined there)")
+        if use_projection:
+            raise ExaAdmmError("use_projection=true is not part of the ACOPF path (pf_projection is disabled upstream)")
+        self.case = case
+        self.initial_rho_pq = float(rho_pq)
+        self.initial_rho_va = float(rho_va)
+        self.tight_factor = float(tight_factor)
+        self.gpu_no = int(gpu_no)
+        self.use_linelimit = True
+        self.use_projection = False
+        self.data = _as_grid_arrays(grid if grid is not None else
+                                    opf_loaddata(case, tight_factor=tight_factor, case_format=case_format))
+        self.params = Parameters()
+        library().exaadmm_default_params(C.byref(self.params))
+        self.params.verbose = int(verbose)
+
+
+class Solution:
+    """Solution (utils/environment.jl:177-226): attribute access downloads the device vector
+    in the reference layout; assignment uploads."""
+
+    def __init__(self, mod):
+        object.__setattr__(self, "_mod", mod)
+
+    def __getattr__(self, name):
+        if name in VECTORS:
+            return self._mod.download(name)
+        raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        if name in VECTORS:
+            self._mod.upload(name, value)
+        else:
+            object.__setattr__(self, name, value)
+
+
+class ModelAcopf:
+    """ModelAcopf (models/acopf/acopf_model.jl:6-95) living on one MI355X."""
+
+    def __init__(self, env):
+        L = library()
+        self.env = env
+        g = env.data
+        self.grid_data = g
+        self.ngen, self.nline, self.nbus = g["ngen"], g["nline"], g["nbus"]
+        self.n = 6
+        self.nvar = 2 * self.ngen + 8 * self.nline
+        self.gen_start, self.line_start = 1, 2 * self.ngen + 1   # 1-based like the reference
+        cg = Grid()
+        cg.ngen, cg.nline, cg.nbus, cg.index_base, cg.baseMVA = self.ngen, self.nline, self.nbus, 0, g["baseMVA"]
+        for k in Grid._F64 + Grid._BUS:
+            setattr(cg, k, _dp(g[k]))
+        for k in Grid._IDX + ("brBusIdx",):
+            setattr(cg, k, g[k].ctypes.data_as(c_i64_p))
+        self._h = C.c_void_p()
+        _check(L.exaadmm_create(C.byref(cg), C.byref(env.params), env.gpu_no, C.byref(self._h)), "exaadmm_create")
+        _check(L.exaadmm_init_solution(self._h, env.initial_rho_pq, env.initial_rho_va), "exaadmm_init_solution")
+        self.info = Info()
+        self.solution = Solution(self)
+        self.pgmin_curr = g["pgmin"].copy()
+        self.pgmax_curr = g["pgmax"].copy()
+
+    # -- plumbing
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if self._h:
+            library().exaadmm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync_params(self):
+        _check(library().exaadmm_set_params(self._h, C.byref(self.env.params)), "exaadmm_set_params")
+
+    def download(self, name):
+        out = np.empty(self.nvar)
+        _check(library().exaadmm_download_solution(self._h, VECTORS[name], _dp(out), self.nvar), "download " + name)
+        return out
+
+    def upload(self, name, value):
+        a = np.ascontiguousarray(value, dtype=np.float64)
+        _check(library().exaadmm_upload_solution(self._h, VECTORS[name], _dp(a), a.size), "upload " + name)
+
+    @property
+    def membuf(self):
+        out = np.zeros((self.nline, 31))
+        _check(library().exaadmm_download_membuf(self._h, _dp(out), 31, self.nline), "download membuf")
+        return out.T  # 31 x nline view like the reference
+
+    @membuf.setter
+    def membuf(self, value):
+        a = np.ascontiguousarray(np.asarray(value, dtype=np.float64).T)
+        _check(library().exaadmm_upload_membuf(self._h, _dp(a), 31, self.nline), "upload membuf")
+
+    def set_load(self, Pd, Qd):
+        Pd = np.ascontiguousarray(Pd, dtype=np.float64)
+        Qd = np.ascontiguousarray(Qd, dtype=np.float64)
+        _check(library().exaadmm_set_load(self._h, _dp(Pd), _dp(Qd), Pd.size), "exaadmm_set_load")
+
+    def set_pg_bounds(self, lo, hi):
+        lo = np.ascontiguousarray(lo, dtype=np.float64)
+        hi = np.ascontiguousarray(hi, dtype=np.float64)
+        _check(library().exaadmm_set_pg_bounds(self._h, _dp(lo), _dp(hi), lo.size), "exaadmm_set_pg_bounds")
+        self.pgmin_curr, self.pgmax_curr = lo.copy(), hi.copy()
+
+    def branch_stats(self):
+        a, m = C.c_double(), C.c_double()
+        _check(library().exaadmm_branch_stats(self._h, C.byref(a), C.byref(m)), "exaadmm_branch_stats")
+        return a.value, m.value
+
+    def run_fixed(self, iters, first_major_iter=2, beta=None, time_branch=False):
+        """K inner iterations without convergence test; returns (norms, ms_total, ms_branch)."""
+        out = np.zeros(4)
+        ms, msb = C.c_double(), C.c_double()
+        beta = self.env.params.beta if beta is None else beta
+        _check(library().exaadmm_run_fixed(self._h, int(iters), int(first_major_iter), float(beta), _dp(out),
+                                           C.byref(ms), C.byref(msb) if time_branch else None), "exaadmm_run_fixed")
+        return out, ms.value, (msb.value if time_branch else None)
+
+    def run_inner(self, outer, max_inner, beta):
+        out = np.zeros(4)
+        done = C.c_int()
+        _check(library().exaadmm_run_inner(self._h, int(outer), int(max_inner), float(beta), C.byref(done), _dp(out)),
+               "exaadmm_run_inner")
+        return done.value, out
+
+
+# --------------------------------------------------------------------------- plugin steps
+# signatures (env, mod, device=None) as in docs/src/dev.md:65-155
+def admm_increment_outer(env, mod, device=None):
+    mod.info.outer += 1
+
+
+def admm_increment_reset_inner(env, mod, device=None):
+    mod.info.inner = 0
+
+
+def admm_increment_inner(env, mod, device=None):
+    mod.info.inner += 1
+    mod.info.cumul += 1
+
+
+def admm_outer_prestep(env, mod, device=None):
+    v = C.c_double()
+    _check(library().exaadmm_norm_z(mod.handle, C.byref(v)), "exaadmm_norm_z")
+    mod.info.norm_z_prev = v.value
+
+
+def admm_inner_prestep(env, mod, device=None):
+    _check(library().exaadmm_inner_prestep(mod.handle), "exaadmm_inner_prestep")
+
+
+def admm_update_x(env, mod, device=None):
+    mod.sync_params()
+    _check(library().exaadmm_update_x(mod.handle, mod.info.inner), "exaadmm_update_x")
+
+
+def admm_update_xbar(env, mod, device=None):
+    _check(library().exaadmm_update_xbar(mod.handle), "exaadmm_update_xbar")
+
+
+def admm_update_z(env, mod, device=None):
+    _check(library().exaadmm_update_z(mod.handle, env.params.beta), "exaadmm_update_z")
+
+
+def admm_update_l(env, mod, device=None):
+    _check(library().exaadmm_update_l(mod.handle, env.params.beta), "exaadmm_update_l")
+
+
+def admm_update_residual(env, mod, device=None):
+    out = np.zeros(4)
+    _check(library().exaadmm_update_residual(mod.handle, _dp(out)), "exaadmm_update_residual")
+    mod.info.primres, mod.info.dualres, mod.info.norm_z_curr, mod.info.mismatch = out
+
+
+def admm_update_lz(env, mod, device=None):
+    mod.sync_params()
+    _check(library().exaadmm_update_lz(mod.handle, env.params.beta), "exaadmm_update_lz")
+
+
+def admm_poststep(env, mod, device=None):
+    v = C.c_double()
+    _check(library().exaadmm_objective(mod.handle, C.byref(v)), "exaadmm_objective")
+    mod.info.objval = v.value
+
+
+def admm_two_level(env, mod, device=None, fused=True):
+    """admm_two_level (algorithms/admm_two_level.jl:1-88).
+    fused=True  : the whole driver runs inside the library (exaadmm_solve_two_level), loop
+                  control on the device.
+    fused=False : this Python loop calls the step-wise entry points exactly in the
+                  reference's order (what the Julia shim does)."""
+    par, info = env.params, mod.info
+    if fused:
+        mod.sync_params()
+        _check(library().exaadmm_solve_two_level(mod.handle, C.byref(info)), "exaadmm_solve_two_level")
+        _check(library().exaadmm_get_params(mod.handle, C.byref(par)), "exaadmm_get_params")
+        return
+    sqrt_d = math.sqrt(mod.nvar)
+    OUTER_TOL = sqrt_d * par.outer_eps
+    C.memset(C.byref(info), 0, C.sizeof(info))
+    info.mismatch = math.inf
+    info.norm_z_prev = info.norm_z_curr = math.inf
+    par.beta = par.initial_beta
+    info.status_code = 0
+    t0 = time.perf_counter()
+    while info.outer < par.outer_iterlim:
+        admm_increment_outer(env, mod, device)
+        admm_outer_prestep(env, mod, device)
+        admm_increment_reset_inner(env, mod, device)
+        while info.inner < par.inner_iterlim:
+            admm_increment_inner(env, mod)
+            admm_inner_prestep(env, mod, device)
+            admm_update_x(env, mod, device)
+            admm_update_xbar(env, mod, device)
+            admm_update_z(env, mod, device)
+            admm_update_l(env, mod, device)
+            admm_update_residual(env, mod, device)
+            info.eps_pri = sqrt_d / (2500 * info.outer)
+            if info.primres <= info.eps_pri:
+                break
+        if info.mismatch <= OUTER_TOL:
+            info.status_code = 1
+            break
+        admm_update_lz(env, mod, device)
+        if info.norm_z_curr > par.theta * info.norm_z_prev:
+            par.beta = min(par.inc_c * par.beta, 1e24)
+    info.time_overall = time.perf_counter() - t0
+    admm_poststep(env, mod, device)
+
+
+def solve_acopf(case, case_format="matpower", outer_iterlim=20, inner_iterlim=1000, rho_pq=400.0,
+                rho_va=40000.0, obj_scale=1.0, scale=1e-4, use_linelimit=True, use_projection=False,
+                tight_factor=1.0, outer_eps=2e-4, gpu_no=0, verbose=0, grid=None, fused=True,
+                check_every=1):
+    """solve_acopf (interface/solve_acopf.jl:1-46), backend fixed to the MI355X library.
+    obj_scale is accepted and, as in the reference (ModelAcopf is built before the parameter
+    is assigned, solve_acopf.jl:33 vs :36), has no effect on the generator costs."""
+    env = AdmmEnv(case, rho_pq, rho_va, case_format=case_format, use_linelimit=use_linelimit,
+                  use_projection=use_projection, tight_factor=tight_factor, gpu_no=gpu_no,
+                  verbose=verbose, grid=grid)
+    mod = ModelAcopf(env)
+    env.params.scale = scale
+    env.params.outer_eps = outer_eps
+    env.params.outer_iterlim = outer_iterlim
+    env.params.inner_iterlim = inner_iterlim
+    env.params.check_every = check_every
+    admm_two_level(env, mod, fused=fused)
+    return env, mod

@@ -1,0 +1,340 @@
+// Per-branch subproblem of the component-based ACOPF ADMM: objective, gradient,
+// Hessian of the branch augmented Lagrangian and the augmented-Lagrangian x TRON
+// loop, one branch per GPU lane.
+//
+// Reference behaviour reproduced (paths under /root/reference/src/models/acopf/):
+//   acopf_eval_linelimit_kernel_gpu.jl:1-49     objective
+//   acopf_eval_linelimit_kernel_gpu.jl:51-187   gradient
+//   acopf_eval_linelimit_kernel_gpu.jl:189-594  dense 6x6 Hessian
+//   acopf_auglag_linelimit_kernel_gpu.jl:76-134 augmented-Lagrangian loop
+//   acopf_tron_linelimit_kernel.jl:44-144       TRON driver constants / control flow
+//
+// The reference expands every derivative term by term (~1500 flops per Hessian,
+// computed redundantly by all 32 threads of a block).  Here the four flows are
+//   phi_k = a_k vi^2 + b_k vj^2 + vi vj E_k(th),  th = ti - tj,
+// with only two independent trig combinations per branch end
+//   E0 = YftR cos + YftI sin,  F0 = dE0/dth,  E2 = YtfR cos - YtfI sin,  F2 = dE2/dth
+// (the q-flows reuse them: E_q = -F_p, F_q = E_p), the Hessian is assembled in
+// the 3 variables (vi, vj, th) from 6 weighted rank-1 terms plus the curvature
+// of the flows, and expanded to (vi, vj, ti, tj) with d/dtj = -d/dti.
+#pragma once
+#include "tron_device.h"
+
+namespace exa {
+
+// Problem constants of one branch.  lam/rho/xt are rows 1-8 / 9-16 / 17-24 of the
+// reference's membuf, ls1/ls2/mu rows 25/26/27 (acopf_auglag_linelimit_kernel_gpu.jl:49-79).
+struct BranchData {
+    double lam[8], rho[8], xt[8];
+    double Y[8];  // YffR YffI YftR YftI YttR YttI YtfR YtfI
+    double ls1, ls2, mu, scale;
+};
+
+// constants of the augmented-Lagrangian loop and of the TRON driver
+struct BranchOptions {
+    int max_auglag;    // Parameters.max_auglag (50)
+    double mu_max;     // Parameters.mu_max (1e8)
+    int max_feval;     // 500   (acopf_auglag_linelimit_kernel_gpu.jl:96)
+    int max_minor;     // 200
+    double gtol;       // 1e-6
+    double frtol;      // 1e-12 (acopf_tron_linelimit_kernel.jl:46-51)
+    double fatol;      // 0
+    double fmin;       // -1e32
+    double cgtol;      // 0.1
+    // mu only takes the values 10^k (k = 1..8) in normal operation; host-computed
+    // mu^0.1 and mu^0.9 for those (same libm as the CPU path), pow() otherwise.
+    double pow10[8], pow01[8], pow09[8];
+};
+
+EXA_HD double mu_pow(const BranchOptions& o, double mu, bool nine)
+{
+    EXA_UNROLL
+    for (int k = 0; k < 8; k++)
+        if (mu == o.pow10[k]) return nine ? o.pow09[k] : o.pow01[k];
+    return pow(mu, nine ? 0.9 : 0.1);
+}
+
+struct FlowTrig {
+    double vi2, vj2, vv, E0, F0, E2, F2;
+};
+
+EXA_HD void flow_trig(const BranchData& d, const double (&x)[6], FlowTrig& t)
+{
+    double sn, cs;
+    sincos(x[2] - x[3], &sn, &cs);
+    t.vi2 = x[0] * x[0];
+    t.vj2 = x[1] * x[1];
+    t.vv = x[0] * x[1];
+    t.E0 = d.Y[2] * cs + d.Y[3] * sn;
+    t.F0 = d.Y[3] * cs - d.Y[2] * sn;
+    t.E2 = d.Y[6] * cs - d.Y[7] * sn;
+    t.F2 = -d.Y[6] * sn - d.Y[7] * cs;
+}
+
+// flows (pij, qij, pji, qji)
+EXA_HD void flows_from_trig(const BranchData& d, const FlowTrig& t, double (&phi)[4])
+{
+    phi[0] = d.Y[0] * t.vi2 + t.vv * t.E0;
+    phi[1] = -d.Y[1] * t.vi2 - t.vv * t.F0;
+    phi[2] = d.Y[4] * t.vj2 + t.vv * t.E2;
+    phi[3] = -d.Y[5] * t.vj2 + t.vv * t.F2;
+}
+
+EXA_HD void branch_flows(const BranchData& d, const double (&x)[6], double (&phi)[4])
+{
+    FlowTrig t;
+    flow_trig(d, x, t);
+    flows_from_trig(d, t, phi);
+}
+
+EXA_HD double objective_from_flows(const BranchData& d, const double (&x)[6], const FlowTrig& t, const double (&phi)[4])
+{
+    const double y[8] = {phi[0], phi[1], phi[2], phi[3], t.vi2, t.vj2, x[2], x[3]};
+    double f = 0.0;
+    EXA_UNROLL
+    for (int k = 0; k < 8; k++) f += d.lam[k] * y[k];
+    EXA_UNROLL
+    for (int k = 0; k < 8; k++) {
+        double e = y[k] - d.xt[k];
+        f += 0.5 * (d.rho[k] * (e * e));
+    }
+    const double c1 = phi[0] * phi[0] + phi[1] * phi[1] + x[4];
+    const double c2 = phi[2] * phi[2] + phi[3] * phi[3] + x[5];
+    f += d.ls1 * c1;
+    f += d.ls2 * c2;
+    f += 0.5 * (d.mu * (c1 * c1));
+    f += 0.5 * (d.mu * (c2 * c2));
+    return f * d.scale;
+}
+
+EXA_HD double branch_f(const BranchData& d, const double (&x)[6])
+{
+    FlowTrig t;
+    double phi[4];
+    flow_trig(d, x, t);
+    flows_from_trig(d, t, phi);
+    return objective_from_flows(d, x, t, phi);
+}
+
+// objective, gradient and packed Hessian at x
+EXA_HD double branch_fgh(const BranchData& d, const double (&x)[6], double (&g)[6], SymMat<6>& A)
+{
+    FlowTrig t;
+    double phi[4];
+    flow_trig(d, x, t);
+    flows_from_trig(d, t, phi);
+    const double f = objective_from_flows(d, x, t, phi);
+
+    const double vi = x[0], vj = x[1], vv = t.vv, sc = d.scale, mu = d.mu;
+    const double E[4] = {t.E0, -t.F0, t.E2, t.F2};
+    const double F[4] = {t.F0, t.E0, t.F2, -t.E2};
+    const double a2[4] = {2 * d.Y[0], -2 * d.Y[1], 0.0, 0.0};  // d2phi/dvi2
+    const double b2[4] = {0.0, 0.0, 2 * d.Y[4], -2 * d.Y[5]};  // d2phi/dvj2
+
+    // Jacobian of the flows in (vi, vj, th)
+    double J[4][3];
+    EXA_UNROLL
+    for (int k = 0; k < 4; k++) {
+        J[k][0] = a2[k] * vi + vj * E[k];
+        J[k][1] = b2[k] * vj + vi * E[k];
+        J[k][2] = vv * F[k];
+    }
+    const double c1 = phi[0] * phi[0] + phi[1] * phi[1] + x[4];
+    const double c2 = phi[2] * phi[2] + phi[3] * phi[3] + x[5];
+    const double m1 = d.ls1 + mu * c1;
+    const double m2 = d.ls2 + mu * c2;
+
+    double w[4], r[4];
+    EXA_UNROLL
+    for (int k = 0; k < 4; k++) {
+        const double mk = (k < 2) ? m1 : m2;
+        w[k] = d.lam[k] + d.rho[k] * (phi[k] - d.xt[k]) + 2 * phi[k] * mk;
+        r[k] = d.rho[k] + 2 * mk;
+    }
+    double d1[3], d2[3], gr[3];
+    EXA_UNROLL
+    for (int i = 0; i < 3; i++) {
+        d1[i] = 2 * (phi[0] * J[0][i] + phi[1] * J[1][i]);
+        d2[i] = 2 * (phi[2] * J[2][i] + phi[3] * J[3][i]);
+        gr[i] = w[0] * J[0][i] + w[1] * J[1][i] + w[2] * J[2][i] + w[3] * J[3][i];
+    }
+    const double wvi = d.lam[4] + d.rho[4] * (t.vi2 - d.xt[4]);
+    const double wvj = d.lam[5] + d.rho[5] * (t.vj2 - d.xt[5]);
+
+    g[0] = sc * (gr[0] + wvi * (2 * vi));
+    g[1] = sc * (gr[1] + wvj * (2 * vj));
+    g[2] = sc * (gr[2] + (d.lam[6] + d.rho[6] * (x[2] - d.xt[6])));
+    g[3] = sc * (-gr[2] + (d.lam[7] + d.rho[7] * (x[3] - d.xt[7])));
+    g[4] = sc * m1;
+    g[5] = sc * m2;
+
+    // reduced 3x3 Hessian in (vi, vj, th): sum_k w_k Hess(phi_k) + sum_k r_k J_k J_k' + mu (d1 d1' + d2 d2')
+    const double WE = w[0] * E[0] + w[1] * E[1] + w[2] * E[2] + w[3] * E[3];
+    const double WF = w[0] * F[0] + w[1] * F[1] + w[2] * F[2] + w[3] * F[3];
+    double Hr[3][3];
+    Hr[0][0] = (w[0] * a2[0] + w[1] * a2[1]) + (2 * wvi + 4 * d.rho[4] * t.vi2);
+    Hr[1][1] = (w[2] * b2[2] + w[3] * b2[3]) + (2 * wvj + 4 * d.rho[5] * t.vj2);
+    Hr[1][0] = WE;
+    Hr[2][0] = vj * WF;
+    Hr[2][1] = vi * WF;
+    Hr[2][2] = -vv * WE;
+    EXA_UNROLL
+    for (int i = 0; i < 3; i++) {
+        EXA_UNROLL
+        for (int j = 0; j <= i; j++) {
+            double s = Hr[i][j];
+            EXA_UNROLL
+            for (int k = 0; k < 4; k++) s += (r[k] * J[k][i]) * J[k][j];
+            s += mu * (d1[i] * d1[j] + d2[i] * d2[j]);
+            Hr[i][j] = s;
+        }
+    }
+    A.lo(0, 0) = sc * Hr[0][0];
+    A.lo(1, 0) = sc * Hr[1][0];
+    A.lo(1, 1) = sc * Hr[1][1];
+    A.lo(2, 0) = sc * Hr[2][0];
+    A.lo(2, 1) = sc * Hr[2][1];
+    A.lo(3, 0) = -(sc * Hr[2][0]);
+    A.lo(3, 1) = -(sc * Hr[2][1]);
+    A.lo(2, 2) = sc * (Hr[2][2] + d.rho[6]);
+    A.lo(3, 2) = -(sc * Hr[2][2]);
+    A.lo(3, 3) = sc * (Hr[2][2] + d.rho[7]);
+    const double smu = sc * mu;
+    A.lo(4, 0) = smu * d1[0];
+    A.lo(4, 1) = smu * d1[1];
+    A.lo(4, 2) = smu * d1[2];
+    A.lo(4, 3) = -(smu * d1[2]);
+    A.lo(4, 4) = smu;
+    A.lo(5, 0) = smu * d2[0];
+    A.lo(5, 1) = smu * d2[1];
+    A.lo(5, 2) = smu * d2[2];
+    A.lo(5, 3) = -(smu * d2[2]);
+    A.lo(5, 4) = 0.0;
+    A.lo(5, 5) = smu;
+    return f;
+}
+
+struct BranchStats {
+    int auglag_it;
+    int minor_it;  // TRON minor iterations summed over the augmented-Lagrangian iterations
+    int ticks;     // trips of the lane's solver loop
+};
+
+// Augmented-Lagrangian x TRON solve of one branch, starting from the feasible x.
+// d.mu must be initialised; d.ls1, d.ls2, d.mu are updated.  phi receives the flows at
+// the final x.  The two nested reference loops (auglag iterations, each a full TRON
+// reverse-communication loop) are flattened into one loop of "ticks": a tick refreshes
+// g, H when the previous tick moved x (or a new subproblem starts), then makes one
+// model step + ratio test.  Lanes of a wavefront therefore stay phase-aligned
+// whatever auglag/TRON iteration each of them is in.
+EXA_HD void branch_solve(BranchData& d, const BranchOptions& o, double (&x)[6], const double (&xl)[6],
+                         const double (&xu)[6], double (&phi)[4], BranchStats& stats)
+{
+    TronState<6> st;
+    SymMat<6> A;
+    double g[6];
+
+    double mu = d.mu;
+    double eta = 1.0 / mu_pow(o, mu, false);
+    int it = 0, minor_total = 0, ticks = 0;
+    bool restart = true, need_gh = true, done = false;
+    const int hard_cap = o.max_auglag * (o.max_feval + o.max_minor + 2) + 8;
+
+    while (!done && ticks < hard_cap) {
+        ticks++;
+        int fin = TRON_RUN;
+        if (need_gh) {
+            if (restart) {
+                // task START: f, g, H at x; delta0 = ||g||  (tron_linelimit_kernel.jl:66-106)
+                it++;
+                st.f = branch_fgh(d, x, g, A);
+                st.delta = nrm2<6>(g);
+                st.iter = 1;
+                st.alphac = 1.0;
+                st.nfev = 1;
+                st.minor_iter = 1;
+                restart = false;
+            } else {
+                // task GH then NEWX  (tron_linelimit_kernel.jl:86-135)
+                (void)branch_fgh(d, x, g, A);
+                st.minor_iter++;
+                if (gpnorm<6>(x, xl, xu, g) <= o.gtol) fin = TRON_CONV;
+                if (st.minor_iter >= o.max_minor) fin = TRON_MAXMINOR;
+            }
+            need_gh = false;
+        }
+        if (fin == TRON_RUN) {
+            tron_compute<6>(st, x, xl, xu, A, g, o.cgtol, 6);
+            const double ftrial = branch_f(d, x);
+            st.nfev++;
+            if (st.nfev >= o.max_feval) {
+                fin = TRON_MAXFEVAL;  // search stops before the ratio test (tron_linelimit_kernel.jl:76-78)
+            } else {
+                int task;
+                const bool success = tron_evaluate<6>(st, ftrial, x, g, o.frtol, o.fatol, o.fmin, task);
+                if (task != TRON_RUN)
+                    fin = task;
+                else
+                    need_gh = success;
+            }
+        }
+        if (fin != TRON_RUN) {
+            // end of one TRON solve: augmented-Lagrangian update
+            // (acopf_auglag_linelimit_kernel_gpu.jl:99-131)
+            minor_total += st.minor_iter;
+            branch_flows(d, x, phi);
+            const double cviol1 = phi[0] * phi[0] + phi[1] * phi[1] + x[4];
+            const double cviol2 = phi[2] * phi[2] + phi[3] * phi[3] + x[5];
+            const double cnorm = fmax(fabs(cviol1), fabs(cviol2));
+            bool terminate = false;
+            if (cnorm <= eta) {
+                if (cnorm <= 1e-6) {
+                    terminate = true;
+                } else {
+                    d.ls1 += mu * cviol1;
+                    d.ls2 += mu * cviol2;
+                    eta = eta / mu_pow(o, mu, true);
+                }
+            } else {
+                mu = fmin(o.mu_max, mu * 10);
+                eta = 1.0 / mu_pow(o, mu, false);
+                d.mu = mu;
+            }
+            if (it >= o.max_auglag) terminate = true;
+            if (terminate) {
+                done = true;
+            } else {
+                restart = true;
+                need_gh = true;
+            }
+        }
+    }
+    d.mu = mu;
+    stats.auglag_it = it;
+    stats.minor_it = minor_total;
+    stats.ticks = ticks;
+}
+
+// bounds + warm start of one branch (acopf_auglag_linelimit_kernel_gpu.jl:34-47)
+// ub: current u of the branch [pij,qij,pji,qji,wi,wj,ti,tj]; bnd: (lo,hi) x (vi,vj,ti,tj); rateA: membuf row 29
+EXA_HD void branch_start(const double (&ub)[8], const double (&bnd)[8], double rateA, double (&x)[6],
+                         double (&xl)[6], double (&xu)[6])
+{
+    EXA_UNROLL
+    for (int k = 0; k < 4; k++) {
+        xl[k] = bnd[2 * k];
+        xu[k] = bnd[2 * k + 1];
+    }
+    xl[4] = -rateA;
+    xu[4] = 0.0;
+    xl[5] = -rateA;
+    xu[5] = 0.0;
+    x[0] = fmin(xu[0], fmax(xl[0], sqrt(ub[4])));
+    x[1] = fmin(xu[1], fmax(xl[1], sqrt(ub[5])));
+    x[2] = fmin(xu[2], fmax(xl[2], ub[6]));
+    x[3] = fmin(xu[3], fmax(xl[3], ub[7]));
+    x[4] = fmin(xu[4], fmax(xl[4], -(ub[0] * ub[0] + ub[1] * ub[1])));
+    x[5] = fmin(xu[5], fmax(xl[5], -(ub[2] * ub[2] + ub[3] * ub[3])));
+}
+
+}  // namespace exa

@@ -1,0 +1,969 @@
+// libexaadmm_hip.so -- host side of the C ABI declared in include/exaadmm_hip.h.
+// Handle management, reference-layout <-> SoA conversion, one entry point per plugin step
+// of the reference (docs/src/dev.md:65-155) and the fused device-resident loops.
+// There is NO CPU execution path in this library: without a gfx950 device every compute
+// entry point fails with EXAADMM_ERR_NO_DEVICE.
+#include "exaadmm_hip.h"
+#include "kernels.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace exa;
+
+static thread_local std::string g_err;
+
+static void set_err(const char* fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+#define HIPCHK(expr)                                                                        \
+    do {                                                                                    \
+        hipError_t e__ = (expr);                                                            \
+        if (e__ != hipSuccess) {                                                            \
+            set_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return EXAADMM_ERR_HIP;                                                         \
+        }                                                                                   \
+    } while (0)
+
+#define REQUIRE(cond, msg)            \
+    do {                              \
+        if (!(cond)) {                \
+            set_err("%s", msg);       \
+            return EXAADMM_ERR_INVALID; \
+        }                             \
+    } while (0)
+
+static inline int round_up(int n, int m) { return ((n + m - 1) / m) * m; }
+
+// host-side data needed only by init_solution! (model construction)
+struct InitData {
+    std::vector<double> Vmin, Vmax, pgmin, pgmax, qgmin, qgmax, Y[8];
+    std::vector<int> brBus;
+};
+
+struct HaloSlot {
+    int* d_idx = nullptr;
+    int count = 0;
+};
+
+struct exaadmm_handle {
+    int device = 0;
+    int G = 0, L = 0, B = 0, Gp = 0, Lp = 0, N = 0;
+    int64_t nvar = 0;
+    double baseMVA = 100.0;
+    exaadmm_params par;
+    Dev d;
+    BranchOptions bo;
+    Ctrl* d_ctrl = nullptr;
+    double* d_sums = nullptr;  // 4 doubles
+    Ctrl* h_ctrl = nullptr;    // pinned
+    double* h_sums = nullptr;  // pinned, 4 doubles
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    int ew_blocks = 1;
+    std::vector<void*> allocs;
+    std::vector<double> c2, c1, c0;  // host copies for the objective
+    std::vector<double> stage;       // host staging, N doubles
+    std::vector<double> rateA_h;
+    unsigned char* d_owned = nullptr;
+    HaloSlot halo[8];
+    bool residual_vectors_valid = false;
+    exaadmm_info info;
+    std::vector<hipEvent_t> ev;
+    InitData init;
+};
+
+static int attach_init_data(exaadmm_handle* h, const exaadmm_grid* g);
+
+template <class T>
+static int dev_alloc(exaadmm_handle* h, T** p, size_t n)
+{
+    void* q = nullptr;
+    HIPCHK(hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)));
+    h->allocs.push_back(q);
+    *p = static_cast<T*>(q);
+    return 0;
+}
+
+// reference index (0-based) -> SoA index
+static inline int soa_index(const exaadmm_handle* h, int64_t r)
+{
+    if (r < 2 * (int64_t)h->G) return (int)((r & 1) * h->Gp + (r >> 1));
+    const int64_t q = r - 2 * (int64_t)h->G;
+    return (int)(2 * h->Gp + (q & 7) * h->Lp + (q >> 3));
+}
+
+static void ref_to_soa(const exaadmm_handle* h, const double* ref, double* soa, double pad)
+{
+    for (int i = 0; i < h->N; i++) soa[i] = pad;
+    for (int i = 0; i < h->G; i++) {
+        soa[i] = ref[2 * i];
+        soa[h->Gp + i] = ref[2 * i + 1];
+    }
+    const double* rb = ref + 2 * (size_t)h->G;
+    for (int k = 0; k < 8; k++) {
+        double* plane = soa + 2 * h->Gp + (size_t)k * h->Lp;
+        for (int b = 0; b < h->L; b++) plane[b] = rb[8 * (size_t)b + k];
+    }
+}
+
+static void soa_to_ref(const exaadmm_handle* h, const double* soa, double* ref)
+{
+    for (int i = 0; i < h->G; i++) {
+        ref[2 * i] = soa[i];
+        ref[2 * i + 1] = soa[h->Gp + i];
+    }
+    double* rb = ref + 2 * (size_t)h->G;
+    for (int k = 0; k < 8; k++) {
+        const double* plane = soa + 2 * h->Gp + (size_t)k * h->Lp;
+        for (int b = 0; b < h->L; b++) rb[8 * (size_t)b + k] = plane[b];
+    }
+}
+
+static double* vec_ptr(exaadmm_handle* h, int which)
+{
+    switch (which) {
+        case EXAADMM_U_CURR: return h->d.u;
+        case EXAADMM_V_CURR: return h->d.v;
+        case EXAADMM_L_CURR: return h->d.l;
+        case EXAADMM_RHO: return h->d.rho;
+        case EXAADMM_RD: return h->d.rd;
+        case EXAADMM_RP: return h->d.rp;
+        case EXAADMM_Z_CURR: return h->d.z;
+        case EXAADMM_Z_PREV: return h->d.zp;
+        case EXAADMM_LZ: return h->d.lz;
+        case EXAADMM_AX_PLUS_BY: return h->d.ax;
+        default: return nullptr;
+    }
+}
+
+extern "C" const char* exaadmm_version(void) { return "exaadmm-hip 0.1 (gfx950)"; }
+extern "C" const char* exaadmm_last_error(void) { return g_err.c_str(); }
+
+extern "C" void exaadmm_default_params(exaadmm_params* p)
+{
+    // src/utils/environment.jl:43-75
+    p->mu_max = 1e8;
+    p->max_auglag = 50;
+    p->initial_beta = 1e3;
+    p->beta = 1e3;
+    p->inc_c = 6.0;
+    p->theta = 0.8;
+    p->outer_eps = 2e-4;
+    p->MAX_MULTIPLIER = 1e12;
+    p->outer_iterlim = 20;
+    p->inner_iterlim = 1000;
+    p->scale = 1e-4;
+    p->verbose = 0;
+    p->check_every = 1;
+}
+
+static void fill_branch_options(exaadmm_handle* h)
+{
+    BranchOptions& o = h->bo;
+    o.max_auglag = h->par.max_auglag;
+    o.mu_max = h->par.mu_max;
+    o.max_feval = 500;  // acopf_auglag_linelimit_kernel_gpu.jl:96
+    o.max_minor = 200;
+    o.gtol = 1e-6;
+    o.frtol = 1e-12;    // acopf_tron_linelimit_kernel.jl:46-51
+    o.fatol = 0.0;
+    o.fmin = -1e32;
+    o.cgtol = 0.1;
+    double p = 1.0;
+    for (int k = 0; k < 8; k++) {
+        p *= 10.0;
+        o.pow10[k] = p;
+        o.pow01[k] = pow(p, 0.1);
+        o.pow09[k] = pow(p, 0.9);
+    }
+}
+
+template <class T>
+static int upload_vec(exaadmm_handle* h, T* dst, const std::vector<T>& src)
+{
+    if (!src.empty()) HIPCHK(hipMemcpy(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+static int build_csr(exaadmm_handle* h, const int64_t* start, const int64_t* idx, int base, int nbus, int64_t nnz_expected,
+                     const int** d_start, const int** d_idx, int idx_limit)
+{
+    std::vector<int> s(nbus + 1), ix((size_t)std::max<int64_t>(nnz_expected, 0));
+    for (int i = 0; i <= nbus; i++) s[i] = (int)(start[i] - base);
+    if (s[0] != 0 || s[nbus] != nnz_expected) {
+        set_err("CSR start array inconsistent (first=%d last=%d expected nnz=%lld)", s[0], s[nbus], (long long)nnz_expected);
+        return EXAADMM_ERR_INVALID;
+    }
+    for (int64_t k = 0; k < nnz_expected; k++) {
+        ix[k] = (int)(idx[k] - base);
+        if (ix[k] < 0 || ix[k] >= idx_limit) {
+            set_err("CSR index out of range");
+            return EXAADMM_ERR_INVALID;
+        }
+    }
+    int *ds = nullptr, *di = nullptr;
+    int rc;
+    if ((rc = dev_alloc(h, &ds, s.size()))) return rc;
+    if ((rc = dev_alloc(h, &di, ix.size()))) return rc;
+    if ((rc = upload_vec(h, ds, s))) return rc;
+    if ((rc = upload_vec(h, di, ix))) return rc;
+    *d_start = ds;
+    *d_idx = di;
+    return 0;
+}
+
+extern "C" int exaadmm_create(const exaadmm_grid* g, const exaadmm_params* p, int device_id, exaadmm_handle** out)
+{
+    REQUIRE(g && out, "null argument");
+    REQUIRE(g->ngen >= 0 && g->nline > 0 && g->nbus > 0, "empty grid");
+    REQUIRE(g->index_base == 0 || g->index_base == 1, "index_base must be 0 or 1");
+    REQUIRE(2 * g->ngen + 8 * g->nline < (int64_t)2000000000, "grid too large for 32-bit device indices");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_err("no HIP device visible: this backend has no CPU fallback");
+        return EXAADMM_ERR_NO_DEVICE;
+    }
+    REQUIRE(device_id >= 0 && device_id < ndev, "device_id out of range");
+    HIPCHK(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_err("device %d is %s; this library carries gfx950 (MI355X) code only", device_id, prop.gcnArchName);
+        return EXAADMM_ERR_NO_DEVICE;
+    }
+
+    exaadmm_handle* h = new exaadmm_handle();
+    h->device = device_id;
+    h->G = (int)g->ngen;
+    h->L = (int)g->nline;
+    h->B = (int)g->nbus;
+    h->Gp = round_up(std::max(h->G, 1), 64);
+    h->Lp = round_up(h->L, 64);
+    h->N = 2 * h->Gp + 8 * h->Lp;
+    h->nvar = 2 * (int64_t)h->G + 8 * (int64_t)h->L;
+    h->baseMVA = g->baseMVA;
+    if (p)
+        h->par = *p;
+    else
+        exaadmm_default_params(&h->par);
+    fill_branch_options(h);
+    memset(&h->info, 0, sizeof(h->info));
+    memset(&h->d, 0, sizeof(h->d));
+    Dev& d = h->d;
+    d.G = h->G; d.L = h->L; d.B = h->B; d.Gp = h->Gp; d.Lp = h->Lp; d.N = h->N;
+    const int base = g->index_base;
+    int rc = 0;
+#define TRY(x) do { if ((rc = (x))) { exaadmm_destroy(h); return rc; } } while (0)
+    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        set_err("hipStreamCreate failed");
+        delete h;
+        return EXAADMM_ERR_HIP;
+    }
+    h->stream = h->own_stream;
+
+    double** svecs[] = {&d.u, &d.v, &d.z, &d.zp, &d.l, &d.lz, &d.rho, &d.rp, &d.rd, &d.ax};
+    for (auto pp : svecs) {
+        TRY(dev_alloc(h, pp, (size_t)h->N));
+        if (hipMemset(*pp, 0, (size_t)h->N * sizeof(double)) != hipSuccess) { set_err("hipMemset failed"); exaadmm_destroy(h); return EXAADMM_ERR_HIP; }
+    }
+    h->stage.assign(h->N, 0.0);
+
+    // branch constants -> planes
+    {
+        std::vector<double> Y((size_t)8 * h->Lp, 0.0), bnd((size_t)8 * h->Lp, 0.0), rate(h->Lp, 0.0);
+        const double* Ysrc[8] = {g->YffR, g->YffI, g->YftR, g->YftI, g->YttR, g->YttI, g->YtfR, g->YtfI};
+        const double* Bsrc[4] = {g->FrVmBound, g->ToVmBound, g->FrVaBound, g->ToVaBound};
+        for (int k = 0; k < 8; k++)
+            for (int b = 0; b < h->L; b++) Y[(size_t)k * h->Lp + b] = Ysrc[k][b];
+        for (int k = 0; k < 4; k++)
+            for (int b = 0; b < h->L; b++) {
+                bnd[(size_t)(2 * k) * h->Lp + b] = Bsrc[k][2 * b];
+                bnd[(size_t)(2 * k + 1) * h->Lp + b] = Bsrc[k][2 * b + 1];
+            }
+        for (int b = 0; b < h->L; b++) rate[b] = g->rateA[b];
+        h->rateA_h.assign(g->rateA, g->rateA + h->L);
+        double *dY, *dB, *dR;
+        TRY(dev_alloc(h, &dY, Y.size()));
+        TRY(dev_alloc(h, &dB, bnd.size()));
+        TRY(dev_alloc(h, &dR, rate.size()));
+        TRY(upload_vec(h, dY, Y));
+        TRY(upload_vec(h, dB, bnd));
+        TRY(upload_vec(h, dR, rate));
+        d.Y = dY; d.bnd = dB; d.rateA = dR;
+        TRY(dev_alloc(h, &d.ls1, (size_t)h->Lp));
+        TRY(dev_alloc(h, &d.ls2, (size_t)h->Lp));
+        TRY(dev_alloc(h, &d.mu, (size_t)h->Lp));
+        std::vector<double> zeros(h->Lp, 0.0);
+        TRY(upload_vec(h, d.ls1, zeros));
+        TRY(upload_vec(h, d.ls2, zeros));
+        TRY(upload_vec(h, d.mu, zeros));
+        TRY(dev_alloc(h, &d.st_auglag, (size_t)h->Lp));
+        TRY(dev_alloc(h, &d.st_minor, (size_t)h->Lp));
+        TRY(dev_alloc(h, &d.st_ticks, (size_t)h->Lp));
+        hipMemset(d.st_auglag, 0, h->Lp * sizeof(int));
+        hipMemset(d.st_minor, 0, h->Lp * sizeof(int));
+        hipMemset(d.st_ticks, 0, h->Lp * sizeof(int));
+    }
+    // generator constants
+    {
+        const double* src[6] = {g->pgmin, g->pgmax, g->qgmin, g->qgmax, g->c2, g->c1};
+        const double** dst[6] = {&d.pgmin, &d.pgmax, &d.qgmin, &d.qgmax, &d.c2, &d.c1};
+        for (int k = 0; k < 6; k++) {
+            std::vector<double> t(h->Gp, 0.0);
+            for (int i = 0; i < h->G; i++) t[i] = src[k][i];
+            double* dp;
+            TRY(dev_alloc(h, &dp, t.size()));
+            TRY(upload_vec(h, dp, t));
+            *dst[k] = dp;
+        }
+        h->c2.assign(g->c2, g->c2 + h->G);
+        h->c1.assign(g->c1, g->c1 + h->G);
+        h->c0.assign(g->c0, g->c0 + h->G);
+    }
+    // bus constants + CSR
+    {
+        const double* src[4] = {g->Pd, g->Qd, g->YshR, g->YshI};
+        const double** dst[4] = {&d.Pd, &d.Qd, &d.YshR, &d.YshI};
+        for (int k = 0; k < 4; k++) {
+            std::vector<double> t(src[k], src[k] + h->B);
+            double* dp;
+            TRY(dev_alloc(h, &dp, t.size()));
+            TRY(upload_vec(h, dp, t));
+            *dst[k] = dp;
+        }
+        TRY(build_csr(h, g->FrStart, g->FrIdx, base, h->B, h->L, &d.FrStart, &d.FrIdx, h->L));
+        TRY(build_csr(h, g->ToStart, g->ToIdx, base, h->B, h->L, &d.ToStart, &d.ToIdx, h->L));
+        TRY(build_csr(h, g->GenStart, g->GenIdx, base, h->B, h->G, &d.GenStart, &d.GenIdx, std::max(h->G, 1)));
+    }
+    // reduction scratch + loop control
+    h->ew_blocks = std::min(2048, std::max(1, (h->N + EW_BLOCK - 1) / EW_BLOCK));
+    TRY(dev_alloc(h, &d.partials, (size_t)h->ew_blocks * 4));
+    TRY(dev_alloc(h, &h->d_ctrl, 1));
+    TRY(dev_alloc(h, &h->d_sums, 4));
+    if (hipHostMalloc((void**)&h->h_ctrl, sizeof(Ctrl), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&h->h_sums, 4 * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+        set_err("hipHostMalloc failed");
+        exaadmm_destroy(h);
+        return EXAADMM_ERR_HIP;
+    }
+    memset(h->h_ctrl, 0, sizeof(Ctrl));
+    TRY(attach_init_data(h, g));
+#undef TRY
+    *out = h;
+    return EXAADMM_OK;
+}
+
+extern "C" int exaadmm_destroy(exaadmm_handle* h)
+{
+    if (!h) return EXAADMM_OK;
+    hipSetDevice(h->device);
+    if (h->own_stream) hipStreamSynchronize(h->own_stream);
+    for (void* p : h->allocs) hipFree(p);
+    for (auto& s : h->halo)
+        if (s.d_idx) hipFree(s.d_idx);
+    if (h->d_owned) hipFree(h->d_owned);
+    if (h->h_ctrl) hipHostFree(h->h_ctrl);
+    if (h->h_sums) hipHostFree(h->h_sums);
+    for (auto e : h->ev) hipEventDestroy(e);
+    if (h->own_stream) hipStreamDestroy(h->own_stream);
+    delete h;
+    return EXAADMM_OK;
+}
+
+extern "C" int exaadmm_set_params(exaadmm_handle* h, const exaadmm_params* p)
+{
+    REQUIRE(h && p, "null argument");
+    h->par = *p;
+    fill_branch_options(h);
+    return EXAADMM_OK;
+}
+
+extern "C" int exaadmm_get_params(exaadmm_handle* h, exaadmm_params* p)
+{
+    REQUIRE(h && p, "null argument");
+    *p = h->par;
+    return EXAADMM_OK;
+}
+
+extern "C" int64_t exaadmm_nvar(exaadmm_handle* h) { return h ? h->nvar : -1; }
+
+extern "C" int exaadmm_set_stream(exaadmm_handle* h, void* hip_stream)
+{
+    REQUIRE(h, "null handle");
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return EXAADMM_OK;
+}
+
+// ------------------------------------------------------------------ host <-> device
+extern "C" int exaadmm_upload_solution(exaadmm_handle* h, int which, const double* host, int64_t n)
+{
+    REQUIRE(h && host, "null argument");
+    REQUIRE(n == h->nvar, "vector length must be nvar = 2*ngen + 8*nline");
+    double* dst = vec_ptr(h, which);
+    REQUIRE(dst, "unknown vector id");
+    HIPCHK(hipSetDevice(h->device));
+    ref_to_soa(h, host, h->stage.data(), which == EXAADMM_RHO ? 1.0 : 0.0);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(dst, h->stage.data(), (size_t)h->N * sizeof(double), hipMemcpyHostToDevice));
+    return EXAADMM_OK;
+}
+
+static int materialize_if_needed(exaadmm_handle* h)
+{
+    if (!h->residual_vectors_valid) {
+        hipLaunchKernelGGL(k_materialize, dim3(h->ew_blocks), dim3(EW_BLOCK), 0, h->stream, h->d);
+        HIPCHK(hipGetLastError());
+        h->residual_vectors_valid = true;
+    }
+    return 0;
+}
+
+extern "C" int exaadmm_download_solution(exaadmm_handle* h, int which, double* host, int64_t n)
+{
+    REQUIRE(h && host, "null argument");
+    REQUIRE(n == h->nvar, "vector length must be nvar = 2*ngen + 8*nline");
+    double* src = vec_ptr(h, which);
+    REQUIRE(src, "unknown vector id");
+    HIPCHK(hipSetDevice(h->device));
+    if (which == EXAADMM_RP || which == EXAADMM_RD || which == EXAADMM_AX_PLUS_BY) {
+        int rc = materialize_if_needed(h);
+        if (rc) return rc;
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(h->stage.data(), src, (size_t)h->N * sizeof(double), hipMemcpyDeviceToHost));
+    soa_to_ref(h, h->stage.data(), host);
+    return EXAADMM_OK;
+}
+
+extern "C" int exaadmm_upload_membuf(exaadmm_handle* h, const double* host, int64_t nrow, int64_t nline)
+{
+    REQUIRE(h && host, "null argument");
+    REQUIRE(nrow == 31 && nline == h->L, "membuf must be 31 x nline");
+    HIPCHK(hipSetDevice(h->device));
+    std::vector<double> a(h->Lp, 0.0), b(h->Lp, 0.0), c(h->Lp, 0.0), r(h->Lp, 0.0);
+    for (int i = 0; i < h->L; i++) {
+        a[i] = host[24 + 31 * (size_t)i];
+        b[i] = host[25 + 31 * (size_t)i];
+        c[i] = host[26 + 31 * (size_t)i];
+        r[i] = host[28 + 31 * (size_t)i];
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(h->d.ls1, a.data(), a.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d.ls2, b.data(), b.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d.mu, c.data(), c.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(const_cast<double*>(h->d.rateA), r.data(), r.size() * sizeof(double), hipMemcpyHostToDevice));
+    return EXAADMM_OK;
+}
+
+extern "C" int exaadmm_download_membuf(exaadmm_handle* h, double* host, int64_t nrow, int64_t nline)
+{
+    REQUIRE(h && host, "null argument");
+    REQUIRE(nrow == 31 && nline == h->L, "membuf must be 31 x nline");
+    HIPCHK(hipSetDevice(h->device));
+    std::vector<double> a(h->Lp), b(h->Lp), c(h->Lp), r(h->Lp);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(a.data(), h->d.ls1, a.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(b.data(), h->d.ls2, b.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(c.data(), h->d.mu, c.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(r.data(), h->d.rateA, r.size() * sizeof(double), hipMemcpyDeviceToHost));
+    memset(host, 0, sizeof(double) * 31 * (size_t)h->L);
+    for (int i = 0; i < h->L; i++) {
+        host[24 + 31 * (size_t)i] = a[i];
+        host[25 + 31 * (size_t)i] = b[i];
+        host[26 + 31 * (size_t)i] = c[i];
+        host[28 + 31 * (size_t)i] = r[i];
+    }
+    return EXAADMM_OK;
+}
+
+extern "C" int exaadmm_set_load(exaadmm_handle* h, const double* Pd, const double* Qd, int64_t nbus)
+{
+    REQUIRE(h && Pd && Qd, "null argument");
+    REQUIRE(nbus == h->B, "nbus mismatch");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(const_cast<double*>(h->d.Pd), Pd, (size_t)h->B * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(const_cast<double*>(h->d.Qd), Qd, (size_t)h->B * sizeof(double), hipMemcpyHostToDevice));
+    return EXAADMM_OK;
+}
+
+extern "C" int exaadmm_set_pg_bounds(exaadmm_handle* h, const double* lo, const double* hi, int64_t ngen)
+{
+    REQUIRE(h && lo && hi, "null argument");
+    REQUIRE(ngen == h->G, "ngen mismatch");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(const_cast<double*>(h->d.pgmin), lo, (size_t)h->G * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(const_cast<double*>(h->d.pgmax), hi, (size_t)h->G * sizeof(double), hipMemcpyHostToDevice));
+    return EXAADMM_OK;
+}
+
+// init_solution! is model construction (runs once): computed on the host in the reference
+// layout, then uploaded.  acopf_init_solution_cpu.jl:1-45 / acopf_model.jl:61-64,87-89.
+static int attach_init_data(exaadmm_handle* h, const exaadmm_grid* g)
+{
+    InitData* id = &h->init;
+    id->Vmin.assign(g->Vmin, g->Vmin + h->B);
+    id->Vmax.assign(g->Vmax, g->Vmax + h->B);
+    id->pgmin.assign(g->pgmin, g->pgmin + h->G);
+    id->pgmax.assign(g->pgmax, g->pgmax + h->G);
+    id->qgmin.assign(g->qgmin, g->qgmin + h->G);
+    id->qgmax.assign(g->qgmax, g->qgmax + h->G);
+    const double* Ysrc[8] = {g->YffR, g->YffI, g->YftR, g->YftI, g->YttR, g->YttI, g->YtfR, g->YtfI};
+    for (int k = 0; k < 8; k++) id->Y[k].assign(Ysrc[k], Ysrc[k] + h->L);
+    id->brBus.resize(2 * (size_t)h->L);
+    for (size_t i = 0; i < id->brBus.size(); i++) {
+        id->brBus[i] = (int)(g->brBusIdx[i] - g->index_base);
+        REQUIRE(id->brBus[i] >= 0 && id->brBus[i] < h->B, "brBusIdx out of range");
+    }
+    return EXAADMM_OK;
+}
+
+extern "C" int exaadmm_init_solution(exaadmm_handle* h, double rho_pq, double rho_va)
+{
+    REQUIRE(h, "null handle");
+    InitData* id = &h->init;
+    HIPCHK(hipSetDevice(h->device));
+    const int64_t nvar = h->nvar;
+    std::vector<double> zero(nvar, 0.0), v(nvar, 0.0), rho(nvar, rho_pq);
+    for (int g = 0; g < h->G; g++) {
+        v[2 * g] = 0.5 * (id->pgmin[g] + id->pgmax[g]);
+        v[2 * g + 1] = 0.5 * (id->qgmin[g] + id->qgmax[g]);
+    }
+    for (int l = 0; l < h->L; l++) {
+        const int fr = id->brBus[2 * l], to = id->brBus[2 * l + 1];
+        const double wij0 = (id->Vmax[fr] * id->Vmax[fr] + id->Vmin[fr] * id->Vmin[fr]) / 2;
+        const double wji0 = (id->Vmax[to] * id->Vmax[to] + id->Vmin[to] * id->Vmin[to]) / 2;
+        const double wR0 = sqrt(wij0 * wji0);
+        const size_t p = 2 * (size_t)h->G + 8 * (size_t)l;
+        v[p] = id->Y[0][l] * wij0 + id->Y[2][l] * wR0;
+        v[p + 1] = -id->Y[1][l] * wij0 - id->Y[3][l] * wR0;
+        v[p + 2] = id->Y[4][l] * wji0 + id->Y[6][l] * wR0;
+        v[p + 3] = -id->Y[5][l] * wji0 - id->Y[7][l] * wR0;
+        v[p + 4] = wij0;
+        v[p + 5] = wji0;
+        for (int k = 4; k < 8; k++) rho[p + k] = rho_va;
+    }
+    int rc;
+    const int zeros[] = {EXAADMM_U_CURR, EXAADMM_L_CURR, EXAADMM_RD, EXAADMM_RP, EXAADMM_Z_CURR,
+                         EXAADMM_Z_PREV, EXAADMM_LZ, EXAADMM_AX_PLUS_BY};
+    for (int w : zeros)
+        if ((rc = exaadmm_upload_solution(h, w, zero.data(), nvar))) return rc;
+    if ((rc = exaadmm_upload_solution(h, EXAADMM_V_CURR, v.data(), nvar))) return rc;
+    if ((rc = exaadmm_upload_solution(h, EXAADMM_RHO, rho.data(), nvar))) return rc;
+    std::vector<double> mb(31 * (size_t)h->L, 0.0);
+    for (int l = 0; l < h->L; l++) mb[28 + 31 * (size_t)l] = h->rateA_h[l];
+    if ((rc = exaadmm_upload_membuf(h, mb.data(), 31, h->L))) return rc;
+    if (h->G > 0 && (rc = exaadmm_set_pg_bounds(h, id->pgmin.data(), id->pgmax.data(), h->G))) return rc;
+    h->residual_vectors_valid = true;
+    return EXAADMM_OK;
+}
+
+// ------------------------------------------------------------------ launches
+static inline dim3 grid_for(int n, int block) { return dim3((unsigned)std::max(1, (n + block - 1) / block)); }
+
+static void launch_gen(exaadmm_handle* h, const Ctrl* c)
+{
+    if (h->G > 0) hipLaunchKernelGGL(k_generator, grid_for(h->G, 64), dim3(64), 0, h->stream, h->d, h->baseMVA, c);
+}
+static void launch_branch(exaadmm_handle* h, int major_iter, const Ctrl* c)
+{
+    hipLaunchKernelGGL(k_branch, grid_for(h->L, BR_BLOCK), dim3(BR_BLOCK), 0, h->stream, h->d, h->bo, h->par.scale, major_iter, c);
+}
+static void launch_bus(exaadmm_handle* h, const Ctrl* c)
+{
+    hipLaunchKernelGGL(k_bus, grid_for(h->B, 64), dim3(64), 0, h->stream, h->d, h->baseMVA, c);
+}
+static void launch_fused_zl(exaadmm_handle* h, double beta, const Ctrl* c)
+{
+    hipLaunchKernelGGL(k_fused_zl, dim3(h->ew_blocks), dim3(EW_BLOCK), 0, h->stream, h->d, beta, c);
+}
+static void launch_final(exaadmm_handle* h, Ctrl* c)
+{
+    hipLaunchKernelGGL(k_final_reduce, dim3(1), dim3(EW_BLOCK), 0, h->stream, h->d.partials, h->ew_blocks, h->d_sums, c);
+}
+
+static int sync_check(exaadmm_handle* h)
+{
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+static int fetch_sums(exaadmm_handle* h, double out[4], bool take_sqrt)
+{
+    HIPCHK(hipMemcpyAsync(h->h_sums, h->d_sums, 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    int rc = sync_check(h);
+    if (rc) return rc;
+    for (int j = 0; j < 4; j++) out[j] = take_sqrt ? sqrt(h->h_sums[j]) : h->h_sums[j];
+    return 0;
+}
+
+// ------------------------------------------------------------------ step-wise plugin surface
+extern "C" int exaadmm_inner_prestep(exaadmm_handle* h)
+{
+    REQUIRE(h, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_copy_z, dim3(h->ew_blocks), dim3(EW_BLOCK), 0, h->stream, h->d);
+    h->residual_vectors_valid = false;
+    return sync_check(h);
+}
+
+extern "C" int exaadmm_update_x_gen(exaadmm_handle* h)
+{
+    REQUIRE(h, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    launch_gen(h, nullptr);
+    h->residual_vectors_valid = false;
+    return sync_check(h);
+}
+
+extern "C" int exaadmm_update_x_line(exaadmm_handle* h, int major_iter)
+{
+    REQUIRE(h, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    launch_branch(h, major_iter, nullptr);
+    h->residual_vectors_valid = false;
+    return sync_check(h);
+}
+
+extern "C" int exaadmm_update_x(exaadmm_handle* h, int major_iter)
+{
+    REQUIRE(h, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    launch_gen(h, nullptr);
+    launch_branch(h, major_iter, nullptr);
+    h->residual_vectors_valid = false;
+    return sync_check(h);
+}
+
+extern "C" int exaadmm_update_xbar(exaadmm_handle* h)
+{
+    REQUIRE(h, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    launch_bus(h, nullptr);
+    h->residual_vectors_valid = false;
+    return sync_check(h);
+}
+
+extern "C" int exaadmm_update_z(exaadmm_handle* h, double beta)
+{
+    REQUIRE(h, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_update_z, dim3(h->ew_blocks), dim3(EW_BLOCK), 0, h->stream, h->d, beta);
+    h->residual_vectors_valid = false;
+    return sync_check(h);
+}
+
+extern "C" int exaadmm_update_l(exaadmm_handle* h, double beta)
+{
+    REQUIRE(h, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_update_l, dim3(h->ew_blocks), dim3(EW_BLOCK), 0, h->stream, h->d, beta);
+    return sync_check(h);
+}
+
+extern "C" int exaadmm_update_lz(exaadmm_handle* h, double beta)
+{
+    REQUIRE(h, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_update_lz, dim3(h->ew_blocks), dim3(EW_BLOCK), 0, h->stream, h->d, beta, h->par.MAX_MULTIPLIER);
+    return sync_check(h);
+}
+
+extern "C" int exaadmm_update_residual(exaadmm_handle* h, double out[4])
+{
+    REQUIRE(h && out, "null argument");
+    HIPCHK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_residual, dim3(h->ew_blocks), dim3(EW_BLOCK), 0, h->stream, h->d);
+    launch_final(h, nullptr);
+    h->residual_vectors_valid = true;
+    return fetch_sums(h, out, true);
+}
+
+extern "C" int exaadmm_residual_partial_sums(exaadmm_handle* h, double** dev_ptr)
+{
+    REQUIRE(h && dev_ptr, "null argument");
+    HIPCHK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_residual, dim3(h->ew_blocks), dim3(EW_BLOCK), 0, h->stream, h->d);
+    launch_final(h, nullptr);
+    h->residual_vectors_valid = true;
+    HIPCHK(hipGetLastError());
+    *dev_ptr = h->d_sums;
+    return EXAADMM_OK;
+}
+
+extern "C" int exaadmm_update_zl_partial(exaadmm_handle* h, double beta, double** dev_sums)
+{
+    REQUIRE(h && dev_sums, "null argument");
+    HIPCHK(hipSetDevice(h->device));
+    launch_fused_zl(h, beta, nullptr);
+    launch_final(h, nullptr);
+    h->residual_vectors_valid = false;
+    HIPCHK(hipGetLastError());
+    *dev_sums = h->d_sums;
+    return EXAADMM_OK;
+}
+
+extern "C" int exaadmm_norm_z(exaadmm_handle* h, double* out)
+{
+    REQUIRE(h && out, "null argument");
+    HIPCHK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_sumsq_z, dim3(h->ew_blocks), dim3(EW_BLOCK), 0, h->stream, h->d);
+    launch_final(h, nullptr);
+    double s[4];
+    int rc = fetch_sums(h, s, true);
+    if (rc) return rc;
+    *out = s[2];
+    return EXAADMM_OK;
+}
+
+extern "C" int exaadmm_objective(exaadmm_handle* h, double* out)
+{
+    // admm_poststep (acopf_admm_prepoststep_cpu.jl:42-45): sum_g c2 (M pg)^2 + c1 (M pg) + c0
+    REQUIRE(h && out, "null argument");
+    HIPCHK(hipSetDevice(h->device));
+    std::vector<double> pg(std::max(h->G, 1));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->G > 0) HIPCHK(hipMemcpy(pg.data(), h->d.u, (size_t)h->G * sizeof(double), hipMemcpyDeviceToHost));
+    double obj = 0.0;
+    for (int g = 0; g < h->G; g++) {
+        const double p = h->baseMVA * pg[g];
+        obj += h->c2[g] * (p * p) + h->c1[g] * p + h->c0[g];
+    }
+    *out = obj;
+    return EXAADMM_OK;
+}
+
+extern "C" int exaadmm_branch_stats(exaadmm_handle* h, double* avg_auglag_it, double* avg_minor_it)
+{
+    REQUIRE(h, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    std::vector<int> a(h->L), m(h->L);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(a.data(), h->d.st_auglag, (size_t)h->L * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(m.data(), h->d.st_minor, (size_t)h->L * sizeof(int), hipMemcpyDeviceToHost));
+    double sa = 0.0, sm = 0.0;
+    for (int i = 0; i < h->L; i++) {
+        sa += a[i];
+        sm += a[i] > 0 ? (double)m[i] / a[i] : 0.0;
+    }
+    if (avg_auglag_it) *avg_auglag_it = sa / h->L;
+    if (avg_minor_it) *avg_minor_it = sm / h->L;
+    return EXAADMM_OK;
+}
+
+// ------------------------------------------------------------------ fused loops
+static void enqueue_iteration(exaadmm_handle* h, Ctrl* c)
+{
+    launch_gen(h, c);
+    launch_branch(h, 0, c);
+    launch_bus(h, c);
+    launch_fused_zl(h, 0.0, c);
+    launch_final(h, c);
+}
+
+extern "C" int exaadmm_run_inner(exaadmm_handle* h, int outer, int max_inner, double beta, int* inner_done, double out[4])
+{
+    REQUIRE(h && outer >= 1 && max_inner >= 1, "bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    Ctrl* hc = h->h_ctrl;
+    memset(hc, 0, sizeof(Ctrl));
+    hc->max_inner = max_inner;
+    hc->check_every = std::max(1, (int)h->par.check_every);
+    hc->eps_pri = sqrt((double)h->nvar) / (2500.0 * outer);  // admm_two_level.jl:45
+    hc->beta = beta;
+    HIPCHK(hipMemcpyAsync(h->d_ctrl, hc, sizeof(Ctrl), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));  // hc is reused as the download target below
+    h->residual_vectors_valid = false;
+    // Kernels are enqueued in batches; each kernel returns at once when the device-side
+    // `done` flag is set, so the break happens at exactly the reference's iteration
+    // without a host round trip per iteration.
+    const int batch = 8;
+    int enq = 0;
+    while (enq < max_inner) {
+        const int nb = std::min(batch, max_inner - enq);
+        for (int i = 0; i < nb; i++) enqueue_iteration(h, h->d_ctrl);
+        enq += nb;
+        HIPCHK(hipMemcpyAsync(hc, h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
+        int rc = sync_check(h);
+        if (rc) return rc;
+        if (hc->done) break;
+    }
+    if (inner_done) *inner_done = hc->inner;
+    if (out)
+        for (int j = 0; j < 4; j++) out[j] = hc->res[j];
+    return EXAADMM_OK;
+}
+
+extern "C" int exaadmm_solve_two_level(exaadmm_handle* h, exaadmm_info* out)
+{
+    // admm_two_level (src/algorithms/admm_two_level.jl:1-88)
+    REQUIRE(h, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    exaadmm_params& par = h->par;
+    exaadmm_info& info = h->info;
+    const double sqrt_d = sqrt((double)h->nvar);
+    const double OUTER_TOL = sqrt_d * par.outer_eps;
+    memset(&info, 0, sizeof(info));
+    info.mismatch = INFINITY;
+    info.norm_z_prev = info.norm_z_curr = INFINITY;
+    par.beta = par.initial_beta;
+    info.status = 0;
+    int rc;
+
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const auto t0 = std::chrono::steady_clock::now();
+    while (info.outer < par.outer_iterlim) {
+        info.outer += 1;
+        if ((rc = exaadmm_norm_z(h, &info.norm_z_prev))) return rc;  // admm_outer_prestep
+        info.inner = 0;
+        int done = 0;
+        double res[4] = {0, 0, 0, 0};
+        if ((rc = exaadmm_run_inner(h, info.outer, par.inner_iterlim, par.beta, &done, res))) return rc;
+        info.inner = done;
+        info.cumul += done;
+        info.primres = res[0];
+        info.dualres = res[1];
+        info.norm_z_curr = res[2];
+        info.mismatch = res[3];
+        info.eps_pri = sqrt_d / (2500.0 * info.outer);
+        if (par.verbose > 0)
+            printf("%8d  %8d  %10.3e  %10.3e  %10.3e  %10.3e  %10.3e  %10.3e  %10.3e\n", info.outer, info.inner,
+                   info.primres, info.eps_pri, info.dualres, info.norm_z_curr, info.mismatch, OUTER_TOL, par.beta);
+        if (info.mismatch <= OUTER_TOL) {
+            info.status = 1;
+            break;
+        }
+        if ((rc = exaadmm_update_lz(h, par.beta))) return rc;
+        if (info.norm_z_curr > par.theta * info.norm_z_prev) par.beta = fmin(par.inc_c * par.beta, 1e24);
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    info.time_overall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if ((rc = exaadmm_objective(h, &info.objval))) return rc;  // admm_poststep
+    exaadmm_branch_stats(h, &info.avg_auglag_it, &info.avg_minor_it);
+    if (out) *out = info;
+    return EXAADMM_OK;
+}
+
+extern "C" int exaadmm_run_fixed(exaadmm_handle* h, int iters, int first_major_iter, double beta, double out[4],
+                                 double* ms_total, double* ms_branch)
+{
+    REQUIRE(h && iters >= 1 && first_major_iter >= 1, "bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    const bool time_branch = (ms_branch != nullptr);
+    const size_t need = 2 + (time_branch ? 2 * (size_t)iters : 0);
+    while (h->ev.size() < need) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        h->ev.push_back(e);
+    }
+    h->residual_vectors_valid = false;
+    HIPCHK(hipEventRecord(h->ev[0], h->stream));
+    for (int i = 0; i < iters; i++) {
+        launch_gen(h, nullptr);
+        if (time_branch) HIPCHK(hipEventRecord(h->ev[2 + 2 * i], h->stream));
+        launch_branch(h, first_major_iter + i, nullptr);
+        if (time_branch) HIPCHK(hipEventRecord(h->ev[3 + 2 * i], h->stream));
+        launch_bus(h, nullptr);
+        launch_fused_zl(h, beta, nullptr);
+        launch_final(h, nullptr);
+    }
+    HIPCHK(hipEventRecord(h->ev[1], h->stream));
+    double s[4];
+    int rc = fetch_sums(h, s, true);
+    if (rc) return rc;
+    if (out)
+        for (int j = 0; j < 4; j++) out[j] = s[j];
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+    if (ms_total) *ms_total = ms;
+    if (time_branch) {
+        double acc = 0.0;
+        for (int i = 0; i < iters; i++) {
+            HIPCHK(hipEventElapsedTime(&ms, h->ev[2 + 2 * i], h->ev[3 + 2 * i]));
+            acc += ms;
+        }
+        *ms_branch = acc / iters;
+    }
+    return EXAADMM_OK;
+}
+
+// ------------------------------------------------------------------ multi-GPU helpers
+extern "C" int exaadmm_set_halo_index(exaadmm_handle* h, int slot, const int64_t* idx, int64_t count)
+{
+    REQUIRE(h && slot >= 0 && slot < 8 && count >= 0, "bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    HaloSlot& s = h->halo[slot];
+    if (s.d_idx) {
+        hipFree(s.d_idx);
+        s.d_idx = nullptr;
+    }
+    s.count = (int)count;
+    if (count == 0) return EXAADMM_OK;
+    REQUIRE(idx, "null index list");
+    std::vector<int> t(count);
+    for (int64_t i = 0; i < count; i++) {
+        REQUIRE(idx[i] >= 0 && idx[i] < h->nvar, "halo index out of range (zero-based reference-layout index expected)");
+        t[i] = soa_index(h, idx[i]);
+    }
+    HIPCHK(hipMalloc((void**)&s.d_idx, count * sizeof(int)));
+    HIPCHK(hipMemcpy(s.d_idx, t.data(), count * sizeof(int), hipMemcpyHostToDevice));
+    return EXAADMM_OK;
+}
+
+extern "C" int exaadmm_halo_pack(exaadmm_handle* h, int slot, int which, double* dev_buf)
+{
+    REQUIRE(h && slot >= 0 && slot < 8, "bad argument");
+    const HaloSlot& s = h->halo[slot];
+    if (s.count == 0) return EXAADMM_OK;
+    double* src = vec_ptr(h, which);
+    REQUIRE(src && dev_buf, "bad vector / buffer");
+    HIPCHK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_gather, grid_for(s.count, 256), dim3(256), 0, h->stream, src, s.d_idx, s.count, dev_buf);
+    HIPCHK(hipGetLastError());
+    return EXAADMM_OK;
+}
+
+extern "C" int exaadmm_halo_unpack(exaadmm_handle* h, int slot, int which, const double* dev_buf)
+{
+    REQUIRE(h && slot >= 0 && slot < 8, "bad argument");
+    const HaloSlot& s = h->halo[slot];
+    if (s.count == 0) return EXAADMM_OK;
+    double* dst = vec_ptr(h, which);
+    REQUIRE(dst && dev_buf, "bad vector / buffer");
+    HIPCHK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_scatter, grid_for(s.count, 256), dim3(256), 0, h->stream, dst, s.d_idx, s.count, dev_buf);
+    HIPCHK(hipGetLastError());
+    h->residual_vectors_valid = false;
+    return EXAADMM_OK;
+}
+
+extern "C" int exaadmm_set_owned_mask(exaadmm_handle* h, const uint8_t* mask, int64_t nvar)
+{
+    REQUIRE(h, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    if (!mask) {
+        h->d.owned = nullptr;
+        return EXAADMM_OK;
+    }
+    REQUIRE(nvar == h->nvar, "mask length must be nvar");
+    std::vector<unsigned char> t(h->N, 0);
+    for (int64_t r = 0; r < nvar; r++) t[soa_index(h, r)] = mask[r] ? 1 : 0;
+    if (!h->d_owned) HIPCHK(hipMalloc((void**)&h->d_owned, (size_t)h->N));
+    HIPCHK(hipMemcpy(h->d_owned, t.data(), (size_t)h->N, hipMemcpyHostToDevice));
+    h->d.owned = h->d_owned;
+    return EXAADMM_OK;
+}

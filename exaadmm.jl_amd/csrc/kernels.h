@@ -1,0 +1,394 @@
+// HIP kernels of the ADMM inner iteration for gfx950 (MI355X).
+//
+// Device layout (DESIGN.md "data layout in HBM"): every solution vector is ONE
+// struct-of-arrays buffer of N = 2*Gp + 8*Lp doubles:
+//     [ pg plane (Gp) | qg plane (Gp) | pij plane (Lp) | qij | pji | qji | wi | wj | ti | tj ]
+// Gp, Lp = ngen, nline rounded up to 64.  Lane b of the branch kernel touches element b of
+// each plane -> every load/store of a wavefront is one contiguous 512-byte segment, where the
+// reference's interleaved 8-stride layout makes each wave touch 8x the cache lines.
+// Padding elements hold u=v=z=l=lz=0, rho=1 and therefore contribute exact zeros everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "branch_solver.h"
+
+namespace exa {
+
+// loop control shared by the kernels of a fused inner loop (lives in device memory)
+struct Ctrl {
+    int done;         // set by k_final_reduce when the inner loop must stop
+    int inner;        // completed inner iterations
+    int max_inner;
+    int check_every;  // 1 = reference semantics
+    double eps_pri;
+    double beta;
+    double res[4];    // primres, dualres, norm_z, mismatch of the last completed iteration
+    double sums[4];   // their squares
+};
+
+struct Dev {
+    int G, L, B, Gp, Lp, N;
+    double *u, *v, *z, *zp, *l, *lz, *rho;
+    double *rp, *rd, *ax;
+    const double* Y;    // 8 planes x Lp
+    const double* bnd;  // 8 planes x Lp: vi lo, vi hi, vj lo, vj hi, ti lo, ti hi, tj lo, tj hi
+    const double* rateA;
+    double *ls1, *ls2, *mu;
+    const double *pgmin, *pgmax, *qgmin, *qgmax, *c2, *c1;
+    const double *Pd, *Qd, *YshR, *YshI;
+    const int *FrStart, *FrIdx, *ToStart, *ToIdx, *GenStart, *GenIdx;
+    const unsigned char* owned;  // SoA order; nullptr = all owned
+    int *st_auglag, *st_minor, *st_ticks;
+    double* partials;  // [blocks][4]
+};
+
+constexpr int EW_BLOCK = 256;   // elementwise kernels
+constexpr int BR_BLOCK = 64;    // branch kernel: one wavefront per block
+
+__device__ __forceinline__ bool loop_done(const Ctrl* c) { return c != nullptr && c->done != 0; }
+
+// ---------------------------------------------------------------- generator
+// generator_kernel_two_level (acopf_generator_kernel_gpu.jl:1-22), one lane per generator
+__global__ void k_generator(Dev d, double baseMVA, const Ctrl* ctrl)
+{
+    if (loop_done(ctrl)) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.G) return;
+    const int pg = i, qg = d.Gp + i;
+    const double M = baseMVA;
+    double t = (-(d.c1[i] * M + d.l[pg] + d.rho[pg] * (-d.v[pg] + d.z[pg]))) / (2 * d.c2[i] * (M * M) + d.rho[pg]);
+    d.u[pg] = fmax(d.pgmin[i], fmin(d.pgmax[i], t));
+    t = (-(d.l[qg] + d.rho[qg] * (-d.v[qg] + d.z[qg]))) / d.rho[qg];
+    d.u[qg] = fmax(d.qgmin[i], fmin(d.qgmax[i], t));
+}
+
+// ---------------------------------------------------------------- branch
+// auglag_linelimit_two_level_alternative (acopf_auglag_linelimit_kernel_gpu.jl:1-151):
+// one lane per branch, 64 branches per wavefront, all solver state in registers.
+__global__ void __launch_bounds__(BR_BLOCK) k_branch(Dev d, BranchOptions o, double scale, int major_iter, const Ctrl* ctrl)
+{
+    if (ctrl != nullptr) {
+        if (ctrl->done) return;
+        major_iter = ctrl->inner + 1;
+    }
+    const int b = blockIdx.x * BR_BLOCK + threadIdx.x;
+    if (b >= d.L) return;
+    const int Lp = d.Lp;
+    const int base = 2 * d.Gp + b;
+
+    double ub[8], bnd[8];
+    BranchData bd;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int e = base + k * Lp;
+        ub[k] = d.u[e];
+        bd.lam[k] = d.l[e];
+        bd.rho[k] = d.rho[e];
+        bd.xt[k] = d.v[e] - d.z[e];
+        bd.Y[k] = d.Y[b + k * Lp];
+        bnd[k] = d.bnd[b + k * Lp];
+    }
+    bd.ls1 = d.ls1[b];
+    bd.ls2 = d.ls2[b];
+    bd.mu = (major_iter == 1) ? 10.0 : d.mu[b];
+    bd.scale = scale;
+
+    double x[6], xl[6], xu[6], phi[4];
+    branch_start(ub, bnd, d.rateA[b], x, xl, xu);
+    BranchStats st;
+    branch_solve(bd, o, x, xl, xu, phi, st);
+
+    d.u[base] = phi[0];
+    d.u[base + Lp] = phi[1];
+    d.u[base + 2 * Lp] = phi[2];
+    d.u[base + 3 * Lp] = phi[3];
+    d.u[base + 4 * Lp] = x[0] * x[0];
+    d.u[base + 5 * Lp] = x[1] * x[1];
+    d.u[base + 6 * Lp] = x[2];
+    d.u[base + 7 * Lp] = x[3];
+    d.ls1[b] = bd.ls1;
+    d.ls2[b] = bd.ls2;
+    d.mu[b] = bd.mu;
+    d.st_auglag[b] = st.auglag_it;
+    d.st_minor[b] = st.minor_it;
+    d.st_ticks[b] = st.ticks;
+}
+
+// ---------------------------------------------------------------- bus
+// bus_kernel_two_level_alternative (acopf_bus_kernel_gpu.jl:1-119), one lane per bus.
+// Gathers 4 planes per incident branch end, 2 per generator; scatters v to the same places.
+__global__ void k_bus(Dev d, double baseMVA, const Ctrl* ctrl)
+{
+    if (loop_done(ctrl)) return;
+    const int I = blockIdx.x * blockDim.x + threadIdx.x;
+    if (I >= d.B) return;
+    const int Lp = d.Lp, Gp = d.Gp, lb = 2 * d.Gp;
+    const double *u = d.u, *z = d.z, *l = d.l, *rho = d.rho;
+    double* v = d.v;
+
+    double common_wi = 0.0, common_ti = 0.0, inv_rhosum_p = 0.0, inv_rhosum_q = 0.0;
+    double rhosum_w = 0.0, rhosum_t = 0.0;
+    const int f0 = d.FrStart[I], f1 = d.FrStart[I + 1];
+    const int t0 = d.ToStart[I], t1 = d.ToStart[I + 1];
+    const int g0 = d.GenStart[I], g1 = d.GenStart[I + 1];
+
+    for (int k = f0; k < f1; k++) {
+        const int e = lb + d.FrIdx[k];
+        const int ew = e + 4 * Lp, et = e + 6 * Lp;
+        common_wi += l[ew] + rho[ew] * (u[ew] + z[ew]);
+        common_ti += l[et] + rho[et] * (u[et] + z[et]);
+        inv_rhosum_p += 1.0 / rho[e];
+        inv_rhosum_q += 1.0 / rho[e + Lp];
+        rhosum_w += rho[ew];
+        rhosum_t += rho[et];
+    }
+    for (int k = t0; k < t1; k++) {
+        const int e = lb + d.ToIdx[k];
+        const int ew = e + 5 * Lp, et = e + 7 * Lp;
+        common_wi += l[ew] + rho[ew] * (u[ew] + z[ew]);
+        common_ti += l[et] + rho[et] * (u[et] + z[et]);
+        inv_rhosum_p += 1.0 / rho[e + 2 * Lp];
+        inv_rhosum_q += 1.0 / rho[e + 3 * Lp];
+        rhosum_w += rho[ew];
+        rhosum_t += rho[et];
+    }
+    common_wi /= rhosum_w;
+
+    double rhs1 = 0.0, rhs2 = 0.0, inv_rhosum_pg = 0.0, inv_rhosum_qg = 0.0;
+    for (int k = g0; k < g1; k++) {
+        const int pg = d.GenIdx[k], qg = Gp + pg;
+        rhs1 += (u[pg] + z[pg]) + (l[pg] / rho[pg]);
+        rhs2 += (u[qg] + z[qg]) + (l[qg] / rho[qg]);
+        inv_rhosum_pg += 1.0 / rho[pg];
+        inv_rhosum_qg += 1.0 / rho[qg];
+    }
+    rhs1 -= (d.Pd[I] / baseMVA);
+    rhs2 -= (d.Qd[I] / baseMVA);
+    for (int k = f0; k < f1; k++) {
+        const int e = lb + d.FrIdx[k], eq = e + Lp;
+        rhs1 -= (u[e] + z[e]) + (l[e] / rho[e]);
+        rhs2 -= (u[eq] + z[eq]) + (l[eq] / rho[eq]);
+    }
+    for (int k = t0; k < t1; k++) {
+        const int e = lb + d.ToIdx[k] + 2 * Lp, eq = e + Lp;
+        rhs1 -= (u[e] + z[e]) + (l[e] / rho[e]);
+        rhs2 -= (u[eq] + z[eq]) + (l[eq] / rho[eq]);
+    }
+    const double ysr = d.YshR[I], ysi = d.YshI[I];
+    rhs1 -= ysr * common_wi;
+    rhs2 += ysi * common_wi;
+
+    const double A11 = (inv_rhosum_pg + inv_rhosum_p) + (ysr * ysr / rhosum_w);
+    const double A12 = -ysr * (ysi / rhosum_w);
+    const double A21 = A12;
+    const double A22 = (inv_rhosum_qg + inv_rhosum_q) + (ysi * ysi / rhosum_w);
+    const double mu2 = (rhs2 - (A21 / A11) * rhs1) / (A22 - (A21 / A11) * A12);
+    const double mu1 = (rhs1 - A12 * mu2) / A11;
+    const double wi = common_wi + ((ysr * mu1 - ysi * mu2) / rhosum_w);
+    const double ti = common_ti / rhosum_t;
+
+    for (int k = g0; k < g1; k++) {
+        const int pg = d.GenIdx[k], qg = Gp + pg;
+        v[pg] = (u[pg] + z[pg]) + (l[pg] - mu1) / rho[pg];
+        v[qg] = (u[qg] + z[qg]) + (l[qg] - mu2) / rho[qg];
+    }
+    for (int k = f0; k < f1; k++) {
+        const int e = lb + d.FrIdx[k], eq = e + Lp;
+        v[e] = (u[e] + z[e]) + (l[e] + mu1) / rho[e];
+        v[eq] = (u[eq] + z[eq]) + (l[eq] + mu2) / rho[eq];
+        v[e + 4 * Lp] = wi;
+        v[e + 6 * Lp] = ti;
+    }
+    for (int k = t0; k < t1; k++) {
+        const int e0 = lb + d.ToIdx[k];
+        const int e = e0 + 2 * Lp, eq = e0 + 3 * Lp;
+        v[e] = (u[e] + z[e]) + (l[e] + mu1) / rho[e];
+        v[eq] = (u[eq] + z[eq]) + (l[eq] + mu2) / rho[eq];
+        v[e0 + 5 * Lp] = wi;
+        v[e0 + 7 * Lp] = ti;
+    }
+}
+
+// ---------------------------------------------------------------- elementwise, step-wise
+__global__ void k_copy_z(Dev d)  // copy_data_kernel (utilities_gpu.jl:1-8)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.N; i += gridDim.x * blockDim.x) d.zp[i] = d.z[i];
+}
+
+__global__ void k_update_z(Dev d, double beta)  // update_zv_kernel (acopf_admm_update_z_gpu.jl:1-11)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.N; i += gridDim.x * blockDim.x) {
+        if (d.owned && !d.owned[i]) continue;
+        d.z[i] = (-(d.lz[i] + d.l[i] + d.rho[i] * (d.u[i] - d.v[i]))) / (beta + d.rho[i]);
+    }
+}
+
+__global__ void k_update_l(Dev d, double beta)  // update_l_kernel (acopf_admm_update_l_gpu.jl:1-14)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.N; i += gridDim.x * blockDim.x) {
+        if (d.owned && !d.owned[i]) continue;
+        d.l[i] = -(d.lz[i] + beta * d.z[i]);
+    }
+}
+
+__global__ void k_update_lz(Dev d, double beta, double maxmult)  // update_lz_kernel (acopf_admm_update_lz_gpu.jl:1-9)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.N; i += gridDim.x * blockDim.x) {
+        if (d.owned && !d.owned[i]) continue;
+        d.lz[i] = fmax(-maxmult, fmin(maxmult, d.lz[i] + (beta * d.z[i])));
+    }
+}
+
+// wavefront + block reduction of 4 running sums; thread 0 of the block gets the totals.
+// Fixed topology -> bitwise reproducible for a given launch shape.
+__device__ __forceinline__ void block_reduce4(double (&s)[4])
+{
+    __shared__ double sh[4][EW_BLOCK / 64];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s[j] += __shfl_down(s[j], off, 64);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) sh[j][wave] = s[j];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            double t = 0.0;
+            for (int w = 0; w < EW_BLOCK / 64; w++) t += sh[j][w];
+            s[j] = t;
+        }
+    }
+}
+
+// compute_primal_residual_kernel + 2x vector_difference + 4 norms
+// (acopf_admm_update_residual_gpu.jl:1-29) in one pass; materialises rp, rd, Ax_plus_By.
+__global__ void __launch_bounds__(EW_BLOCK) k_residual(Dev d)
+{
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.N; i += gridDim.x * blockDim.x) {
+        if (d.owned && !d.owned[i]) continue;
+        const double z = d.z[i];
+        const double rp = d.u[i] - d.v[i] + z;
+        const double rd = z - d.zp[i];
+        const double ax = rp - z;
+        d.rp[i] = rp;
+        d.rd[i] = rd;
+        d.ax[i] = ax;
+        s[0] += rp * rp;
+        s[1] += rd * rd;
+        s[2] += z * z;
+        s[3] += ax * ax;
+    }
+    block_reduce4(s);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) d.partials[blockIdx.x * 4 + j] = s[j];
+    }
+}
+
+__global__ void __launch_bounds__(EW_BLOCK) k_sumsq_z(Dev d)
+{
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.N; i += gridDim.x * blockDim.x) {
+        if (d.owned && !d.owned[i]) continue;
+        const double z = d.z[i];
+        s[2] += z * z;
+    }
+    block_reduce4(s);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) d.partials[blockIdx.x * 4 + j] = s[j];
+    }
+}
+
+// ---------------------------------------------------------------- elementwise, fused
+// z_prev <- z ; z-update ; l-update ; residual sums, one pass, 6 reads + 3 writes per element.
+// (admm_inner_prestep + admm_update_z + admm_update_l + admm_update_residual of the reference:
+//  7 launches + 4 library norms there.)
+__global__ void __launch_bounds__(EW_BLOCK) k_fused_zl(Dev d, double beta_arg, const Ctrl* ctrl)
+{
+    if (loop_done(ctrl)) return;
+    const double beta = ctrl ? ctrl->beta : beta_arg;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.N; i += gridDim.x * blockDim.x) {
+        if (d.owned && !d.owned[i]) continue;
+        const double u = d.u[i], v = d.v[i], rho = d.rho[i], lz = d.lz[i];
+        const double zold = d.z[i];
+        const double z = (-(lz + d.l[i] + rho * (u - v))) / (beta + rho);
+        const double rp = u - v + z;
+        const double rd = z - zold;
+        const double ax = rp - z;
+        d.zp[i] = zold;
+        d.z[i] = z;
+        d.l[i] = -(lz + beta * z);
+        s[0] += rp * rp;
+        s[1] += rd * rd;
+        s[2] += z * z;
+        s[3] += ax * ax;
+    }
+    block_reduce4(s);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) d.partials[blockIdx.x * 4 + j] = s[j];
+    }
+}
+
+// Sum the per-block partials in a fixed order; optionally advance the loop control:
+// inner++, res = sqrt(sums), done = (primres <= eps_pri) || inner == max_inner
+// (admm_two_level.jl:45,60-62 evaluated on the device).
+__global__ void __launch_bounds__(EW_BLOCK) k_final_reduce(const double* partials, int nblk, double* out_sums, Ctrl* ctrl)
+{
+    if (ctrl != nullptr && ctrl->done) return;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int b = threadIdx.x; b < nblk; b += EW_BLOCK) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) s[j] += partials[b * 4 + j];
+    }
+    block_reduce4(s);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) out_sums[j] = s[j];
+        if (ctrl != nullptr) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                ctrl->sums[j] = s[j];
+                ctrl->res[j] = sqrt(s[j]);
+            }
+            const int inner = ctrl->inner + 1;
+            ctrl->inner = inner;
+            const bool test = (ctrl->check_every <= 1) || (inner % ctrl->check_every == 0);
+            if ((test && ctrl->res[0] <= ctrl->eps_pri) || inner >= ctrl->max_inner) ctrl->done = 1;
+        }
+    }
+}
+
+// rp, rd, Ax_plus_By from u, v, z, z_prev (only needed when a caller downloads them after a fused loop)
+__global__ void k_materialize(Dev d)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.N; i += gridDim.x * blockDim.x) {
+        const double z = d.z[i];
+        const double rp = d.u[i] - d.v[i] + z;
+        d.rp[i] = rp;
+        d.rd[i] = z - d.zp[i];
+        d.ax[i] = rp - z;
+    }
+}
+
+// halo exchange helpers: gather / scatter through a SoA index list
+__global__ void k_gather(const double* src, const int* idx, int n, double* dst)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+
+__global__ void k_scatter(double* dst, const int* idx, int n, const double* src)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[idx[i]] = src[i];
+}
+
+}  // namespace exa

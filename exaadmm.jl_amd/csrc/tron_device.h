@@ -1,0 +1,564 @@
+// Bound-constrained trust-region Newton solver (TRON) for one tiny dense problem
+// per GPU lane, N known at compile time (N = 6 for the ACOPF branch subproblem).
+//
+// Replaces, for the hot path, what the reference gets from ExaTron.jl through
+//   /root/reference/src/models/acopf/acopf_tron_linelimit_kernel.jl:61-144  (driver)
+//   ExaTron.dtron / dcauchy / dspcg / dtrpcg / dprsrch / dicfs             (external pkg)
+//
+// MI355X-first design notes
+//  * The reference runs ONE 32-thread block per branch and keeps x, g, A, B, L and
+//    11 work vectors in shared memory, with 26-31 of 32 lanes idle.  Here one LANE
+//    owns one branch and every loop has a compile-time trip count N, so after
+//    unrolling all vectors and both packed-symmetric matrices live in VGPRs
+//    (512 per lane on gfx950); only the 35 read-only problem constants are staged
+//    through LDS by the caller.
+//  * The face loop of the subspace CG does not compact the free variables into
+//    a smaller system (that needs run-time indexing -> scratch memory).  It keeps
+//    a free-variable MASK and works on the N x N system whose bound rows/columns
+//    are replaced by the identity.  In exact and in floating-point arithmetic the
+//    free block sees the same operations in the same order (the extra terms are
+//    exact zeros), so iterates equal those of the compacted formulation.
+//  * The reverse-communication state machine of dtron is linearised by the
+//    caller (branch_solver.h) into "ticks" so that the 64 lanes of a wavefront
+//    stay in the same phase (model step -> f(trial) -> ratio test -> g,H).
+//
+// The header is also compilable by a host C++ compiler (EXA_HD empty): tests/
+// build it into a CPU harness to check this exact code against the oracle.
+#pragma once
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define EXA_HD __host__ __device__ __forceinline__
+#define EXA_UNROLL _Pragma("unroll")
+#else
+#define EXA_HD inline
+#define EXA_UNROLL
+#endif
+
+namespace exa {
+
+// task / termination codes (numbering of acopf_tron_linelimit_kernel.jl)
+enum { TRON_RUN = 0, TRON_CONV = 4, TRON_WARN = 10, TRON_MAXMINOR = 20, TRON_MAXFEVAL = 21 };
+
+template <int N>
+struct SymMat {  // packed lower triangle, (i,j) with i >= j at i(i+1)/2 + j
+    double a[N * (N + 1) / 2];
+    EXA_HD double get(int i, int j) const { return i >= j ? a[i * (i + 1) / 2 + j] : a[j * (j + 1) / 2 + i]; }
+    EXA_HD double& lo(int i, int j) { return a[i * (i + 1) / 2 + j]; }  // requires i >= j
+    EXA_HD double lo(int i, int j) const { return a[i * (i + 1) / 2 + j]; }
+};
+
+template <int N>
+EXA_HD double dot(const double (&a)[N], const double (&b)[N])
+{
+    double s = 0.0;
+    EXA_UNROLL
+    for (int i = 0; i < N; i++) s += a[i] * b[i];
+    return s;
+}
+
+template <int N>
+EXA_HD double nrm2(const double (&a)[N])
+{
+    return sqrt(dot<N>(a, a));
+}
+
+// w = A x (A symmetric, packed)
+template <int N>
+EXA_HD void symv(const SymMat<N>& A, const double (&x)[N], double (&w)[N])
+{
+    EXA_UNROLL
+    for (int i = 0; i < N; i++) {
+        double s = 0.0;
+        EXA_UNROLL
+        for (int j = 0; j < N; j++) s += A.get(i, j) * x[j];
+        w[i] = s;
+    }
+}
+
+// projected gradient inf-norm (ExaTron.dgpnorm; call site tron_linelimit_kernel.jl:122)
+template <int N>
+EXA_HD double gpnorm(const double (&x)[N], const double (&xl)[N], const double (&xu)[N], const double (&g)[N])
+{
+    double r = 0.0;
+    EXA_UNROLL
+    for (int i = 0; i < N; i++) {
+        if (xl[i] != xu[i]) {
+            double v;
+            if (x[i] == xl[i])
+                v = fabs(fmin(g[i], 0.0));
+            else if (x[i] == xu[i])
+                v = fabs(fmax(g[i], 0.0));
+            else
+                v = fabs(g[i]);
+            r = fmax(r, v);
+        }
+    }
+    return r;
+}
+
+template <int N>
+EXA_HD void breakpt(const double (&x)[N], const double (&xl)[N], const double (&xu)[N], const double (&w)[N],
+                    double& brptmin, double& brptmax)
+{
+    int nb = 0;
+    double bmin = 0.0, bmax = 0.0;
+    EXA_UNROLL
+    for (int i = 0; i < N; i++) {
+        bool up = (x[i] < xu[i]) && (w[i] > 0.0);
+        bool dn = (x[i] > xl[i]) && (w[i] < 0.0);
+        if (up || dn) {
+            double brpt = ((up ? xu[i] : xl[i]) - x[i]) / w[i];
+            bmin = (nb == 0) ? brpt : fmin(brpt, bmin);
+            bmax = (nb == 0) ? brpt : fmax(brpt, bmax);
+            nb++;
+        }
+    }
+    brptmin = bmin;
+    brptmax = bmax;
+}
+
+// s = P[x + alpha w] - x
+template <int N>
+EXA_HD void gpstep(const double (&x)[N], const double (&xl)[N], const double (&xu)[N], double alpha,
+                   const double (&w)[N], double (&s)[N])
+{
+    EXA_UNROLL
+    for (int i = 0; i < N; i++) {
+        double aw = alpha * w[i];
+        double t = x[i] + aw;
+        s[i] = (t < xl[i]) ? (xl[i] - x[i]) : ((t > xu[i]) ? (xu[i] - x[i]) : aw);
+    }
+}
+
+// q(s) = 1/2 s'As + g's and g's
+template <int N>
+EXA_HD void quad_model(const SymMat<N>& A, const double (&g)[N], const double (&s)[N], double& q, double& gts)
+{
+    double wa[N];
+    symv<N>(A, s, wa);
+    gts = dot<N>(g, s);
+    q = 0.5 * dot<N>(s, wa) + gts;
+}
+
+// Cauchy step (TRON dcauchy).  alpha persists across calls.
+template <int N>
+EXA_HD void cauchy(const double (&x)[N], const double (&xl)[N], const double (&xu)[N], const SymMat<N>& A,
+                   const double (&g)[N], double delta, double& alpha, double (&s)[N])
+{
+    const double mu0 = 0.01, interpf = 0.1, extrapf = 10.0;
+    double mg[N];
+    EXA_UNROLL
+    for (int i = 0; i < N; i++) mg[i] = -g[i];
+    double brptmin, brptmax;
+    breakpt<N>(x, xl, xu, mg, brptmin, brptmax);
+
+    bool interp;
+    gpstep<N>(x, xl, xu, -alpha, g, s);
+    if (nrm2<N>(s) > delta) {
+        interp = true;
+    } else {
+        double q, gts;
+        quad_model<N>(A, g, s, q, gts);
+        interp = (q >= mu0 * gts);
+    }
+
+    if (interp) {
+        bool search = true;
+        // alpha shrinks 10x per trip; 400 trips take any finite alpha to 0 (guard against NaN spins)
+        for (int guard = 0; search && guard < 400; guard++) {
+            alpha = interpf * alpha;
+            gpstep<N>(x, xl, xu, -alpha, g, s);
+            if (nrm2<N>(s) <= delta) {
+                double q, gts;
+                quad_model<N>(A, g, s, q, gts);
+                search = (q > mu0 * gts);
+            }
+        }
+    } else {
+        bool search = true;
+        double alphas = alpha;
+        for (int guard = 0; search && alpha <= brptmax && guard < 400; guard++) {
+            alpha = extrapf * alpha;
+            gpstep<N>(x, xl, xu, -alpha, g, s);
+            if (nrm2<N>(s) <= delta) {
+                double q, gts;
+                quad_model<N>(A, g, s, q, gts);
+                if (q < mu0 * gts) alphas = alpha;
+            } else {
+                search = false;
+            }
+        }
+        alpha = alphas;
+        gpstep<N>(x, xl, xu, -alpha, g, s);
+    }
+}
+
+// r <- L^{-1} r  (entries outside `fr` stay exactly 0 because their L row/column is the identity)
+template <int N>
+EXA_HD void trsol_n(const SymMat<N>& L, double (&r)[N])
+{
+    EXA_UNROLL
+    for (int j = 0; j < N; j++) {
+        double t = r[j] / L.lo(j, j);
+        EXA_UNROLL
+        for (int k = j + 1; k < N; k++) r[k] -= L.lo(k, j) * t;
+        r[j] = t;
+    }
+}
+
+// r <- L^{-T} r
+template <int N>
+EXA_HD void trsol_t(const SymMat<N>& L, double (&r)[N])
+{
+    r[N - 1] = r[N - 1] / L.lo(N - 1, N - 1);
+    EXA_UNROLL
+    for (int j = N - 2; j >= 0; j--) {
+        double t = 0.0;
+        EXA_UNROLL
+        for (int k = j + 1; k < N; k++) t += L.lo(k, j) * r[k];
+        r[j] = (r[j] - t) / L.lo(j, j);
+    }
+}
+
+// Scaled / shifted Cholesky of the free block of A (TRON dicfs + dicf, dense).
+// fr: bit i set = variable i free.  Bound rows/cols of L are the identity.
+template <int N>
+EXA_HD void icfs_masked(unsigned fr, const SymMat<N>& A, SymMat<N>& L)
+{
+    const int nbmax = 3;
+    const double alpham = 1.0e-3, nbfactor = 512.0;
+    double wa2[N];
+
+    EXA_UNROLL
+    for (int j = 0; j < N; j++) {
+        double s = 0.0;
+        EXA_UNROLL
+        for (int i = 0; i < N; i++) {
+            double aij = ((fr >> i) & 1u) ? A.get(i, j) : 0.0;
+            s += aij * aij;
+        }
+        double nrm = sqrt(s);
+        wa2[j] = (((fr >> j) & 1u) && nrm > 0.0) ? 1.0 / sqrt(nrm) : 1.0;
+    }
+
+    double alphas = alpham;
+    double alpha = 0.0;
+    EXA_UNROLL
+    for (int i = 0; i < N; i++) {
+        if ((fr >> i) & 1u) {
+            double aii = A.lo(i, i);
+            alpha = (aii == 0.0) ? alphas : fmax(alpha, -aii * (wa2[i] * wa2[i]));
+        }
+    }
+    if (alpha > 0.0) alpha = fmax(alpha, alphas);
+
+    int nb = 1;
+    for (int guard = 0; guard < 200; guard++) {
+        EXA_UNROLL
+        for (int i = 0; i < N; i++) {
+            EXA_UNROLL
+            for (int j = 0; j <= i; j++) {
+                bool f2 = ((fr >> i) & 1u) && ((fr >> j) & 1u);
+                double v;
+                if (i == j)
+                    v = f2 ? A.lo(i, i) * (wa2[i] * wa2[i]) + alpha : 1.0;
+                else
+                    v = f2 ? A.lo(i, j) * wa2[i] * wa2[j] : 0.0;
+                L.lo(i, j) = v;
+            }
+        }
+        // left-looking Cholesky, columns in order
+        bool ok = true;
+        EXA_UNROLL
+        for (int j = 0; j < N; j++) {
+            EXA_UNROLL
+            for (int k = 0; k < j; k++) {
+                double ljk = L.lo(j, k);
+                EXA_UNROLL
+                for (int i = j; i < N; i++) L.lo(i, j) -= L.lo(i, k) * ljk;
+            }
+            double d = L.lo(j, j);
+            ok = ok && (d > 0.0);
+            d = sqrt(d);  // NaN after a failed pivot; result discarded when !ok
+            L.lo(j, j) = d;
+            EXA_UNROLL
+            for (int i = j + 1; i < N; i++) L.lo(i, j) /= d;
+        }
+        if (ok) {
+            if (alpha == alphas && nb < nbmax) {
+                alphas = alphas / nbfactor;
+                alpha = alphas;
+                nb++;
+            } else {
+                EXA_UNROLL
+                for (int i = 0; i < N; i++) {
+                    EXA_UNROLL
+                    for (int j = 0; j <= i; j++) L.lo(i, j) = L.lo(i, j) / wa2[i];
+                }
+                return;
+            }
+        } else {
+            alpha = fmax(2.0 * alpha, alphas);
+        }
+    }
+}
+
+template <int N>
+EXA_HD double trqsol(const double (&x)[N], const double (&p)[N], double delta)
+{
+    double ptx = dot<N>(p, x), ptp = dot<N>(p, p), xtx = dot<N>(x, x);
+    double dsq = delta * delta;
+    double rad = ptx * ptx + ptp * (dsq - xtx);
+    rad = sqrt(fmax(rad, 0.0));
+    if (ptx > 0.0) return (dsq - xtx) / (ptx + rad);
+    if (rad > 0.0) return (rad - ptx) / ptp;
+    return 0.0;
+}
+
+// mask helper: zero the bound entries
+template <int N>
+EXA_HD void mask_vec(unsigned fr, double (&v)[N])
+{
+    EXA_UNROLL
+    for (int i = 0; i < N; i++) v[i] = ((fr >> i) & 1u) ? v[i] : 0.0;
+}
+
+// Preconditioned CG on the free block inside || L' w || <= delta  (TRON dtrpcg).
+// gf, w are zero on bound entries.  Returns info (1,2 converged; 3 neg. curvature; 4 boundary; 5 itermax).
+template <int N>
+EXA_HD int trpcg_masked(unsigned fr, const SymMat<N>& A, const double (&gf)[N], double delta, const SymMat<N>& L,
+                        double tol, double stol, int itermax, double (&w)[N], int& iters_out)
+{
+    double p[N], q[N], r[N], t[N], z[N];
+    EXA_UNROLL
+    for (int i = 0; i < N; i++) {
+        w[i] = 0.0;
+        t[i] = -gf[i];
+        r[i] = t[i];
+    }
+    trsol_n<N>(L, r);
+    EXA_UNROLL
+    for (int i = 0; i < N; i++) p[i] = r[i];
+
+    double rho = dot<N>(r, r);
+    if (sqrt(rho) == 0.0) {
+        iters_out = 0;
+        return 1;
+    }
+
+    for (int iters = 1; iters <= itermax; iters++) {
+        EXA_UNROLL
+        for (int i = 0; i < N; i++) z[i] = p[i];
+        trsol_t<N>(L, z);
+        symv<N>(A, z, q);
+        mask_vec<N>(fr, q);
+        EXA_UNROLL
+        for (int i = 0; i < N; i++) z[i] = q[i];
+        trsol_n<N>(L, q);
+
+        double ptq = dot<N>(p, q);
+        double alpha = (ptq > 0.0) ? rho / ptq : 0.0;
+        double sigma = trqsol<N>(w, p, delta);
+
+        if (ptq <= 0.0 || alpha >= sigma) {
+            EXA_UNROLL
+            for (int i = 0; i < N; i++) w[i] += sigma * p[i];
+            iters_out = iters;
+            return (ptq <= 0.0) ? 3 : 4;
+        }
+        EXA_UNROLL
+        for (int i = 0; i < N; i++) {
+            w[i] += alpha * p[i];
+            r[i] -= alpha * q[i];
+            t[i] -= alpha * z[i];
+        }
+        double rtr = dot<N>(r, r);
+        double rnorm = sqrt(rtr);
+        double tnorm = nrm2<N>(t);
+        if (tnorm <= tol) {
+            iters_out = iters;
+            return 1;
+        }
+        if (rnorm <= stol) {
+            iters_out = iters;
+            return 2;
+        }
+        double beta = rtr / rho;
+        EXA_UNROLL
+        for (int i = 0; i < N; i++) p[i] = r[i] + beta * p[i];
+        rho = rtr;
+    }
+    iters_out = itermax;
+    return 5;
+}
+
+// Projected search along w from x on the free block (TRON dprsrch); w <- actual step.
+template <int N>
+EXA_HD void prsrch_masked(unsigned fr, double (&x)[N], const double (&xl)[N], const double (&xu)[N],
+                          const SymMat<N>& A, const double (&gf)[N], double (&w)[N])
+{
+    const double mu0 = 0.01, interpf = 0.5;
+    double wa1[N], wa2[N];
+    double alpha = 1.0;
+    double brptmin, brptmax;
+    breakpt<N>(x, xl, xu, w, brptmin, brptmax);
+
+    bool search = true;
+    for (int guard = 0; search && alpha > brptmin && guard < 1100; guard++) {
+        gpstep<N>(x, xl, xu, alpha, w, wa1);
+        symv<N>(A, wa1, wa2);
+        mask_vec<N>(fr, wa2);
+        double gts = dot<N>(gf, wa1);
+        double q = 0.5 * dot<N>(wa1, wa2) + gts;
+        if (q <= mu0 * gts)
+            search = false;
+        else
+            alpha = interpf * alpha;
+    }
+    if (alpha < 1.0 && alpha < brptmin) alpha = brptmin;
+
+    gpstep<N>(x, xl, xu, alpha, w, wa1);
+    EXA_UNROLL
+    for (int i = 0; i < N; i++) {
+        double xi = x[i] + alpha * w[i];
+        x[i] = fmax(xl[i], fmin(xi, xu[i]));
+        w[i] = wa1[i];
+    }
+}
+
+// Subspace-projected CG from the Cauchy point (TRON dspcg).  On entry s = Cauchy step;
+// on exit x is the trial point and s = x - x0.
+template <int N>
+EXA_HD void spcg(double (&x)[N], const double (&xl)[N], const double (&xu)[N], const SymMat<N>& A,
+                 const double (&g)[N], double delta, double rtol, double (&s)[N], int itermax)
+{
+    double w[N], gf[N];
+    SymMat<N> L;
+    symv<N>(A, s, w);
+    EXA_UNROLL
+    for (int i = 0; i < N; i++) {
+        double xi = x[i] + s[i];
+        x[i] = fmax(xl[i], fmin(xi, xu[i]));
+    }
+
+    int iters = 0;
+    for (int nfaces = 1; nfaces <= N; nfaces++) {
+        unsigned fr = 0u;
+        EXA_UNROLL
+        for (int i = 0; i < N; i++)
+            if (xl[i] < x[i] && x[i] < xu[i]) fr |= (1u << i);
+        if (fr == 0u) return;
+
+        icfs_masked<N>(fr, A, L);
+
+        double gfn2 = 0.0;
+        EXA_UNROLL
+        for (int i = 0; i < N; i++) {
+            bool f = (fr >> i) & 1u;
+            gf[i] = f ? (w[i] + g[i]) : 0.0;
+            double gi = f ? g[i] : 0.0;
+            gfn2 += gi * gi;
+        }
+        double gfnorm = sqrt(gfn2);
+
+        int itertr;
+        int infotr = trpcg_masked<N>(fr, A, gf, delta, L, rtol * gfnorm, 0.0, itermax, w, itertr);
+        iters += itertr;
+        trsol_t<N>(L, w);
+
+        prsrch_masked<N>(fr, x, xl, xu, A, gf, w);
+
+        EXA_UNROLL
+        for (int i = 0; i < N; i++) s[i] += w[i];
+
+        symv<N>(A, s, w);
+        double gn2 = 0.0;
+        EXA_UNROLL
+        for (int i = 0; i < N; i++) {
+            double gi = ((fr >> i) & 1u) ? (w[i] + g[i]) : 0.0;
+            gn2 += gi * gi;
+        }
+        double gfnormf = sqrt(gn2);
+
+        if (gfnormf <= rtol * gfnorm) return;
+        if (infotr == 3 || infotr == 4) return;
+        if (iters > itermax) return;
+    }
+}
+
+// Per-lane state of one trust-region Newton solve (isave/dsave of dtron + driver counters).
+template <int N>
+struct TronState {
+    double f, fc, delta, alphac, prered;
+    double xc[N], s[N];
+    int iter, minor_iter, nfev;
+};
+
+// dtron, work = COMPUTE: model step from x (f, g, A valid at x).  x becomes the trial point.
+template <int N>
+EXA_HD void tron_compute(TronState<N>& st, double (&x)[N], const double (&xl)[N], const double (&xu)[N],
+                         const SymMat<N>& A, const double (&g)[N], double cgtol, int cg_itermax)
+{
+    st.fc = st.f;
+    EXA_UNROLL
+    for (int i = 0; i < N; i++) st.xc[i] = x[i];
+    cauchy<N>(x, xl, xu, A, g, st.delta, st.alphac, st.s);
+    spcg<N>(x, xl, xu, A, g, st.delta, cgtol, st.s, cg_itermax);
+    double wa[N];
+    symv<N>(A, st.s, wa);
+    st.prered = -(dot<N>(st.s, g) + 0.5 * dot<N>(st.s, wa));
+}
+
+// dtron, work = EVALUATE: ratio test with ftrial = f(x).  Returns true when the step is
+// accepted (caller must then refresh g, A at x); on rejection x is restored.
+// task is set to TRON_RUN, TRON_CONV or TRON_WARN.
+template <int N>
+EXA_HD bool tron_evaluate(TronState<N>& st, double ftrial, double (&x)[N], const double (&g)[N], double frtol,
+                          double fatol, double fmin_, int& task)
+{
+    const double eta0 = 1e-4, eta1 = 0.25, eta2 = 0.75;
+    const double sigma1 = 0.25, sigma2 = 0.5, sigma3 = 4.0;
+    double f = ftrial;
+    const double fc = st.fc;
+    double delta = st.delta;
+    const double actred = fc - f;
+    const double snorm = nrm2<N>(st.s);
+    if (st.iter == 1) delta = fmin(delta, snorm);
+
+    const double g0 = dot<N>(g, st.s);
+    double alpha;
+    if (f - fc - g0 <= 0.0)
+        alpha = sigma3;
+    else
+        alpha = fmax(sigma1, -0.5 * (g0 / (f - fc - g0)));
+
+    const double prered = st.prered;
+    if (actred < eta0 * prered)
+        delta = fmin(fmax(alpha, sigma1) * snorm, sigma2 * delta);
+    else if (actred < eta1 * prered)
+        delta = fmax(sigma1 * delta, fmin(alpha * snorm, sigma2 * delta));
+    else if (actred < eta2 * prered)
+        delta = fmax(sigma1 * delta, fmin(alpha * snorm, sigma3 * delta));
+    else
+        delta = fmax(delta, fmin(alpha * snorm, sigma3 * delta));
+    st.delta = delta;
+
+    bool success = (actred > eta0 * prered);
+    if (success) {
+        st.iter++;
+    } else {
+        EXA_UNROLL
+        for (int i = 0; i < N; i++) x[i] = st.xc[i];
+        f = fc;
+    }
+    st.f = f;
+
+    task = TRON_RUN;
+    if (f < fmin_) task = TRON_WARN;
+    if (fabs(actred) <= fatol && prered <= fatol) task = TRON_CONV;
+    if (fabs(actred) <= frtol * fabs(f) && prered <= frtol * fabs(f)) task = TRON_CONV;
+    return success;
+}
+
+}  // namespace exa

@@ -1,0 +1,178 @@
+/*
+ * exaadmm_hip.h -- C ABI of the MI355X-native backend for ExaAdmm.jl's two-level
+ * ADMM ACOPF inner loop (libexaadmm_hip.so, HIP for gfx950).
+ *
+ * Drop-in boundary: the reference drives its backends through 12 generic functions
+ * dispatched on (env::AdmmEnv, mod::AbstractOPFModel, device)
+ *   /root/reference/docs/src/dev.md:65-155, called from
+ *   /root/reference/src/algorithms/admm_two_level.jl:29-81.
+ * A Julia method `admm_update_x(env, mod, dev::HipNative) = ccall((:exaadmm_update_x, lib), ...)`
+ * per step binds to exactly the entry points below (see INTEGRATION.md and
+ * julia/ExaAdmmHip.jl).  All functions are extern "C", take plain pointers and sizes,
+ * return 0 on success or a negative exaadmm_status; no exception crosses the boundary.
+ *
+ * Conventions
+ *  - The library owns all device memory behind the opaque handle; callers own the host
+ *    buffers they pass.  Host vectors use the REFERENCE layout: length
+ *    nvar = 2*ngen + 8*nline, generators first [pg,qg], then per branch
+ *    [pij,qij,pji,qji,wi,wj,ti,tj] (src/models/acopf/acopf_model.jl:55-58).  Device
+ *    storage is struct-of-arrays; conversion happens inside upload/download.
+ *  - Index arrays are int64 as Julia holds them; exaadmm_grid.index_base says whether
+ *    they are 1-based (Julia) or 0-based (C/Python).
+ *  - Step-wise entry points are synchronous on return (the reference reads mod.info right
+ *    after each step).  The fused entry points keep control on the device side.
+ *  - Not re-entrant per handle; one handle per GPU, different handles may be driven
+ *    from different host threads.
+ */
+#ifndef EXAADMM_HIP_H
+#define EXAADMM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct exaadmm_handle exaadmm_handle;
+typedef struct exaadmm_case exaadmm_case;
+
+typedef enum {
+    EXAADMM_OK = 0,
+    EXAADMM_ERR_INVALID = -1,   /* bad argument / inconsistent sizes */
+    EXAADMM_ERR_HIP = -2,       /* HIP runtime error (message in exaadmm_last_error) */
+    EXAADMM_ERR_NO_DEVICE = -3, /* no usable gfx950 device: there is NO CPU fallback */
+    EXAADMM_ERR_IO = -4,        /* file not found / parse error */
+    EXAADMM_ERR_ALLOC = -5
+} exaadmm_status;
+
+/* Mirrors GridData (src/utils/grid_data.jl:3-83), fields the ACOPF path reads. */
+typedef struct {
+    int64_t ngen, nline, nbus;
+    int32_t index_base; /* 1: arrays exactly as Julia holds them; 0: zero-based */
+    double baseMVA;
+    const double *pgmin, *pgmax, *qgmin, *qgmax, *c2, *c1, *c0;           /* ngen */
+    const double *YffR, *YffI, *YftR, *YftI, *YttR, *YttI, *YtfR, *YtfI;  /* nline */
+    const double *FrVmBound, *ToVmBound, *FrVaBound, *ToVaBound;          /* 2*nline (lo,hi) */
+    const double *rateA;                                                  /* nline */
+    const int64_t *brBusIdx;                                              /* 2*nline (from,to) */
+    const double *Pd, *Qd, *Vmin, *Vmax, *YshR, *YshI;                    /* nbus */
+    const int64_t *FrStart, *FrIdx, *ToStart, *ToIdx, *GenStart, *GenIdx; /* CSR bus -> branch/gen */
+} exaadmm_grid;
+
+/* Mirrors Parameters (src/utils/environment.jl:6-76), fields the path reads. */
+typedef struct {
+    double mu_max;         /* 1e8 */
+    int32_t max_auglag;    /* 50 */
+    double initial_beta;   /* 1e3 */
+    double beta;           /* running value */
+    double inc_c;          /* 6 */
+    double theta;          /* 0.8 */
+    double outer_eps;      /* 2e-4 */
+    double MAX_MULTIPLIER; /* 1e12 */
+    int32_t outer_iterlim; /* 20 */
+    int32_t inner_iterlim; /* 1000 */
+    double scale;          /* 1e-4 */
+    int32_t verbose;       /* 0 */
+    int32_t check_every;   /* 1 = exact per-iteration inner-loop break (reference semantics);
+                              k>1 = opt-in relaxed mode: test convergence every k iterations */
+} exaadmm_params;
+
+/* Mirrors IterationInformation (src/utils/environment.jl:328-358). */
+typedef struct {
+    int32_t status; /* 0 = :IterationLimit, 1 = :Solved */
+    int32_t inner, outer, cumul;
+    double objval, primres, dualres, mismatch, norm_z_curr, norm_z_prev, eps_pri;
+    double time_overall;                                    /* seconds, scope of admm_two_level.jl:28-80 */
+    double time_x_update, time_xbar_update, time_zl_update; /* device time from HIP events (fused: sampled) */
+    double avg_auglag_it, avg_minor_it;                     /* of the last x-update (cpu path returns these) */
+} exaadmm_info;
+
+/* which vector of Solution (src/utils/environment.jl:177-226) */
+typedef enum {
+    EXAADMM_U_CURR = 0, EXAADMM_V_CURR = 1, EXAADMM_L_CURR = 2, EXAADMM_RHO = 3,
+    EXAADMM_RD = 4, EXAADMM_RP = 5, EXAADMM_Z_CURR = 6, EXAADMM_Z_PREV = 7,
+    EXAADMM_LZ = 8, EXAADMM_AX_PLUS_BY = 9
+} exaadmm_vector;
+
+const char *exaadmm_version(void);
+const char *exaadmm_last_error(void);
+const char *exaadmm_io_error(void); /* message of the last failed exaadmm_load_matpower */
+void exaadmm_default_params(exaadmm_params *p);
+
+/* ModelAcopf(env) without init: uploads the grid (src/models/acopf/acopf_model.jl:41-94) */
+int exaadmm_create(const exaadmm_grid *g, const exaadmm_params *p, int device_id, exaadmm_handle **out);
+int exaadmm_destroy(exaadmm_handle *h);
+int exaadmm_set_params(exaadmm_handle *h, const exaadmm_params *p);
+int exaadmm_get_params(exaadmm_handle *h, exaadmm_params *p);
+int64_t exaadmm_nvar(exaadmm_handle *h);
+
+/* init_solution! + membuf fill + pg bound copy
+ * (acopf_init_solution_gpu.jl:1-64, acopf_model.jl:61-64,87-89) */
+int exaadmm_init_solution(exaadmm_handle *h, double rho_pq, double rho_va);
+
+/* host <-> device, reference layout */
+int exaadmm_upload_solution(exaadmm_handle *h, int which, const double *host, int64_t n);
+int exaadmm_download_solution(exaadmm_handle *h, int which, double *host, int64_t n);
+/* membuf is 31 x nline column-major as in the reference; rows 25,26,27 (line-limit
+ * multipliers, penalty) and 29 (rateA) are state, rows 1-24 are scratch the device keeps
+ * in registers/LDS and returns as zeros (acopf_auglag_linelimit_kernel_gpu.jl:49-79). */
+int exaadmm_upload_membuf(exaadmm_handle *h, const double *host, int64_t nrow, int64_t nline);
+int exaadmm_download_membuf(exaadmm_handle *h, double *host, int64_t nrow, int64_t nline);
+/* rolling-horizon hooks (acopf_admm_rolling_gpu.jl:1-14): per-period load and ramp-limited bounds */
+int exaadmm_set_load(exaadmm_handle *h, const double *Pd, const double *Qd, int64_t nbus);
+int exaadmm_set_pg_bounds(exaadmm_handle *h, const double *pgmin_curr, const double *pgmax_curr, int64_t ngen);
+
+/* ---- one entry point per plugin step (docs/src/dev.md:65-155) ---- */
+int exaadmm_inner_prestep(exaadmm_handle *h);            /* acopf_admm_prepoststep_gpu.jl:11-21  */
+int exaadmm_update_x(exaadmm_handle *h, int major_iter); /* acopf_admm_update_x_gpu.jl:48-57     */
+int exaadmm_update_x_gen(exaadmm_handle *h);             /* acopf_generator_kernel_gpu.jl:1-33   */
+int exaadmm_update_x_line(exaadmm_handle *h, int major_iter); /* acopf_auglag_linelimit_kernel_gpu.jl */
+int exaadmm_update_xbar(exaadmm_handle *h);              /* acopf_bus_kernel_gpu.jl:1-119        */
+int exaadmm_update_z(exaadmm_handle *h, double beta);    /* acopf_admm_update_z_gpu.jl:1-24      */
+int exaadmm_update_l(exaadmm_handle *h, double beta);    /* acopf_admm_update_l_gpu.jl:1-26      */
+/* out = {primres, dualres, norm_z_curr, mismatch}         acopf_admm_update_residual_gpu.jl:11-29 */
+int exaadmm_update_residual(exaadmm_handle *h, double out[4]);
+int exaadmm_update_lz(exaadmm_handle *h, double beta);   /* acopf_admm_update_lz_gpu.jl:1-21     */
+int exaadmm_norm_z(exaadmm_handle *h, double *out);      /* admm_outer_prestep: ||z_curr||       */
+int exaadmm_objective(exaadmm_handle *h, double *out);   /* admm_poststep objective              */
+int exaadmm_branch_stats(exaadmm_handle *h, double *avg_auglag_it, double *avg_minor_it);
+
+/* ---- fused: control stays on the device side ---- */
+/* Inner while-loop of admm_two_level (admm_two_level.jl:34-63) for outer iteration `outer`:
+ * runs until primres <= sqrt(nvar)/(2500*outer) or max_inner iterations.
+ * inner_done = iterations executed; out = the four norms of the last one. */
+int exaadmm_run_inner(exaadmm_handle *h, int outer, int max_inner, double beta, int *inner_done, double out[4]);
+/* Whole admm_two_level (admm_two_level.jl:1-88) with the handle's parameters. */
+int exaadmm_solve_two_level(exaadmm_handle *h, exaadmm_info *out);
+/* K inner iterations with no convergence test (benchmark / roofline mode; counts as major_iter
+ * first_major_iter, first_major_iter+1, ...).  If ms_branch != NULL it receives the mean
+ * duration of the branch kernel measured with HIP events on the launch stream. */
+int exaadmm_run_fixed(exaadmm_handle *h, int iters, int first_major_iter, double beta, double out[4],
+                      double *ms_total, double *ms_branch);
+
+/* ---- multi-GPU helpers (one handle = one partition; see DESIGN.md "multi-GPU") ---- */
+/* run on a caller-provided HIP stream (e.g. torch's current stream); NULL = library stream */
+int exaadmm_set_stream(exaadmm_handle *h, void *hip_stream);
+/* squared partial sums {|rp|^2, |rd|^2, |z|^2, |Ax+By|^2} of the elements this handle owns,
+ * left on the device at *dev_ptr (4 doubles) for an all-reduce by the caller */
+int exaadmm_residual_partial_sums(exaadmm_handle *h, double **dev_ptr);
+/* gather/scatter `count` entries (reference-layout indices idx[], base per grid.index_base)
+ * of one solution vector into/from a contiguous DEVICE buffer (halo exchange) */
+int exaadmm_set_halo_index(exaadmm_handle *h, int slot, const int64_t *idx, int64_t count);
+int exaadmm_halo_pack(exaadmm_handle *h, int slot, int which, double *dev_buf);
+int exaadmm_halo_unpack(exaadmm_handle *h, int slot, int which, const double *dev_buf);
+/* elementwise steps restricted by an ownership mask (1 = this rank owns the element's
+ * z/l/lz/residual contribution); NULL restores "owns everything" */
+int exaadmm_set_owned_mask(exaadmm_handle *h, const uint8_t *mask, int64_t nvar);
+/* fused z + l + residual partial sums without the final norm (distributed inner iteration) */
+int exaadmm_update_zl_partial(exaadmm_handle *h, double beta, double **dev_sums);
+
+/* ---- MATPOWER ingest (next row f1: utils/parse_matpower.jl, utils/opfdata.jl) ---- */
+int exaadmm_load_matpower(const char *path, double tight_factor, const char *case_format, exaadmm_case **out);
+int exaadmm_case_grid(const exaadmm_case *c, exaadmm_grid *out); /* zero-based view, valid until free */
+int exaadmm_case_free(exaadmm_case *c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

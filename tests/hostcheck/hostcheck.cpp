@@ -1,0 +1,91 @@
+// TEST HARNESS ONLY: compiles the product's device solver headers
+// (exaadmm.jl_amd/csrc/{tron_device,branch_solver}.h) with the HOST compiler so the
+// exact lane code can be compared with the oracle on CPU, before it runs on a GPU.
+// Built into tests/hostcheck/libhostcheck.so by tests/test_device_code_on_host.py.
+// Not part of the product; the product has no CPU execution path.
+#define _GNU_SOURCE 1
+#include <math.h>
+#include "branch_solver.h"
+
+using namespace exa;
+
+static void fill(BranchData& d, const double* param, const double* Y, double scale)
+{
+    for (int k = 0; k < 8; k++) {
+        d.lam[k] = param[k];
+        d.rho[k] = param[8 + k];
+        d.xt[k] = param[16 + k];
+        d.Y[k] = Y[k];
+    }
+    d.ls1 = param[24];
+    d.ls2 = param[25];
+    d.mu = param[26];
+    d.scale = scale;
+}
+
+extern "C" double hostcheck_fgh(const double* x_, const double* param, const double* Y, double scale,
+                                double* g_, double* Afull)
+{
+    BranchData d;
+    fill(d, param, Y, scale);
+    double x[6], g[6];
+    for (int i = 0; i < 6; i++) x[i] = x_[i];
+    SymMat<6> A;
+    double f = branch_fgh(d, x, g, A);
+    for (int i = 0; i < 6; i++) {
+        g_[i] = g[i];
+        for (int j = 0; j < 6; j++) Afull[i + 6 * j] = A.get(i, j);
+    }
+    return f;
+}
+
+extern "C" double hostcheck_f(const double* x_, const double* param, const double* Y, double scale)
+{
+    BranchData d;
+    fill(d, param, Y, scale);
+    double x[6];
+    for (int i = 0; i < 6; i++) x[i] = x_[i];
+    return branch_f(d, x);
+}
+
+// same contract as oracle_branch_solve
+extern "C" int hostcheck_branch_solve(double* x_, const double* xl_, const double* xu_, double* param,
+                                      const double* Y, double scale, int max_auglag, double mu_max,
+                                      int* auglag_it, int* minor_it, int* ticks)
+{
+    BranchData d;
+    fill(d, param, Y, scale);
+    BranchOptions o;
+    o.max_auglag = max_auglag;
+    o.mu_max = mu_max;
+    o.max_feval = 500;
+    o.max_minor = 200;
+    o.gtol = 1e-6;
+    o.frtol = 1e-12;
+    o.fatol = 0.0;
+    o.fmin = -1e32;
+    o.cgtol = 0.1;
+    double p = 1.0;
+    for (int k = 0; k < 8; k++) {
+        p *= 10.0;
+        o.pow10[k] = p;
+        o.pow01[k] = pow(p, 0.1);
+        o.pow09[k] = pow(p, 0.9);
+    }
+    double x[6], xl[6], xu[6], phi[4];
+    for (int i = 0; i < 6; i++) {
+        x[i] = x_[i];
+        xl[i] = xl_[i];
+        xu[i] = xu_[i];
+    }
+    BranchStats st;
+    branch_solve(d, o, x, xl, xu, phi, st);
+    for (int i = 0; i < 6; i++) x_[i] = x[i];
+    param[24] = d.ls1;
+    param[25] = d.ls2;
+    param[26] = d.mu;
+    *auglag_it = st.auglag_it;
+    *minor_it = st.minor_it;
+    *ticks = st.ticks;
+    return 0;
+}

@@ -1,0 +1,98 @@
+"""CPU-side checks of the drop-in boundary: the shared library loads, exports every symbol
+include/exaadmm_hip.h declares, the native MATPOWER loader agrees with the oracle's numpy
+loader, and compute entry points fail loudly without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import CASE9, ROOT
+import exaadmm_loader
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import __graft_entry__
+    __graft_entry__.build()
+    return exaadmm_loader.load_package()
+
+
+def test_every_declared_symbol_is_exported(pkg):
+    hdr = open(os.path.join(ROOT, "include", "exaadmm_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(exaadmm_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) >= 35
+    lib = C.CDLL(pkg.LIB_PATH)
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_native_matpower_loader_matches_oracle_loader(pkg, oracle):
+    a = pkg.opf_loaddata(CASE9)
+    b = oracle.grid_from_matpower(CASE9)
+    assert (a["ngen"], a["nline"], a["nbus"]) == (b["ngen"], b["nline"], b["nbus"])
+    for k in pkg.Grid._F64 + pkg.Grid._BUS:
+        assert np.allclose(a[k], b[k], rtol=1e-15, atol=0), k
+    for k in pkg.Grid._IDX + ("brBusIdx",):
+        assert np.array_equal(a[k], b[k].astype(np.int64)), k
+
+
+def test_loader_filters_inactive_and_applies_tight_factor(pkg, tmp_path):
+    src = open(CASE9).read()
+    # switch generator 3 and branch 9 off; rateA of branch 1 -> 0 (becomes 1e3)
+    src = src.replace("3\t85\t-10.95\t300\t-300\t1.025\t100\t1", "3\t85\t-10.95\t300\t-300\t1.025\t100\t0")
+    src = src.replace("9\t4\t0.01\t0.085\t0.176\t250\t250\t250\t0\t0\t1", "9\t4\t0.01\t0.085\t0.176\t250\t250\t250\t0\t0\t0")
+    src = src.replace("1\t4\t0\t0.0576\t0\t250", "1\t4\t0\t0.0576\t0\t0")
+    p = tmp_path / "c.m"
+    p.write_text(src)
+    g = pkg.opf_loaddata(str(p), tight_factor=0.99)
+    assert (g["ngen"], g["nline"]) == (2, 8)
+    assert g["rateA"][0] == 1e3
+    assert np.isclose(g["rateA"][1], 0.99 * 6.25)
+
+
+def test_loader_reports_missing_file(pkg):
+    with pytest.raises(pkg.ExaAdmmError):
+        pkg.opf_loaddata("/nonexistent/case.m")
+
+
+def test_compute_fails_loudly_without_gpu(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(pkg.ExaAdmmError, match="no CPU fallback|no HIP device|failed"):
+        env = pkg.AdmmEnv(CASE9, 4e2, 4e4, verbose=0)
+        pkg.ModelAcopf(env)
+
+
+def test_product_never_imports_oracle():
+    """no import / include / dlopen of anything under oracle/ from the product tree"""
+    pdir = os.path.join(ROOT, "exaadmm.jl_amd")
+    bad = re.compile(r"(import\s+oracle|from\s+oracle|oracle/|oracle\.py|libexaadmm_oracle|acopf_oracle\.h|tron_dense\.h)")
+    for dp, _, files in os.walk(pdir):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp", "Makefile")):
+                txt = open(os.path.join(dp, f)).read()
+                assert not bad.search(txt), (dp, f)
+
+
+def test_synthetic_grid_is_connected_and_sized(pkg):
+    syn = exaadmm_loader.load_submodule("synthetic")
+    g = syn.sized_like("case1354pegase")
+    assert (g["ngen"], g["nline"], g["nbus"]) == syn.CASE_SIZES["case1354pegase"]
+    # connectivity by union-find
+    parent = list(range(g["nbus"]))
+
+    def find(a):
+        while parent[a] != a:
+            parent[a] = parent[parent[a]]
+            a = parent[a]
+        return a
+    bb = g["brBusIdx"].reshape(-1, 2)
+    for f, t in bb:
+        parent[find(f)] = find(t)
+    assert len({find(i) for i in range(g["nbus"])}) == 1
+    assert g["FrStart"][-1] == g["nline"] and g["GenStart"][-1] == g["ngen"]
+    assert (bb[:, 0] != bb[:, 1]).all()

@@ -1,0 +1,122 @@
+"""Run the product's per-lane solver code (exaadmm.jl_amd/csrc/*.h), compiled for the
+HOST by a test-only harness, against the oracle and the reference-generated vectors.
+This is a CPU pre-check of the device code; the GPU parity tests are in test_gpu_*.py."""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+HC_DIR = os.path.join(ROOT, "tests", "hostcheck")
+CSRC = os.path.join(ROOT, "exaadmm.jl_amd", "csrc")
+dp = C.POINTER(C.c_double)
+ip = C.POINTER(C.c_int)
+
+
+def _p(a):
+    return a.ctypes.data_as(dp)
+
+
+@pytest.fixture(scope="module")
+def hc():
+    so = os.path.join(HC_DIR, "libhostcheck.so")
+    srcs = [os.path.join(HC_DIR, "hostcheck.cpp"), os.path.join(CSRC, "tron_device.h"),
+            os.path.join(CSRC, "branch_solver.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+                               "-I", CSRC, srcs[0], "-o", so, "-lm"])
+    L = C.CDLL(so)
+    L.hostcheck_fgh.restype = C.c_double
+    L.hostcheck_fgh.argtypes = [dp, dp, dp, C.c_double, dp, dp]
+    L.hostcheck_f.restype = C.c_double
+    L.hostcheck_f.argtypes = [dp, dp, dp, C.c_double]
+    L.hostcheck_branch_solve.argtypes = [dp, dp, dp, dp, dp, C.c_double, C.c_int, C.c_double, ip, ip, ip]
+    return L
+
+
+def test_lane_fgh_matches_reference_outputs(hc):
+    d = json.load(open(os.path.join(GOLDEN, "branch_eval_vectors.json")))
+    for c in d["cases"]:
+        x, p, Y = (np.array(c[k]) for k in ("x", "param", "Y"))
+        g = np.zeros(6)
+        A = np.zeros(36)
+        f = hc.hostcheck_fgh(_p(x), _p(p), _p(Y), c["scale"], _p(g), _p(A))
+        f2 = hc.hostcheck_f(_p(x), _p(p), _p(Y), c["scale"])
+        assert f == f2
+        H, gr = np.array(c["H"]), np.array(c["g"])
+        assert abs(f - c["f"]) <= 1e-12 * max(1.0, abs(c["f"]))
+        assert np.abs(g - gr).max() <= 1e-12 * max(1.0, np.abs(gr).max())
+        assert np.abs(A.reshape(6, 6) - H).max() <= 1e-12 * max(1.0, np.abs(H).max())
+
+
+def _random_branch(rng, cold):
+    r, xx, b = rng.uniform(0.0, 0.05), rng.uniform(0.02, 0.3), rng.uniform(0, 0.4)
+    tap = rng.choice([1.0, 1.0, 0.98, 1.05]) * np.exp(1j * rng.choice([0.0, 0.0, 0.05]))
+    Ys = 1 / (r + 1j * xx)
+    Ytt = Ys + 1j * b / 2
+    Yff = Ytt / (tap * np.conj(tap))
+    Yft = -Ys / np.conj(tap)
+    Ytf = -Ys / tap
+    Y = np.array([Yff.real, Yff.imag, Yft.real, Yft.imag, Ytt.real, Ytt.imag, Ytf.real, Ytf.imag])
+    rate = rng.choice([1e3, 0.99 * rng.uniform(0.3, 4.0) ** 2])
+    xl = np.array([0.9, 0.9, -2 * np.pi, -2 * np.pi, -rate, -rate])
+    xu = np.array([1.1, 1.1, 2 * np.pi, 2 * np.pi, 0.0, 0.0])
+    if rng.random() < 0.15:
+        xl[2] = xu[2] = 0.0   # reference bus on the from side
+    p = np.zeros(31)
+    rho_pq, rho_va = rng.choice([(10.0, 1e3), (50.0, 5e3), (400.0, 4e4)])
+    p[8:12], p[12:16] = rho_pq, rho_va
+    if cold:
+        w0 = 1.01
+        p[16:24] = [Y[0] * w0 + Y[2] * w0, -Y[1] * w0 - Y[3] * w0, Y[4] * w0 + Y[6] * w0,
+                    -Y[5] * w0 - Y[7] * w0, w0, w0, 0, 0]
+        x = np.array([0.9, 0.9, 0, 0, 0, 0.0])
+    else:
+        vi, vj, th = rng.uniform(0.92, 1.08), rng.uniform(0.92, 1.08), rng.uniform(-0.4, 0.4)
+        ti = 0.0 if xl[2] == xu[2] else rng.uniform(-0.3, 0.3)
+        tj = ti - th
+        cs, sn = np.cos(th), np.sin(th)
+        flow = np.array([Y[0] * vi * vi + Y[2] * vi * vj * cs + Y[3] * vi * vj * sn,
+                         -Y[1] * vi * vi - Y[3] * vi * vj * cs + Y[2] * vi * vj * sn,
+                         Y[4] * vj * vj + Y[6] * vi * vj * cs - Y[7] * vi * vj * sn,
+                         -Y[5] * vj * vj - Y[7] * vi * vj * cs - Y[6] * vi * vj * sn])
+        p[16:24] = np.concatenate([flow, [vi * vi, vj * vj, ti, tj]]) + rng.normal(0, 0.02, 8)
+        p[0:8] = rng.normal(0, 5.0, 8) * np.array([1, 1, 1, 1, 10, 10, 10, 10])
+        p[24:26] = rng.choice([0.0, 1.0]) * rng.uniform(0, 3, 2)
+        x = np.array([vi, vj, ti, tj, max(-rate, -(flow[0] ** 2 + flow[1] ** 2)),
+                      max(-rate, -(flow[2] ** 2 + flow[3] ** 2))])
+        x += rng.normal(0, 0.01, 6)
+        x = np.minimum(xu, np.maximum(xl, x))
+    p[26] = 10.0 ** rng.integers(1, 4)
+    p[28] = rate
+    return x, xl, xu, p, Y
+
+
+@pytest.mark.parametrize("cold", [True, False])
+def test_lane_branch_solve_matches_oracle(hc, oracle, cold):
+    rng = np.random.default_rng(7 if cold else 11)
+    OL = oracle.lib()
+    n_same_counts = 0
+    ncase = 300
+    for _ in range(ncase):
+        x, xl, xu, p, Y = _random_branch(rng, cold)
+        scale = float(rng.choice([1e-4, 1e-5]))
+        xo, po = x.copy(), p.copy()
+        ito, mio = C.c_int(), C.c_int()
+        OL.oracle_branch_solve(_p(xo), _p(xl), _p(xu), _p(po), _p(Y), scale, 50, 1e8,
+                               C.cast(C.byref(ito), oracle.c_int_p), C.cast(C.byref(mio), oracle.c_int_p))
+        xh, ph = x.copy(), p.copy()
+        ith, mih, tk = C.c_int(), C.c_int(), C.c_int()
+        hc.hostcheck_branch_solve(_p(xh), _p(xl), _p(xu), _p(ph), _p(Y), scale, 50, 1e8,
+                                  C.byref(ith), C.byref(mih), C.byref(tk))
+        # the lane code evaluates f/g/H through a different (cheaper) factorisation of the same
+        # mathematics, so iterates agree to rounding-amplified-by-conditioning, not bitwise
+        assert np.abs(xh - xo).max() <= 1e-7, (xh, xo)
+        assert np.abs(ph[24:27] - po[24:27]).max() <= 1e-6 * max(1.0, np.abs(po[24:27]).max())
+        n_same_counts += (ith.value == ito.value and mih.value == mio.value)
+        assert tk.value >= mih.value - ith.value
+    assert n_same_counts >= 0.97 * ncase

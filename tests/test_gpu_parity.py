@@ -1,0 +1,186 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the CPU oracle
+on the same inputs, against the reference's golden vectors, and - at benchmark sizes -
+through size-independent properties.  Tolerances are written next to each assertion."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import CASE9, GOLDEN
+import exaadmm_loader
+
+pytestmark = pytest.mark.gpu
+
+G = json.load(open(os.path.join(GOLDEN, "case9_iter1.json")))
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    p = exaadmm_loader.load_package()
+    p.library()  # raises if the HIP extension is missing
+    return p
+
+
+@pytest.fixture(scope="module")
+def syn():
+    return exaadmm_loader.load_submodule("synthetic")
+
+
+def _one_iter_stepwise(pkg, env, mod, inner=1):
+    mod.info.inner = inner - 1
+    pkg.admm_increment_inner(env, mod)
+    pkg.admm_inner_prestep(env, mod)
+    pkg.admm_update_x(env, mod)
+    pkg.admm_update_xbar(env, mod)
+    pkg.admm_update_z(env, mod)
+    pkg.admm_update_l(env, mod)
+    pkg.admm_update_residual(env, mod)
+
+
+def test_case9_one_iteration_reference_known_answers(pkg):
+    """Same sequence and vectors as test/algorithms/acopf_update_gpu.jl, atol 1e-6."""
+    env = pkg.AdmmEnv(CASE9, 4e2, 4e4, verbose=0)
+    mod = pkg.ModelAcopf(env)
+    env.params.scale, env.params.initial_beta, env.params.beta = 1e-4, 1e3, 1e3
+    pkg.admm_increment_outer(env, mod)
+    pkg.admm_outer_prestep(env, mod)
+    pkg.admm_increment_reset_inner(env, mod)
+    pkg.admm_increment_inner(env, mod)
+    pkg.admm_inner_prestep(env, mod)
+    sol = mod.solution
+    atol = G["atol"]
+    pkg.admm_update_x(env, mod)
+    u = sol.u_curr
+    assert np.abs(u[:6] - G["U_GEN"]).max() <= atol
+    assert np.abs(u[6:] - G["U_BR"]).max() <= atol
+    pkg.admm_update_xbar(env, mod)
+    v = sol.v_curr
+    assert np.abs(v[:6] - G["V_GEN"]).max() <= atol
+    assert np.abs(v[6:] - G["V_BR"]).max() <= atol
+    pkg.admm_update_z(env, mod)
+    z = sol.z_curr
+    assert np.abs(z[:6] - G["Z_GEN"]).max() <= atol
+    assert np.abs(z[6:] - G["Z_BR"]).max() <= atol
+    pkg.admm_update_l(env, mod)
+    l = sol.l_curr
+    assert np.abs(l[:6] - G["L_GEN"]).max() <= atol + 1e-6   # literals truncated at 6 decimals
+    assert np.abs(l[6:] - G["L_BR"]).max() <= atol + 1e-6
+    pkg.admm_update_residual(env, mod)
+    assert np.abs(sol.rp - (sol.u_curr - sol.v_curr + sol.z_curr)).max() <= atol
+    assert np.abs(sol.rd - (sol.z_curr - sol.z_prev)).max() <= atol
+    assert np.abs(sol.Ax_plus_By - (sol.u_curr - sol.v_curr)).max() <= atol
+    lz_prev = sol.lz
+    pkg.admm_update_lz(env, mod)
+    assert np.abs(sol.lz - (lz_prev + env.params.beta * sol.z_curr)).max() <= atol
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_case9_full_solve_anchor(pkg, fused):
+    """Solved / outer 20 / cumul 705 / objval 5303.435 (acopf_update_gpu.jl:190-194)."""
+    a = G["solve_case9"]
+    env, mod = pkg.solve_acopf(CASE9, outer_iterlim=a["outer_iterlim"], rho_pq=4e2, rho_va=4e4,
+                               outer_eps=a["outer_eps"], verbose=0, fused=fused)
+    assert mod.info.status == "Solved"
+    assert mod.info.outer == a["outer"]
+    assert mod.info.cumul == a["cumul"]
+    assert abs(mod.info.objval - a["objval"]) <= a["objval_atol"]
+
+
+def test_case9_trajectory_matches_oracle(pkg, oracle, case9_grid):
+    """10 step-wise iterations: every state vector within 1e-8 (abs, values are O(1..100))."""
+    env = pkg.AdmmEnv(CASE9, 4e2, 4e4, verbose=0)
+    mod = pkg.ModelAcopf(env)
+    ref = oracle.OracleModel(case9_grid, 4e2, 4e4)
+    mod.info.outer = 1
+    for it in range(1, 11):
+        _one_iter_stepwise(pkg, env, mod, it)
+        ref.inner_prestep(); ref.update_x(it); ref.update_xbar(); ref.update_z(); ref.update_l()
+        res = ref.update_residual()
+        for name in ("u_curr", "v_curr", "z_curr", "l_curr"):
+            scale = max(1.0, np.abs(ref.sol[name]).max())
+            assert np.abs(getattr(mod.solution, name) - ref.sol[name]).max() <= 1e-8 * scale, (it, name)
+        got = (mod.info.primres, mod.info.dualres, mod.info.norm_z_curr, mod.info.mismatch)
+        assert np.allclose(got, res, rtol=1e-9, atol=1e-12)
+    mb, mbr = mod.membuf, ref.membuf.T
+    assert np.allclose(mb[24:27], mbr[24:27], rtol=1e-7, atol=1e-9)
+    assert np.array_equal(mb[28], mbr[28])
+
+
+@pytest.mark.parametrize("case", ["case118", "case1354pegase"])
+def test_synthetic_fused_loop_matches_oracle(pkg, oracle, syn, case):
+    """Fused device-resident inner loop vs oracle on size-matched synthetic grids:
+    same iteration count, u/v to 1e-6 relative (FP64 with different summation orders and FMA)."""
+    g = syn.sized_like(case, seed=3)
+    rho = (4e2, 4e4) if case == "case118" else (1e1, 1e3)
+    kw = dict(outer_iterlim=2, inner_iterlim=40, rho_pq=rho[0], rho_va=rho[1], scale=1e-4)
+    env, mod = pkg.solve_acopf(case, grid=g, verbose=0, **kw)
+    ref = oracle.solve_acopf(case, grid=g, **kw)
+    assert mod.info.cumul == ref.info.cumul
+    assert mod.info.outer == ref.info.outer
+    for name in ("u_curr", "v_curr"):
+        a, b = getattr(mod.solution, name), ref.sol[name]
+        assert np.abs(a - b).max() <= 1e-6 * max(1.0, np.abs(b).max()), name
+    assert abs(mod.info.objval - ref.info.objval) <= 1e-6 * abs(ref.info.objval)
+    assert np.isclose(mod.info.primres, ref.info.primres, rtol=1e-6)
+
+
+def test_ragged_and_edge_grids(pkg, oracle, syn):
+    """sizes not multiples of the 64-lane padding, a generator-free bus majority, and a bus with
+    many incident branches"""
+    for (G_, L_, B_) in [(1, 63, 40), (2, 65, 64), (5, 129, 100)]:
+        g = syn.synthetic_grid(G_, L_, B_, seed=G_ + L_, locality=8)
+        kw = dict(outer_iterlim=1, inner_iterlim=12, rho_pq=4e2, rho_va=4e4)
+        env, mod = pkg.solve_acopf("x", grid=g, verbose=0, **kw)
+        ref = oracle.solve_acopf("x", grid=g, **kw)
+        assert mod.info.cumul == ref.info.cumul
+        b = ref.sol["u_curr"]
+        assert np.abs(mod.solution.u_curr - b).max() <= 1e-6 * max(1.0, np.abs(b).max())
+
+
+def test_upload_download_roundtrip_and_membuf(pkg):
+    env = pkg.AdmmEnv(CASE9, 4e2, 4e4, verbose=0)
+    mod = pkg.ModelAcopf(env)
+    rng = np.random.default_rng(0)
+    for name in ("u_curr", "v_curr", "l_curr", "z_curr", "lz", "rho"):
+        x = rng.normal(size=mod.nvar)
+        setattr(mod.solution, name, x)
+        assert np.array_equal(getattr(mod.solution, name), x)
+    mb = np.zeros((31, mod.nline))
+    mb[24], mb[25], mb[26], mb[28] = rng.normal(size=(4, mod.nline))
+    mod.membuf = mb
+    assert np.array_equal(mod.membuf, mb)
+
+
+def test_properties_at_benchmark_size(pkg, syn):
+    """case13659pegase-sized grid: determinism (bitwise) of the fused loop, residual identities,
+    v consensus (all branch ends at a bus see the same w, theta), flows consistent with (w, theta)."""
+    g = syn.sized_like("case13659pegase")
+    outs = []
+    for _ in range(2):
+        env = pkg.AdmmEnv("syn", 5e1, 5e3, verbose=0, grid=g)
+        mod = pkg.ModelAcopf(env)
+        env.params.scale = 1e-4
+        mod.sync_params()
+        norms, ms, _ = mod.run_fixed(5, first_major_iter=1, beta=1e3)
+        outs.append((mod.solution.u_curr, mod.solution.v_curr, norms))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert np.array_equal(outs[0][2], outs[1][2])
+    u, v = outs[0][0], outs[0][1]
+    sol = mod.solution
+    z, zp = sol.z_curr, sol.z_prev
+    assert np.allclose(sol.rp, u - v + z, atol=1e-12)
+    assert np.allclose(sol.rd, z - zp, atol=1e-12)
+    nrm = np.sqrt([np.sum((u - v + z) ** 2), np.sum((z - zp) ** 2), np.sum(z ** 2), np.sum((u - v) ** 2)])
+    assert np.allclose(outs[0][2], nrm, rtol=1e-10)
+    G_, L_ = g["ngen"], g["nline"]
+    vb = v[2 * G_:].reshape(L_, 8)
+    bb = g["brBusIdx"].reshape(L_, 2)
+    w_bus = np.full(g["nbus"], np.nan)
+    w_bus[bb[:, 0]] = vb[:, 4]
+    assert np.array_equal(w_bus[bb[:, 0]], vb[:, 4]) and np.array_equal(w_bus[bb[:, 1]], vb[:, 5])
+    ub = u[2 * G_:].reshape(L_, 8)
+    vi, vj, th = np.sqrt(ub[:, 4]), np.sqrt(ub[:, 5]), ub[:, 6] - ub[:, 7]
+    pij = g["YffR"] * vi ** 2 + g["YftR"] * vi * vj * np.cos(th) + g["YftI"] * vi * vj * np.sin(th)
+    assert np.allclose(ub[:, 0], pij, rtol=1e-9, atol=1e-9)
+    assert (ub[:, 4] >= 0.81 - 1e-12).all() and (ub[:, 4] <= 1.21 + 1e-12).all()

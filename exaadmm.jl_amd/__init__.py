@@ -24,7 +24,7 @@ import time
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libexaadmm_hip.so")
+LIB_PATH = os.environ.get("EXAADMM_HIP_LIB", os.path.join(_HERE, "libexaadmm_hip.so"))
 
 c_double_p = C.POINTER(C.c_double)
 c_i64_p = C.POINTER(C.c_int64)
@@ -117,6 +117,8 @@ def library():
     L.exaadmm_norm_z.argtypes = [H, c_double_p]
     L.exaadmm_objective.argtypes = [H, c_double_p]
     L.exaadmm_branch_stats.argtypes = [H, c_double_p, c_double_p]
+    L.exaadmm_download_branch_counters.argtypes = [H, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                                   C.POINTER(C.c_int32), C.c_int64]
     L.exaadmm_run_inner.argtypes = [H, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int), c_double_p]
     L.exaadmm_solve_two_level.argtypes = [H, C.POINTER(Info)]
     L.exaadmm_run_fixed.argtypes = [H, C.c_int, C.c_int, C.c_double, c_double_p, c_double_p, c_double_p]
@@ -308,6 +310,14 @@ class ModelAcopf:
         a, m = C.c_double(), C.c_double()
         _check(library().exaadmm_branch_stats(self._h, C.byref(a), C.byref(m)), "exaadmm_branch_stats")
         return a.value, m.value
+
+    def branch_counters(self):
+        """per-branch (auglag iterations, TRON minor iterations, solver-loop trips) of the last x-update"""
+        a, m, t = (np.zeros(self.nline, dtype=np.int32) for _ in range(3))
+        ip = C.POINTER(C.c_int32)
+        _check(library().exaadmm_download_branch_counters(self._h, a.ctypes.data_as(ip), m.ctypes.data_as(ip),
+                                                          t.ctypes.data_as(ip), self.nline), "branch counters")
+        return a, m, t
 
     def run_fixed(self, iters, first_major_iter=2, beta=None, time_branch=False):
         """K inner iterations without convergence test; returns (norms, ms_total, ms_branch)."""

@@ -107,7 +107,7 @@ EXA_HD double objective_from_flows(const BranchData& d, const double (&x)[6], co
     return f * d.scale;
 }
 
-EXA_HD double branch_f(const BranchData& d, const double (&x)[6])
+EXA_BIG double branch_f(const BranchData& d, const double (&x)[6])
 {
     FlowTrig t;
     double phi[4];
@@ -117,7 +117,7 @@ EXA_HD double branch_f(const BranchData& d, const double (&x)[6])
 }
 
 // objective, gradient and packed Hessian at x
-EXA_HD double branch_fgh(const BranchData& d, const double (&x)[6], double (&g)[6], SymMat<6>& A)
+EXA_BIG double branch_fgh(const BranchData& d, const double (&x)[6], double (&g)[6], SymMat<6>& A)
 {
     FlowTrig t;
     double phi[4];

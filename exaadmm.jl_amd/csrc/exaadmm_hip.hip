@@ -312,9 +312,9 @@ extern "C" int exaadmm_create(const exaadmm_grid* g, const exaadmm_params* p, in
         TRY(dev_alloc(h, &d.st_auglag, (size_t)h->Lp));
         TRY(dev_alloc(h, &d.st_minor, (size_t)h->Lp));
         TRY(dev_alloc(h, &d.st_ticks, (size_t)h->Lp));
-        hipMemset(d.st_auglag, 0, h->Lp * sizeof(int));
-        hipMemset(d.st_minor, 0, h->Lp * sizeof(int));
-        hipMemset(d.st_ticks, 0, h->Lp * sizeof(int));
+        (void)hipMemset(d.st_auglag, 0, h->Lp * sizeof(int));
+        (void)hipMemset(d.st_minor, 0, h->Lp * sizeof(int));
+        (void)hipMemset(d.st_ticks, 0, h->Lp * sizeof(int));
     }
     // generator constants
     {
@@ -368,16 +368,16 @@ extern "C" int exaadmm_create(const exaadmm_grid* g, const exaadmm_params* p, in
 extern "C" int exaadmm_destroy(exaadmm_handle* h)
 {
     if (!h) return EXAADMM_OK;
-    hipSetDevice(h->device);
-    if (h->own_stream) hipStreamSynchronize(h->own_stream);
-    for (void* p : h->allocs) hipFree(p);
+    (void)hipSetDevice(h->device);
+    if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
+    for (void* p : h->allocs) (void)hipFree(p);
     for (auto& s : h->halo)
-        if (s.d_idx) hipFree(s.d_idx);
-    if (h->d_owned) hipFree(h->d_owned);
-    if (h->h_ctrl) hipHostFree(h->h_ctrl);
-    if (h->h_sums) hipHostFree(h->h_sums);
-    for (auto e : h->ev) hipEventDestroy(e);
-    if (h->own_stream) hipStreamDestroy(h->own_stream);
+        if (s.d_idx) (void)hipFree(s.d_idx);
+    if (h->d_owned) (void)hipFree(h->d_owned);
+    if (h->h_ctrl) (void)hipHostFree(h->h_ctrl);
+    if (h->h_sums) (void)hipHostFree(h->h_sums);
+    for (auto e : h->ev) (void)hipEventDestroy(e);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return EXAADMM_OK;
 }
@@ -765,6 +765,17 @@ extern "C" int exaadmm_branch_stats(exaadmm_handle* h, double* avg_auglag_it, do
     return EXAADMM_OK;
 }
 
+extern "C" int exaadmm_download_branch_counters(exaadmm_handle* h, int32_t* a, int32_t* m, int32_t* t, int64_t nline)
+{
+    REQUIRE(h && nline == h->L, "nline mismatch");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (a) HIPCHK(hipMemcpy(a, h->d.st_auglag, (size_t)h->L * sizeof(int), hipMemcpyDeviceToHost));
+    if (m) HIPCHK(hipMemcpy(m, h->d.st_minor, (size_t)h->L * sizeof(int), hipMemcpyDeviceToHost));
+    if (t) HIPCHK(hipMemcpy(t, h->d.st_ticks, (size_t)h->L * sizeof(int), hipMemcpyDeviceToHost));
+    return EXAADMM_OK;
+}
+
 // ------------------------------------------------------------------ fused loops
 static void enqueue_iteration(exaadmm_handle* h, Ctrl* c)
 {
@@ -908,7 +919,7 @@ extern "C" int exaadmm_set_halo_index(exaadmm_handle* h, int slot, const int64_t
     HIPCHK(hipSetDevice(h->device));
     HaloSlot& s = h->halo[slot];
     if (s.d_idx) {
-        hipFree(s.d_idx);
+        (void)hipFree(s.d_idx);
         s.d_idx = nullptr;
     }
     s.count = (int)count;

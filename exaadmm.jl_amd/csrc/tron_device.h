@@ -30,8 +30,14 @@
 #if defined(__HIPCC__)
 #define EXA_HD __host__ __device__ __forceinline__
 #define EXA_UNROLL _Pragma("unroll")
+#if defined(EXA_NOINLINE_BIG)
+#define EXA_BIG __host__ __device__ __attribute__((noinline))
+#else
+#define EXA_BIG EXA_HD
+#endif
 #else
 #define EXA_HD inline
+#define EXA_BIG inline
 #define EXA_UNROLL
 #endif
 
@@ -143,7 +149,7 @@ EXA_HD void quad_model(const SymMat<N>& A, const double (&g)[N], const double (&
 
 // Cauchy step (TRON dcauchy).  alpha persists across calls.
 template <int N>
-EXA_HD void cauchy(const double (&x)[N], const double (&xl)[N], const double (&xu)[N], const SymMat<N>& A,
+EXA_BIG void cauchy(const double (&x)[N], const double (&xl)[N], const double (&xu)[N], const SymMat<N>& A,
                    const double (&g)[N], double delta, double& alpha, double (&s)[N])
 {
     const double mu0 = 0.01, interpf = 0.1, extrapf = 10.0;
@@ -224,7 +230,7 @@ EXA_HD void trsol_t(const SymMat<N>& L, double (&r)[N])
 // Scaled / shifted Cholesky of the free block of A (TRON dicfs + dicf, dense).
 // fr: bit i set = variable i free.  Bound rows/cols of L are the identity.
 template <int N>
-EXA_HD void icfs_masked(unsigned fr, const SymMat<N>& A, SymMat<N>& L)
+EXA_BIG void icfs_masked(unsigned fr, const SymMat<N>& A, SymMat<N>& L)
 {
     const int nbmax = 3;
     const double alpham = 1.0e-3, nbfactor = 512.0;
@@ -327,7 +333,7 @@ EXA_HD void mask_vec(unsigned fr, double (&v)[N])
 // Preconditioned CG on the free block inside || L' w || <= delta  (TRON dtrpcg).
 // gf, w are zero on bound entries.  Returns info (1,2 converged; 3 neg. curvature; 4 boundary; 5 itermax).
 template <int N>
-EXA_HD int trpcg_masked(unsigned fr, const SymMat<N>& A, const double (&gf)[N], double delta, const SymMat<N>& L,
+EXA_BIG int trpcg_masked(unsigned fr, const SymMat<N>& A, const double (&gf)[N], double delta, const SymMat<N>& L,
                         double tol, double stol, int itermax, double (&w)[N], int& iters_out)
 {
     double p[N], q[N], r[N], t[N], z[N];
@@ -395,7 +401,7 @@ EXA_HD int trpcg_masked(unsigned fr, const SymMat<N>& A, const double (&gf)[N], 
 
 // Projected search along w from x on the free block (TRON dprsrch); w <- actual step.
 template <int N>
-EXA_HD void prsrch_masked(unsigned fr, double (&x)[N], const double (&xl)[N], const double (&xu)[N],
+EXA_BIG void prsrch_masked(unsigned fr, double (&x)[N], const double (&xl)[N], const double (&xu)[N],
                           const SymMat<N>& A, const double (&gf)[N], double (&w)[N])
 {
     const double mu0 = 0.01, interpf = 0.5;
@@ -430,7 +436,7 @@ EXA_HD void prsrch_masked(unsigned fr, double (&x)[N], const double (&xl)[N], co
 // Subspace-projected CG from the Cauchy point (TRON dspcg).  On entry s = Cauchy step;
 // on exit x is the trial point and s = x - x0.
 template <int N>
-EXA_HD void spcg(double (&x)[N], const double (&xl)[N], const double (&xu)[N], const SymMat<N>& A,
+EXA_BIG void spcg(double (&x)[N], const double (&xl)[N], const double (&xu)[N], const SymMat<N>& A,
                  const double (&g)[N], double delta, double rtol, double (&s)[N], int itermax)
 {
     double w[N], gf[N];

@@ -136,6 +136,9 @@ int exaadmm_update_lz(exaadmm_handle *h, double beta);   /* acopf_admm_update_lz
 int exaadmm_norm_z(exaadmm_handle *h, double *out);      /* admm_outer_prestep: ||z_curr||       */
 int exaadmm_objective(exaadmm_handle *h, double *out);   /* admm_poststep objective              */
 int exaadmm_branch_stats(exaadmm_handle *h, double *avg_auglag_it, double *avg_minor_it);
+/* per-branch work counters of the last x-update: augmented-Lagrangian iterations, TRON minor
+ * iterations (summed), solver-loop trips of the lane (divergence diagnostics) */
+int exaadmm_download_branch_counters(exaadmm_handle *h, int32_t *auglag_it, int32_t *minor_it, int32_t *ticks, int64_t nline);
 
 /* ---- fused: control stays on the device side ---- */
 /* Inner while-loop of admm_two_level (admm_two_level.jl:34-63) for outer iteration `outer`:

@@ -1,0 +1,159 @@
+# ExaAdmmHip.jl -- binding of libexaadmm_hip.so (include/exaadmm_hip.h) into ExaAdmm.jl.
+#
+# UNEXECUTED SOURCE: no Julia runtime exists in the build image; every entry point used here
+# is exercised from Python/ctypes by tests/ through the same C ABI.
+#
+# Usage inside ExaAdmm (after `include("ExaAdmmHip.jl")` at the end of src/ExaAdmm.jl):
+#     env, mod = ExaAdmm.solve_acopf_hip("case13659pegase.m"; rho_pq=5e1, rho_va=5e3, scale=1e-4,
+#                                        tight_factor=0.99)
+# The reference's dispatch seam is the third positional argument `device` of the generic
+# functions called by admm_two_level (src/algorithms/admm_two_level.jl:29-81); `HipNative`
+# is a new concrete type there, so no existing method is touched.
+
+const libexaadmm_hip = get(ENV, "EXAADMM_HIP_LIB", "libexaadmm_hip.so")
+
+struct ExaadmmGrid            # == exaadmm_grid
+    ngen::Int64; nline::Int64; nbus::Int64
+    index_base::Int32
+    baseMVA::Float64
+    pgmin::Ptr{Float64}; pgmax::Ptr{Float64}; qgmin::Ptr{Float64}; qgmax::Ptr{Float64}
+    c2::Ptr{Float64}; c1::Ptr{Float64}; c0::Ptr{Float64}
+    YffR::Ptr{Float64}; YffI::Ptr{Float64}; YftR::Ptr{Float64}; YftI::Ptr{Float64}
+    YttR::Ptr{Float64}; YttI::Ptr{Float64}; YtfR::Ptr{Float64}; YtfI::Ptr{Float64}
+    FrVmBound::Ptr{Float64}; ToVmBound::Ptr{Float64}; FrVaBound::Ptr{Float64}; ToVaBound::Ptr{Float64}
+    rateA::Ptr{Float64}
+    brBusIdx::Ptr{Int64}
+    Pd::Ptr{Float64}; Qd::Ptr{Float64}; Vmin::Ptr{Float64}; Vmax::Ptr{Float64}
+    YshR::Ptr{Float64}; YshI::Ptr{Float64}
+    FrStart::Ptr{Int64}; FrIdx::Ptr{Int64}; ToStart::Ptr{Int64}; ToIdx::Ptr{Int64}
+    GenStart::Ptr{Int64}; GenIdx::Ptr{Int64}
+end
+
+mutable struct ExaadmmParams  # == exaadmm_params
+    mu_max::Float64; max_auglag::Int32; initial_beta::Float64; beta::Float64; inc_c::Float64
+    theta::Float64; outer_eps::Float64; MAX_MULTIPLIER::Float64; outer_iterlim::Int32
+    inner_iterlim::Int32; scale::Float64; verbose::Int32; check_every::Int32
+end
+
+"Device tag: owns the opaque library handle of one MI355X."
+mutable struct HipNative
+    handle::Ptr{Cvoid}
+end
+
+const U_CURR, V_CURR, L_CURR, RHO, RD, RP, Z_CURR, Z_PREV, LZ, AX_PLUS_BY = 0:9
+
+function hipcheck(rc::Cint, what)
+    rc == 0 || error("$what failed ($rc): " * unsafe_string(ccall((:exaadmm_last_error, libexaadmm_hip), Cstring, ())))
+    return nothing
+end
+
+to_params(par::Parameters) = ExaadmmParams(par.mu_max, par.max_auglag, par.initial_beta, par.beta, par.inc_c,
+    par.theta, par.outer_eps, par.MAX_MULTIPLIER, par.outer_iterlim, par.inner_iterlim, par.scale,
+    par.verbose, 1)
+
+"Create the device model from a CPU-typed ModelAcopf (arrays stay 1-based: index_base = 1)."
+function HipNative(env::AdmmEnv, mod::ModelAcopf; gpu_no::Int=0)
+    d = mod.grid_data
+    g = ExaadmmGrid(d.ngen, d.nline, d.nbus, 1, d.baseMVA,
+        pointer(d.pgmin), pointer(d.pgmax), pointer(d.qgmin), pointer(d.qgmax), pointer(d.c2), pointer(d.c1), pointer(d.c0),
+        pointer(d.YffR), pointer(d.YffI), pointer(d.YftR), pointer(d.YftI), pointer(d.YttR), pointer(d.YttI),
+        pointer(d.YtfR), pointer(d.YtfI), pointer(d.FrVmBound), pointer(d.ToVmBound), pointer(d.FrVaBound),
+        pointer(d.ToVaBound), pointer(d.rateA), pointer(d.brBusIdx), pointer(d.Pd), pointer(d.Qd), pointer(d.Vmin),
+        pointer(d.Vmax), pointer(d.YshR), pointer(d.YshI), pointer(d.FrStart), pointer(d.FrIdx), pointer(d.ToStart),
+        pointer(d.ToIdx), pointer(d.GenStart), pointer(d.GenIdx))
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    p = to_params(env.params)
+    GC.@preserve d begin
+        hipcheck(ccall((:exaadmm_create, libexaadmm_hip), Cint, (Ref{ExaadmmGrid}, Ref{ExaadmmParams}, Cint, Ref{Ptr{Cvoid}}),
+                       g, p, gpu_no, h), "exaadmm_create")
+    end
+    dev = HipNative(h[])
+    finalizer(x -> ccall((:exaadmm_destroy, libexaadmm_hip), Cint, (Ptr{Cvoid},), x.handle), dev)
+    upload!(dev, mod)
+    return dev
+end
+
+function upload!(dev::HipNative, mod::ModelAcopf)
+    s = mod.solution; n = length(s.u_curr)
+    for (id, v) in ((U_CURR, s.u_curr), (V_CURR, s.v_curr), (L_CURR, s.l_curr), (RHO, s.rho), (Z_CURR, s.z_curr),
+                    (Z_PREV, s.z_prev), (LZ, s.lz))
+        hipcheck(ccall((:exaadmm_upload_solution, libexaadmm_hip), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Int64),
+                       dev.handle, id, v, n), "exaadmm_upload_solution")
+    end
+    hipcheck(ccall((:exaadmm_upload_membuf, libexaadmm_hip), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64),
+                   dev.handle, mod.membuf, 31, size(mod.membuf, 2)), "exaadmm_upload_membuf")
+    hipcheck(ccall((:exaadmm_set_pg_bounds, libexaadmm_hip), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64),
+                   dev.handle, mod.pgmin_curr, mod.pgmax_curr, length(mod.pgmin_curr)), "exaadmm_set_pg_bounds")
+end
+
+function download!(dev::HipNative, mod::ModelAcopf)
+    s = mod.solution; n = length(s.u_curr)
+    for (id, v) in ((U_CURR, s.u_curr), (V_CURR, s.v_curr), (L_CURR, s.l_curr), (RD, s.rd), (RP, s.rp),
+                    (Z_CURR, s.z_curr), (Z_PREV, s.z_prev), (LZ, s.lz), (AX_PLUS_BY, s.Ax_plus_By))
+        hipcheck(ccall((:exaadmm_download_solution, libexaadmm_hip), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Int64),
+                       dev.handle, id, v, n), "exaadmm_download_solution")
+    end
+    hipcheck(ccall((:exaadmm_download_membuf, libexaadmm_hip), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64),
+                   dev.handle, mod.membuf, 31, size(mod.membuf, 2)), "exaadmm_download_membuf")
+end
+
+# ---- the plugin steps (docs/src/dev.md:65-155); counters keep the generic untyped methods of
+# ---- acopf_admm_increment.jl, which only touch mod.info
+function admm_outer_prestep(env::AdmmEnv, mod::AbstractOPFModel, dev::HipNative)
+    r = Ref{Float64}(0.0)
+    hipcheck(ccall((:exaadmm_norm_z, libexaadmm_hip), Cint, (Ptr{Cvoid}, Ref{Float64}), dev.handle, r), "exaadmm_norm_z")
+    mod.info.norm_z_prev = r[]
+    return
+end
+admm_inner_prestep(env::AdmmEnv, mod::AbstractOPFModel, dev::HipNative) =
+    hipcheck(ccall((:exaadmm_inner_prestep, libexaadmm_hip), Cint, (Ptr{Cvoid},), dev.handle), "exaadmm_inner_prestep")
+admm_update_x(env::AdmmEnv, mod::AbstractOPFModel, dev::HipNative) =
+    hipcheck(ccall((:exaadmm_update_x, libexaadmm_hip), Cint, (Ptr{Cvoid}, Cint), dev.handle, mod.info.inner), "exaadmm_update_x")
+admm_update_xbar(env::AdmmEnv, mod::AbstractOPFModel, dev::HipNative) =
+    hipcheck(ccall((:exaadmm_update_xbar, libexaadmm_hip), Cint, (Ptr{Cvoid},), dev.handle), "exaadmm_update_xbar")
+admm_update_z(env::AdmmEnv, mod::AbstractOPFModel, dev::HipNative) =
+    hipcheck(ccall((:exaadmm_update_z, libexaadmm_hip), Cint, (Ptr{Cvoid}, Cdouble), dev.handle, env.params.beta), "exaadmm_update_z")
+admm_update_l(env::AdmmEnv, mod::AbstractOPFModel, dev::HipNative) =
+    hipcheck(ccall((:exaadmm_update_l, libexaadmm_hip), Cint, (Ptr{Cvoid}, Cdouble), dev.handle, env.params.beta), "exaadmm_update_l")
+function admm_update_residual(env::AdmmEnv, mod::AbstractOPFModel, dev::HipNative)
+    out = zeros(4)
+    hipcheck(ccall((:exaadmm_update_residual, libexaadmm_hip), Cint, (Ptr{Cvoid}, Ptr{Float64}), dev.handle, out), "exaadmm_update_residual")
+    mod.info.primres, mod.info.dualres, mod.info.norm_z_curr, mod.info.mismatch = out
+    return
+end
+admm_update_lz(env::AdmmEnv, mod::AbstractOPFModel, dev::HipNative) =
+    hipcheck(ccall((:exaadmm_update_lz, libexaadmm_hip), Cint, (Ptr{Cvoid}, Cdouble), dev.handle, env.params.beta), "exaadmm_update_lz")
+function admm_poststep(env::AdmmEnv, mod::AbstractOPFModel, dev::HipNative)
+    r = Ref{Float64}(0.0)
+    hipcheck(ccall((:exaadmm_objective, libexaadmm_hip), Cint, (Ptr{Cvoid}, Ref{Float64}), dev.handle, r), "exaadmm_objective")
+    mod.info.objval = r[]
+    download!(dev, mod)
+    return
+end
+
+"solve_acopf with the MI355X backend; same keyword surface as interface/solve_acopf.jl:1-7."
+function solve_acopf_hip(case::String; case_format="matpower", outer_iterlim=20, inner_iterlim=1000,
+        rho_pq=400.0, rho_va=40000.0, obj_scale=1.0, scale=1e-4, tight_factor=1.0, outer_eps=2e-4,
+        gpu_no=0, verbose=1, fused=false)
+    T = Float64; TD = Array{Float64,1}; TI = Array{Int,1}; TM = Array{Float64,2}
+    env = AdmmEnv{T,TD,TI,TM}(case, rho_pq, rho_va; case_format=case_format, use_gpu=false,
+                              tight_factor=tight_factor, verbose=verbose)
+    mod = ModelAcopf{T,TD,TI,TM}(env)
+    env.params.scale = scale; env.params.obj_scale = obj_scale; env.params.outer_eps = outer_eps
+    env.params.outer_iterlim = outer_iterlim; env.params.inner_iterlim = inner_iterlim
+    dev = HipNative(env, mod; gpu_no=gpu_no)
+    if fused   # whole driver inside the library, loop control on the device
+        info = zeros(UInt8, 160)
+        hipcheck(ccall((:exaadmm_solve_two_level, libexaadmm_hip), Cint, (Ptr{Cvoid}, Ptr{UInt8}), dev.handle, info),
+                 "exaadmm_solve_two_level")
+        ints = reinterpret(Int32, info[1:16]); dbl = reinterpret(Float64, info[17:end])
+        mod.info.status = ints[1] == 1 ? :Solved : :IterationLimit
+        mod.info.inner, mod.info.outer, mod.info.cumul = ints[2], ints[3], ints[4]
+        mod.info.objval, mod.info.primres, mod.info.dualres, mod.info.mismatch = dbl[1:4]
+        mod.info.norm_z_curr, mod.info.norm_z_prev, mod.info.eps_pri, mod.info.time_overall = dbl[5:8]
+        download!(dev, mod)
+    else       # the reference's own driver, unchanged, calling the step-wise entry points
+        admm_two_level(env, mod, dev)
+    end
+    return env, mod
+end

@@ -123,12 +123,18 @@ def library():
     L.exaadmm_solve_two_level.argtypes = [H, C.POINTER(Info)]
     L.exaadmm_run_fixed.argtypes = [H, C.c_int, C.c_int, C.c_double, c_double_p, c_double_p, c_double_p]
     L.exaadmm_set_stream.argtypes = [H, C.c_void_p]
-    L.exaadmm_residual_partial_sums.argtypes = [H, C.POINTER(C.c_void_p)]
-    L.exaadmm_set_halo_index.argtypes = [H, C.c_int, c_i64_p, C.c_int64]
-    L.exaadmm_halo_pack.argtypes = [H, C.c_int, C.c_int, C.c_void_p]
-    L.exaadmm_halo_unpack.argtypes = [H, C.c_int, C.c_int, C.c_void_p]
+    L.exaadmm_set_async.argtypes = [H, C.c_int]
+    L.exaadmm_set_active.argtypes = [H, C.c_int64, C.c_int64]
     L.exaadmm_set_owned_mask.argtypes = [H, C.POINTER(C.c_uint8), C.c_int64]
-    L.exaadmm_update_zl_partial.argtypes = [H, C.c_double, C.POINTER(C.c_void_p)]
+    L.exaadmm_set_halo_index.argtypes = [H, C.c_int, C.POINTER(C.c_int32), c_i64_p, C.c_int64]
+    L.exaadmm_halo_pack.argtypes = [H, C.c_int, C.c_void_p]
+    L.exaadmm_halo_unpack.argtypes = [H, C.c_int, C.c_void_p]
+    L.exaadmm_update_zl_partial.argtypes = [H, C.c_double, C.c_void_p]
+    L.exaadmm_sumsq_z_partial.argtypes = [H, C.c_void_p]
+    L.exaadmm_ctrl_begin.argtypes = [H, C.c_int, C.c_int, C.c_double, C.c_int64]
+    L.exaadmm_ctrl_step.argtypes = [H, C.c_void_p]
+    L.exaadmm_ctrl_read.argtypes = [H, C.POINTER(C.c_int), C.POINTER(C.c_int), c_double_p]
+    L.exaadmm_ctrl_end.argtypes = [H]
     L.exaadmm_load_matpower.argtypes = [C.c_char_p, C.c_double, C.c_char_p, C.POINTER(C.c_void_p)]
     L.exaadmm_case_grid.argtypes = [C.c_void_p, C.POINTER(Grid)]
     L.exaadmm_case_free.argtypes = [C.c_void_p]

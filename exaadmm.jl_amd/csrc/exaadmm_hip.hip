@@ -54,6 +54,7 @@ struct InitData {
 };
 
 struct HaloSlot {
+    int* d_which = nullptr;
     int* d_idx = nullptr;
     int count = 0;
 };
@@ -79,6 +80,8 @@ struct exaadmm_handle {
     unsigned char* d_owned = nullptr;
     HaloSlot halo[8];
     bool residual_vectors_valid = false;
+    bool async_mode = false;
+    bool ctrl_mode = false;
     exaadmm_info info;
     std::vector<hipEvent_t> ev;
     InitData init;
@@ -202,10 +205,18 @@ static int build_csr(exaadmm_handle* h, const int64_t* start, const int64_t* idx
 {
     std::vector<int> s(nbus + 1), ix((size_t)std::max<int64_t>(nnz_expected, 0));
     for (int i = 0; i <= nbus; i++) s[i] = (int)(start[i] - base);
-    if (s[0] != 0 || s[nbus] != nnz_expected) {
-        set_err("CSR start array inconsistent (first=%d last=%d expected nnz=%lld)", s[0], s[nbus], (long long)nnz_expected);
+    // a partition lists only the ends that touch its own buses: nnz may be smaller than the count
+    if (s[0] != 0 || s[nbus] < 0 || s[nbus] > nnz_expected) {
+        set_err("CSR start array inconsistent (first=%d last=%d max nnz=%lld)", s[0], s[nbus], (long long)nnz_expected);
         return EXAADMM_ERR_INVALID;
     }
+    for (int i = 0; i < nbus; i++)
+        if (s[i + 1] < s[i]) {
+            set_err("CSR start array not monotone");
+            return EXAADMM_ERR_INVALID;
+        }
+    nnz_expected = s[nbus];
+    ix.resize((size_t)nnz_expected);
     for (int64_t k = 0; k < nnz_expected; k++) {
         ix[k] = (int)(idx[k] - base);
         if (ix[k] < 0 || ix[k] >= idx_limit) {
@@ -263,6 +274,7 @@ extern "C" int exaadmm_create(const exaadmm_grid* g, const exaadmm_params* p, in
     memset(&h->d, 0, sizeof(h->d));
     Dev& d = h->d;
     d.G = h->G; d.L = h->L; d.B = h->B; d.Gp = h->Gp; d.Lp = h->Lp; d.N = h->N;
+    d.La = h->L; d.Ba = h->B;
     const int base = g->index_base;
     int rc = 0;
 #define TRY(x) do { if ((rc = (x))) { exaadmm_destroy(h); return rc; } } while (0)
@@ -371,8 +383,10 @@ extern "C" int exaadmm_destroy(exaadmm_handle* h)
     (void)hipSetDevice(h->device);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     for (void* p : h->allocs) (void)hipFree(p);
-    for (auto& s : h->halo)
+    for (auto& s : h->halo) {
         if (s.d_idx) (void)hipFree(s.d_idx);
+        if (s.d_which) (void)hipFree(s.d_which);
+    }
     if (h->d_owned) (void)hipFree(h->d_owned);
     if (h->h_ctrl) (void)hipHostFree(h->h_ctrl);
     if (h->h_sums) (void)hipHostFree(h->h_sums);
@@ -580,32 +594,33 @@ static void launch_gen(exaadmm_handle* h, const Ctrl* c)
 }
 static void launch_branch(exaadmm_handle* h, int major_iter, const Ctrl* c)
 {
-    hipLaunchKernelGGL(k_branch, grid_for(h->L, BR_BLOCK), dim3(BR_BLOCK), 0, h->stream, h->d, h->bo, h->par.scale, major_iter, c);
+    hipLaunchKernelGGL(k_branch, grid_for(h->d.La, BR_BLOCK), dim3(BR_BLOCK), 0, h->stream, h->d, h->bo, h->par.scale, major_iter, c);
 }
 static void launch_bus(exaadmm_handle* h, const Ctrl* c)
 {
-    hipLaunchKernelGGL(k_bus, grid_for(h->B, 64), dim3(64), 0, h->stream, h->d, h->baseMVA, c);
+    hipLaunchKernelGGL(k_bus, grid_for(h->d.Ba, 64), dim3(64), 0, h->stream, h->d, h->baseMVA, c);
 }
 static void launch_fused_zl(exaadmm_handle* h, double beta, const Ctrl* c)
 {
     hipLaunchKernelGGL(k_fused_zl, dim3(h->ew_blocks), dim3(EW_BLOCK), 0, h->stream, h->d, beta, c);
 }
-static void launch_final(exaadmm_handle* h, Ctrl* c)
+static void launch_final(exaadmm_handle* h, Ctrl* c, double* out = nullptr)
 {
-    hipLaunchKernelGGL(k_final_reduce, dim3(1), dim3(EW_BLOCK), 0, h->stream, h->d.partials, h->ew_blocks, h->d_sums, c);
+    hipLaunchKernelGGL(k_final_reduce, dim3(1), dim3(EW_BLOCK), 0, h->stream, h->d.partials, h->ew_blocks,
+                       out ? out : h->d_sums, c);
 }
 
-static int sync_check(exaadmm_handle* h)
+static int sync_check(exaadmm_handle* h, bool force = false)
 {
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(h->stream));
+    if (force || !h->async_mode) HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
 }
 
 static int fetch_sums(exaadmm_handle* h, double out[4], bool take_sqrt)
 {
     HIPCHK(hipMemcpyAsync(h->h_sums, h->d_sums, 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    int rc = sync_check(h);
+    int rc = sync_check(h, true);
     if (rc) return rc;
     for (int j = 0; j < 4; j++) out[j] = take_sqrt ? sqrt(h->h_sums[j]) : h->h_sums[j];
     return 0;
@@ -625,7 +640,7 @@ extern "C" int exaadmm_update_x_gen(exaadmm_handle* h)
 {
     REQUIRE(h, "null handle");
     HIPCHK(hipSetDevice(h->device));
-    launch_gen(h, nullptr);
+    launch_gen(h, h->ctrl_mode ? h->d_ctrl : nullptr);
     h->residual_vectors_valid = false;
     return sync_check(h);
 }
@@ -634,7 +649,7 @@ extern "C" int exaadmm_update_x_line(exaadmm_handle* h, int major_iter)
 {
     REQUIRE(h, "null handle");
     HIPCHK(hipSetDevice(h->device));
-    launch_branch(h, major_iter, nullptr);
+    launch_branch(h, major_iter, h->ctrl_mode ? h->d_ctrl : nullptr);
     h->residual_vectors_valid = false;
     return sync_check(h);
 }
@@ -644,7 +659,7 @@ extern "C" int exaadmm_update_x(exaadmm_handle* h, int major_iter)
     REQUIRE(h, "null handle");
     HIPCHK(hipSetDevice(h->device));
     launch_gen(h, nullptr);
-    launch_branch(h, major_iter, nullptr);
+    launch_branch(h, major_iter, h->ctrl_mode ? h->d_ctrl : nullptr);
     h->residual_vectors_valid = false;
     return sync_check(h);
 }
@@ -653,7 +668,7 @@ extern "C" int exaadmm_update_xbar(exaadmm_handle* h)
 {
     REQUIRE(h, "null handle");
     HIPCHK(hipSetDevice(h->device));
-    launch_bus(h, nullptr);
+    launch_bus(h, h->ctrl_mode ? h->d_ctrl : nullptr);
     h->residual_vectors_valid = false;
     return sync_check(h);
 }
@@ -693,28 +708,23 @@ extern "C" int exaadmm_update_residual(exaadmm_handle* h, double out[4])
     return fetch_sums(h, out, true);
 }
 
-extern "C" int exaadmm_residual_partial_sums(exaadmm_handle* h, double** dev_ptr)
+extern "C" int exaadmm_update_zl_partial(exaadmm_handle* h, double beta, double* dev_out4)
 {
-    REQUIRE(h && dev_ptr, "null argument");
+    REQUIRE(h && dev_out4, "null argument");
     HIPCHK(hipSetDevice(h->device));
-    hipLaunchKernelGGL(k_residual, dim3(h->ew_blocks), dim3(EW_BLOCK), 0, h->stream, h->d);
-    launch_final(h, nullptr);
-    h->residual_vectors_valid = true;
-    HIPCHK(hipGetLastError());
-    *dev_ptr = h->d_sums;
-    return EXAADMM_OK;
+    launch_fused_zl(h, beta, h->ctrl_mode ? h->d_ctrl : nullptr);
+    launch_final(h, nullptr, dev_out4);
+    h->residual_vectors_valid = false;
+    return sync_check(h);
 }
 
-extern "C" int exaadmm_update_zl_partial(exaadmm_handle* h, double beta, double** dev_sums)
+extern "C" int exaadmm_sumsq_z_partial(exaadmm_handle* h, double* dev_out4)
 {
-    REQUIRE(h && dev_sums, "null argument");
+    REQUIRE(h && dev_out4, "null argument");
     HIPCHK(hipSetDevice(h->device));
-    launch_fused_zl(h, beta, nullptr);
-    launch_final(h, nullptr);
-    h->residual_vectors_valid = false;
-    HIPCHK(hipGetLastError());
-    *dev_sums = h->d_sums;
-    return EXAADMM_OK;
+    hipLaunchKernelGGL(k_sumsq_z, dim3(h->ew_blocks), dim3(EW_BLOCK), 0, h->stream, h->d);
+    launch_final(h, nullptr, dev_out4);
+    return sync_check(h);
 }
 
 extern "C" int exaadmm_norm_z(exaadmm_handle* h, double* out)
@@ -809,7 +819,7 @@ extern "C" int exaadmm_run_inner(exaadmm_handle* h, int outer, int max_inner, do
         for (int i = 0; i < nb; i++) enqueue_iteration(h, h->d_ctrl);
         enq += nb;
         HIPCHK(hipMemcpyAsync(hc, h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
-        int rc = sync_check(h);
+        int rc = sync_check(h, true);
         if (rc) return rc;
         if (hc->done) break;
     }
@@ -913,53 +923,119 @@ extern "C" int exaadmm_run_fixed(exaadmm_handle* h, int iters, int first_major_i
 }
 
 // ------------------------------------------------------------------ multi-GPU helpers
-extern "C" int exaadmm_set_halo_index(exaadmm_handle* h, int slot, const int64_t* idx, int64_t count)
+extern "C" int exaadmm_ctrl_begin(exaadmm_handle* h, int outer, int max_inner, double beta, int64_t nvar_global)
+{
+    REQUIRE(h && outer >= 1 && max_inner >= 1 && nvar_global >= 1, "bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    Ctrl* hc = h->h_ctrl;
+    memset(hc, 0, sizeof(Ctrl));
+    hc->max_inner = max_inner;
+    hc->check_every = std::max(1, (int)h->par.check_every);
+    hc->eps_pri = sqrt((double)nvar_global) / (2500.0 * outer);
+    hc->beta = beta;
+    HIPCHK(hipMemcpyAsync(h->d_ctrl, hc, sizeof(Ctrl), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->ctrl_mode = true;
+    return EXAADMM_OK;
+}
+
+extern "C" int exaadmm_ctrl_step(exaadmm_handle* h, const double* dev_sums4)
+{
+    REQUIRE(h && dev_sums4 && h->ctrl_mode, "ctrl not armed");
+    HIPCHK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_ctrl_step, dim3(1), dim3(64), 0, h->stream, dev_sums4, h->d_ctrl);
+    return sync_check(h);
+}
+
+extern "C" int exaadmm_ctrl_read(exaadmm_handle* h, int* done, int* inner, double res[4])
+{
+    REQUIRE(h && h->ctrl_mode, "ctrl not armed");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(h->h_ctrl, h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
+    int rc = sync_check(h, true);
+    if (rc) return rc;
+    if (done) *done = h->h_ctrl->done;
+    if (inner) *inner = h->h_ctrl->inner;
+    if (res)
+        for (int j = 0; j < 4; j++) res[j] = h->h_ctrl->res[j];
+    return EXAADMM_OK;
+}
+
+extern "C" int exaadmm_ctrl_end(exaadmm_handle* h)
+{
+    REQUIRE(h, "null handle");
+    h->ctrl_mode = false;
+    return EXAADMM_OK;
+}
+
+extern "C" int exaadmm_set_async(exaadmm_handle* h, int async)
+{
+    REQUIRE(h, "null handle");
+    h->async_mode = (async != 0);
+    return EXAADMM_OK;
+}
+
+extern "C" int exaadmm_set_active(exaadmm_handle* h, int64_t nbranch, int64_t nbus)
+{
+    REQUIRE(h && nbranch >= 0 && nbranch <= h->L && nbus >= 0 && nbus <= h->B, "active counts out of range");
+    h->d.La = (int)nbranch;
+    h->d.Ba = (int)nbus;
+    return EXAADMM_OK;
+}
+
+static VecTable vec_table(exaadmm_handle* h)
+{
+    VecTable t;
+    for (int w = 0; w < 10; w++) t.p[w] = vec_ptr(h, w);
+    return t;
+}
+
+extern "C" int exaadmm_set_halo_index(exaadmm_handle* h, int slot, const int32_t* which, const int64_t* idx, int64_t count)
 {
     REQUIRE(h && slot >= 0 && slot < 8 && count >= 0, "bad argument");
     HIPCHK(hipSetDevice(h->device));
     HaloSlot& s = h->halo[slot];
-    if (s.d_idx) {
-        (void)hipFree(s.d_idx);
-        s.d_idx = nullptr;
-    }
+    if (s.d_idx) { (void)hipFree(s.d_idx); s.d_idx = nullptr; }
+    if (s.d_which) { (void)hipFree(s.d_which); s.d_which = nullptr; }
     s.count = (int)count;
     if (count == 0) return EXAADMM_OK;
-    REQUIRE(idx, "null index list");
-    std::vector<int> t(count);
+    REQUIRE(idx && which, "null index list");
+    std::vector<int> t(count), w(count);
     for (int64_t i = 0; i < count; i++) {
         REQUIRE(idx[i] >= 0 && idx[i] < h->nvar, "halo index out of range (zero-based reference-layout index expected)");
+        REQUIRE(which[i] >= 0 && which[i] < 10, "halo vector id out of range");
         t[i] = soa_index(h, idx[i]);
+        w[i] = which[i];
     }
     HIPCHK(hipMalloc((void**)&s.d_idx, count * sizeof(int)));
+    HIPCHK(hipMalloc((void**)&s.d_which, count * sizeof(int)));
     HIPCHK(hipMemcpy(s.d_idx, t.data(), count * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(s.d_which, w.data(), count * sizeof(int), hipMemcpyHostToDevice));
     return EXAADMM_OK;
 }
 
-extern "C" int exaadmm_halo_pack(exaadmm_handle* h, int slot, int which, double* dev_buf)
+extern "C" int exaadmm_halo_pack(exaadmm_handle* h, int slot, double* dev_buf)
 {
     REQUIRE(h && slot >= 0 && slot < 8, "bad argument");
     const HaloSlot& s = h->halo[slot];
     if (s.count == 0) return EXAADMM_OK;
-    double* src = vec_ptr(h, which);
-    REQUIRE(src && dev_buf, "bad vector / buffer");
+    REQUIRE(dev_buf, "null buffer");
     HIPCHK(hipSetDevice(h->device));
-    hipLaunchKernelGGL(k_gather, grid_for(s.count, 256), dim3(256), 0, h->stream, src, s.d_idx, s.count, dev_buf);
-    HIPCHK(hipGetLastError());
-    return EXAADMM_OK;
+    hipLaunchKernelGGL(k_gather, grid_for(s.count, 256), dim3(256), 0, h->stream, vec_table(h), s.d_which, s.d_idx, s.count, dev_buf);
+    return sync_check(h);
 }
 
-extern "C" int exaadmm_halo_unpack(exaadmm_handle* h, int slot, int which, const double* dev_buf)
+extern "C" int exaadmm_halo_unpack(exaadmm_handle* h, int slot, const double* dev_buf)
 {
     REQUIRE(h && slot >= 0 && slot < 8, "bad argument");
     const HaloSlot& s = h->halo[slot];
     if (s.count == 0) return EXAADMM_OK;
-    double* dst = vec_ptr(h, which);
-    REQUIRE(dst && dev_buf, "bad vector / buffer");
+    REQUIRE(dev_buf, "null buffer");
     HIPCHK(hipSetDevice(h->device));
-    hipLaunchKernelGGL(k_scatter, grid_for(s.count, 256), dim3(256), 0, h->stream, dst, s.d_idx, s.count, dev_buf);
-    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_scatter, grid_for(s.count, 256), dim3(256), 0, h->stream, vec_table(h), s.d_which, s.d_idx, s.count, dev_buf);
     h->residual_vectors_valid = false;
-    return EXAADMM_OK;
+    return sync_check(h);
 }
 
 extern "C" int exaadmm_set_owned_mask(exaadmm_handle* h, const uint8_t* mask, int64_t nvar)

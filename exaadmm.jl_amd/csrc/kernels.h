@@ -27,6 +27,7 @@ struct Ctrl {
 
 struct Dev {
     int G, L, B, Gp, Lp, N;
+    int La, Ba;  // active branches / buses (<= L, B): a partition's ghosts come after them
     double *u, *v, *z, *zp, *l, *lz, *rho;
     double *rp, *rd, *ax;
     const double* Y;    // 8 planes x Lp
@@ -71,7 +72,7 @@ __global__ void __launch_bounds__(BR_BLOCK) k_branch(Dev d, BranchOptions o, dou
         major_iter = ctrl->inner + 1;
     }
     const int b = blockIdx.x * BR_BLOCK + threadIdx.x;
-    if (b >= d.L) return;
+    if (b >= d.La) return;
     const int Lp = d.Lp;
     const int base = 2 * d.Gp + b;
 
@@ -120,7 +121,7 @@ __global__ void k_bus(Dev d, double baseMVA, const Ctrl* ctrl)
 {
     if (loop_done(ctrl)) return;
     const int I = blockIdx.x * blockDim.x + threadIdx.x;
-    if (I >= d.B) return;
+    if (I >= d.Ba) return;
     const int Lp = d.Lp, Gp = d.Gp, lb = 2 * d.Gp;
     const double *u = d.u, *z = d.z, *l = d.l, *rho = d.rho;
     double* v = d.v;
@@ -366,6 +367,20 @@ __global__ void __launch_bounds__(EW_BLOCK) k_final_reduce(const double* partial
     }
 }
 
+// distributed loop: consume all-reduced sums (admm_two_level.jl:45,60-62 on the device)
+__global__ void k_ctrl_step(const double* sums, Ctrl* ctrl)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0 || ctrl->done) return;
+    for (int j = 0; j < 4; j++) {
+        ctrl->sums[j] = sums[j];
+        ctrl->res[j] = sqrt(sums[j]);
+    }
+    const int inner = ctrl->inner + 1;
+    ctrl->inner = inner;
+    const bool test = (ctrl->check_every <= 1) || (inner % ctrl->check_every == 0);
+    if ((test && ctrl->res[0] <= ctrl->eps_pri) || inner >= ctrl->max_inner) ctrl->done = 1;
+}
+
 // rp, rd, Ax_plus_By from u, v, z, z_prev (only needed when a caller downloads them after a fused loop)
 __global__ void k_materialize(Dev d)
 {
@@ -378,17 +393,21 @@ __global__ void k_materialize(Dev d)
     }
 }
 
-// halo exchange helpers: gather / scatter through a SoA index list
-__global__ void k_gather(const double* src, const int* idx, int n, double* dst)
+// halo exchange helpers: gather / scatter (vector id, SoA index) lists
+struct VecTable {
+    double* p[10];
+};
+
+__global__ void k_gather(VecTable t, const int* which, const int* idx, int n, double* dst)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = src[idx[i]];
+    if (i < n) dst[i] = t.p[which[i]][idx[i]];
 }
 
-__global__ void k_scatter(double* dst, const int* idx, int n, const double* src)
+__global__ void k_scatter(VecTable t, const int* which, const int* idx, int n, const double* src)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[idx[i]] = src[i];
+    if (i < n) t.p[which[i]][idx[i]] = src[i];
 }
 
 }  // namespace exa

@@ -153,22 +153,40 @@ int exaadmm_solve_two_level(exaadmm_handle *h, exaadmm_info *out);
 int exaadmm_run_fixed(exaadmm_handle *h, int iters, int first_major_iter, double beta, double out[4],
                       double *ms_total, double *ms_branch);
 
-/* ---- multi-GPU helpers (one handle = one partition; see DESIGN.md "multi-GPU") ---- */
+/* ---- multi-GPU helpers (one handle = one partition of the grid) ---- */
 /* run on a caller-provided HIP stream (e.g. torch's current stream); NULL = library stream */
 int exaadmm_set_stream(exaadmm_handle *h, void *hip_stream);
-/* squared partial sums {|rp|^2, |rd|^2, |z|^2, |Ax+By|^2} of the elements this handle owns,
- * left on the device at *dev_ptr (4 doubles) for an all-reduce by the caller */
-int exaadmm_residual_partial_sums(exaadmm_handle *h, double **dev_ptr);
-/* gather/scatter `count` entries (reference-layout indices idx[], base per grid.index_base)
- * of one solution vector into/from a contiguous DEVICE buffer (halo exchange) */
-int exaadmm_set_halo_index(exaadmm_handle *h, int slot, const int64_t *idx, int64_t count);
-int exaadmm_halo_pack(exaadmm_handle *h, int slot, int which, double *dev_buf);
-int exaadmm_halo_unpack(exaadmm_handle *h, int slot, int which, const double *dev_buf);
+/* async != 0: step-wise entry points only enqueue (no stream synchronisation on return);
+ * the caller orders them against its collectives through the stream */
+int exaadmm_set_async(exaadmm_handle *h, int async);
+/* a partition stores its own ("native") branches first and ghost copies of remote branches
+ * after them, owned buses first: restrict the branch kernel to the first nbranch branches and
+ * the bus kernel to the first nbus buses (defaults: all) */
+int exaadmm_set_active(exaadmm_handle *h, int64_t nbranch, int64_t nbus);
 /* elementwise steps restricted by an ownership mask (1 = this rank owns the element's
- * z/l/lz/residual contribution); NULL restores "owns everything" */
+ * z / l / lz / residual contribution); NULL restores "owns everything" */
 int exaadmm_set_owned_mask(exaadmm_handle *h, const uint8_t *mask, int64_t nvar);
-/* fused z + l + residual partial sums without the final norm (distributed inner iteration) */
-int exaadmm_update_zl_partial(exaadmm_handle *h, double beta, double **dev_sums);
+/* halo lists: entry i moves element idx[i] (zero-based reference-layout index) of solution
+ * vector which[i] (exaadmm_vector).  pack gathers into a contiguous DEVICE buffer, unpack
+ * scatters from one; 8 slots per handle */
+int exaadmm_set_halo_index(exaadmm_handle *h, int slot, const int32_t *which, const int64_t *idx, int64_t count);
+int exaadmm_halo_pack(exaadmm_handle *h, int slot, double *dev_buf);
+int exaadmm_halo_unpack(exaadmm_handle *h, int slot, const double *dev_buf);
+/* fused z_prev/z/l update of the owned elements; the 4 partial sums of squares
+ * {|rp|^2, |rd|^2, |z|^2, |Ax+By|^2} are written to dev_out4 (DEVICE memory) for an
+ * all-reduce by the caller.  exaadmm_sumsq_z_partial: dev_out4[2] = sum z^2 of owned elements. */
+int exaadmm_update_zl_partial(exaadmm_handle *h, double beta, double *dev_out4);
+int exaadmm_sumsq_z_partial(exaadmm_handle *h, double *dev_out4);
+/* Device-resident loop control for a distributed inner loop (same Ctrl block the fused
+ * single-GPU loop uses).  ctrl_begin arms it for outer iteration `outer`; while armed, the
+ * step-wise entry points become no-ops on the device once the loop has converged, the branch
+ * kernel takes major_iter = completed iterations + 1, z/l updates take beta from the block.
+ * ctrl_step consumes the ALL-REDUCED sums (device pointer): inner++, norms = sqrt(sums),
+ * done = primres <= sqrt(nvar_global)/(2500*outer) or inner == max_inner.  ctrl_read syncs. */
+int exaadmm_ctrl_begin(exaadmm_handle *h, int outer, int max_inner, double beta, int64_t nvar_global);
+int exaadmm_ctrl_step(exaadmm_handle *h, const double *dev_sums4);
+int exaadmm_ctrl_read(exaadmm_handle *h, int *done, int *inner, double res[4]);
+int exaadmm_ctrl_end(exaadmm_handle *h);
 
 /* ---- MATPOWER ingest (next row f1: utils/parse_matpower.jl, utils/opfdata.jl) ---- */
 int exaadmm_load_matpower(const char *path, double tight_factor, const char *case_format, exaadmm_case **out);

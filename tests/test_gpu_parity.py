@@ -187,3 +187,68 @@ def test_properties_at_benchmark_size(pkg, syn):
     pij = g["YffR"] * vi ** 2 + g["YftR"] * vi * vj * np.cos(th) + g["YftI"] * vi * vj * np.sin(th)
     assert np.allclose(ub[:, 0], pij, rtol=1e-9, atol=1e-9)
     assert (ub[:, 4] >= 0.81 - 1e-12).all() and (ub[:, 4] <= 1.21 + 1e-12).all()
+
+
+def test_two_partitions_on_one_gpu_match_single_handle(pkg, syn, oracle):
+    """Multi-GPU helpers of the C ABI on real hardware: two partitions (two handles) of one grid
+    driven in lockstep on the same GPU, halo exchange emulated by device-to-device copies in the
+    all_to_all layout; must reproduce the single-handle trajectory (1e-10) and the oracle."""
+    import torch
+    dm = exaadmm_loader.load_submodule("distributed")
+    g = syn.sized_like("case1354pegase", seed=2)
+    rho = (1e1, 1e3)
+    world = 2
+    st = dm.init_state(g, *rho)
+    parts = [dm.Partition(g, world, r) for r in range(world)]
+    assert parts[0].n_cut + parts[1].n_cut > 0
+    bes = [dm.HipBackend(pkg, p, rho[0], rho[1], device_index=0) for p in parts]
+    bufs = []
+    for p, be in zip(parts, bes):
+        for name in ("v_curr", "rho"):
+            be.upload(name, p.slice_global(st[name]))
+        bufs.append([be.new_buffer(sum(pl[2])) for pl in (p.plan_send_uzl, p.plan_recv_uzl, p.plan_send_v, p.plan_recv_v)])
+
+    def exchange(send_slot, recv_slot, send_plan, recv_plan):
+        # all_to_all_single semantics: block q of rank r's send buffer -> block r of rank q's recv buffer
+        for r in range(world):
+            so = np.concatenate([[0], np.cumsum(getattr(parts[r], send_plan)[2])])
+            for q in range(world):
+                ro = np.concatenate([[0], np.cumsum(getattr(parts[q], recv_plan)[2])])
+                n = so[q + 1] - so[q]
+                assert n == ro[r + 1] - ro[r]
+                if n:
+                    bufs[q][recv_slot][ro[r]:ro[r + 1]] = bufs[r][send_slot][so[q]:so[q + 1]]
+
+    env = pkg.AdmmEnv("single", rho[0], rho[1], verbose=0, grid=g)
+    single = pkg.ModelAcopf(env)
+    ref = oracle.OracleModel(g, *rho)
+    beta = 1e3
+    for it in range(1, 7):
+        for be, b in zip(bes, bufs):
+            be.update_x(it)
+            be.pack(0, b[0])
+        torch.cuda.synchronize()
+        exchange(0, 1, "plan_send_uzl", "plan_recv_uzl")
+        for be, b in zip(bes, bufs):
+            be.unpack(1, b[1])
+            be.update_xbar()
+            be.pack(2, b[2])
+        torch.cuda.synchronize()
+        exchange(2, 3, "plan_send_v", "plan_recv_v")
+        tot = torch.zeros(4, dtype=torch.float64, device="cuda")
+        for be, b in zip(bes, bufs):
+            be.unpack(3, b[3])
+            tot += be.update_zl_partial(beta)
+        torch.cuda.synchronize()
+        norms = torch.sqrt(tot).cpu().numpy()
+        n1, _, _ = single.run_fixed(1, first_major_iter=it, beta=beta)
+        ref.inner_prestep(); ref.update_x(it); ref.update_xbar(); ref.update_z(); ref.update_l()
+        r = ref.update_residual()
+        assert np.allclose(norms, n1, rtol=1e-10), (it, norms, n1)
+        assert np.allclose(norms, r, rtol=1e-8), (it, norms, r)
+    for name in ("u_curr", "v_curr", "z_curr", "l_curr"):
+        glob = np.zeros(parts[0].nvar_global)
+        for p, be in zip(parts, bes):
+            glob[p.local_index_map()[:p.nvar_owned]] = be.download(name)[:p.nvar_owned]
+        one = getattr(single.solution, name)
+        assert np.abs(glob - one).max() <= 1e-10 * max(1.0, np.abs(one).max()), name

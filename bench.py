@@ -76,12 +76,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--case", default=CASE)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU code path even with one rank")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or args.force_dist:
         import exaadmm_loader
         dist_mod = exaadmm_loader.load_submodule("distributed")
         return dist_mod.bench_main(args, rank, world, local_rank)

@@ -412,6 +412,10 @@ def bench_main(args, rank, world, local_rank):
 
     torch.cuda.set_device(local_rank)
     if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     world = dist.get_world_size()
     params = B.CASE_PARAMS[args.case]

@@ -24,10 +24,27 @@ namespace exa {
 
 // Problem constants of one branch.  lam/rho/xt are rows 1-8 / 9-16 / 17-24 of the
 // reference's membuf, ls1/ls2/mu rows 25/26/27 (acopf_auglag_linelimit_kernel_gpu.jl:49-79).
+// Y = YffR YffI YftR YftI YttR YttI YtfR YtfI.
+// BranchData owns the 32 read-only constants; BranchDataRef<STRIDE> views them in storage with
+// an element stride (the kernel stages them in LDS as [k][lane], STRIDE = 64).  The three
+// values the augmented-Lagrangian loop updates stay in registers either way.
 struct BranchData {
-    double lam[8], rho[8], xt[8];
-    double Y[8];  // YffR YffI YftR YftI YttR YttI YtfR YtfI
+    double lam_[8], rho_[8], xt_[8], Y_[8];
     double ls1, ls2, mu, scale;
+    EXA_HD double lam(int k) const { return lam_[k]; }
+    EXA_HD double rho(int k) const { return rho_[k]; }
+    EXA_HD double xt(int k) const { return xt_[k]; }
+    EXA_HD double Y(int k) const { return Y_[k]; }
+};
+
+template <int STRIDE>
+struct BranchDataRef {
+    const double* p;  // 32 entries: lam[8] rho[8] xt[8] Y[8]
+    double ls1, ls2, mu, scale;
+    EXA_HD double lam(int k) const { return p[k * STRIDE]; }
+    EXA_HD double rho(int k) const { return p[(8 + k) * STRIDE]; }
+    EXA_HD double xt(int k) const { return p[(16 + k) * STRIDE]; }
+    EXA_HD double Y(int k) const { return p[(24 + k) * STRIDE]; }
 };
 
 // constants of the augmented-Lagrangian loop and of the TRON driver
@@ -41,16 +58,20 @@ struct BranchOptions {
     double fatol;      // 0
     double fmin;       // -1e32
     double cgtol;      // 0.1
-    // mu only takes the values 10^k (k = 1..8) in normal operation; host-computed
-    // mu^0.1 and mu^0.9 for those (same libm as the CPU path), pow() otherwise.
+};
+
+// mu only takes the values 10^k (k = 1..8) in normal operation; host-computed mu^0.1 and
+// mu^0.9 for those (same libm as the CPU path), pow() otherwise.  Kept out of the kernel
+// arguments (48 SGPRs) in a small table the lanes index on demand.
+struct MuPowTable {
     double pow10[8], pow01[8], pow09[8];
 };
 
-EXA_HD double mu_pow(const BranchOptions& o, double mu, bool nine)
+EXA_HD double mu_pow(const MuPowTable& t, double mu, bool nine)
 {
     EXA_UNROLL
     for (int k = 0; k < 8; k++)
-        if (mu == o.pow10[k]) return nine ? o.pow09[k] : o.pow01[k];
+        if (mu == t.pow10[k]) return nine ? t.pow09[k] : t.pow01[k];
     return pow(mu, nine ? 0.9 : 0.1);
 }
 
@@ -58,45 +79,49 @@ struct FlowTrig {
     double vi2, vj2, vv, E0, F0, E2, F2;
 };
 
-EXA_HD void flow_trig(const BranchData& d, const double (&x)[6], FlowTrig& t)
+template <class D>
+EXA_HD void flow_trig(const D& d, const double (&x)[6], FlowTrig& t)
 {
     double sn, cs;
     sincos(x[2] - x[3], &sn, &cs);
     t.vi2 = x[0] * x[0];
     t.vj2 = x[1] * x[1];
     t.vv = x[0] * x[1];
-    t.E0 = d.Y[2] * cs + d.Y[3] * sn;
-    t.F0 = d.Y[3] * cs - d.Y[2] * sn;
-    t.E2 = d.Y[6] * cs - d.Y[7] * sn;
-    t.F2 = -d.Y[6] * sn - d.Y[7] * cs;
+    t.E0 = d.Y(2) * cs + d.Y(3) * sn;
+    t.F0 = d.Y(3) * cs - d.Y(2) * sn;
+    t.E2 = d.Y(6) * cs - d.Y(7) * sn;
+    t.F2 = -d.Y(6) * sn - d.Y(7) * cs;
 }
 
 // flows (pij, qij, pji, qji)
-EXA_HD void flows_from_trig(const BranchData& d, const FlowTrig& t, double (&phi)[4])
+template <class D>
+EXA_HD void flows_from_trig(const D& d, const FlowTrig& t, double (&phi)[4])
 {
-    phi[0] = d.Y[0] * t.vi2 + t.vv * t.E0;
-    phi[1] = -d.Y[1] * t.vi2 - t.vv * t.F0;
-    phi[2] = d.Y[4] * t.vj2 + t.vv * t.E2;
-    phi[3] = -d.Y[5] * t.vj2 + t.vv * t.F2;
+    phi[0] = d.Y(0) * t.vi2 + t.vv * t.E0;
+    phi[1] = -d.Y(1) * t.vi2 - t.vv * t.F0;
+    phi[2] = d.Y(4) * t.vj2 + t.vv * t.E2;
+    phi[3] = -d.Y(5) * t.vj2 + t.vv * t.F2;
 }
 
-EXA_HD void branch_flows(const BranchData& d, const double (&x)[6], double (&phi)[4])
+template <class D>
+EXA_HD void branch_flows(const D& d, const double (&x)[6], double (&phi)[4])
 {
     FlowTrig t;
     flow_trig(d, x, t);
     flows_from_trig(d, t, phi);
 }
 
-EXA_HD double objective_from_flows(const BranchData& d, const double (&x)[6], const FlowTrig& t, const double (&phi)[4])
+template <class D>
+EXA_HD double objective_from_flows(const D& d, const double (&x)[6], const FlowTrig& t, const double (&phi)[4])
 {
     const double y[8] = {phi[0], phi[1], phi[2], phi[3], t.vi2, t.vj2, x[2], x[3]};
     double f = 0.0;
     EXA_UNROLL
-    for (int k = 0; k < 8; k++) f += d.lam[k] * y[k];
+    for (int k = 0; k < 8; k++) f += d.lam(k) * y[k];
     EXA_UNROLL
     for (int k = 0; k < 8; k++) {
-        double e = y[k] - d.xt[k];
-        f += 0.5 * (d.rho[k] * (e * e));
+        double e = y[k] - d.xt(k);
+        f += 0.5 * (d.rho(k) * (e * e));
     }
     const double c1 = phi[0] * phi[0] + phi[1] * phi[1] + x[4];
     const double c2 = phi[2] * phi[2] + phi[3] * phi[3] + x[5];
@@ -107,7 +132,8 @@ EXA_HD double objective_from_flows(const BranchData& d, const double (&x)[6], co
     return f * d.scale;
 }
 
-EXA_BIG double branch_f(const BranchData& d, const double (&x)[6])
+template <class D>
+EXA_BIG double branch_f(const D& d, const double (&x)[6])
 {
     FlowTrig t;
     double phi[4];
@@ -117,7 +143,8 @@ EXA_BIG double branch_f(const BranchData& d, const double (&x)[6])
 }
 
 // objective, gradient and packed Hessian at x
-EXA_BIG double branch_fgh(const BranchData& d, const double (&x)[6], double (&g)[6], SymMat<6>& A)
+template <class D, class MA>
+EXA_BIG double branch_fgh(const D& d, const double (&x)[6], double (&g)[6], MA& A)
 {
     FlowTrig t;
     double phi[4];
@@ -128,8 +155,8 @@ EXA_BIG double branch_fgh(const BranchData& d, const double (&x)[6], double (&g)
     const double vi = x[0], vj = x[1], vv = t.vv, sc = d.scale, mu = d.mu;
     const double E[4] = {t.E0, -t.F0, t.E2, t.F2};
     const double F[4] = {t.F0, t.E0, t.F2, -t.E2};
-    const double a2[4] = {2 * d.Y[0], -2 * d.Y[1], 0.0, 0.0};  // d2phi/dvi2
-    const double b2[4] = {0.0, 0.0, 2 * d.Y[4], -2 * d.Y[5]};  // d2phi/dvj2
+    const double a2[4] = {2 * d.Y(0), -2 * d.Y(1), 0.0, 0.0};  // d2phi/dvi2
+    const double b2[4] = {0.0, 0.0, 2 * d.Y(4), -2 * d.Y(5)};  // d2phi/dvj2
 
     // Jacobian of the flows in (vi, vj, th)
     double J[4][3];
@@ -148,8 +175,8 @@ EXA_BIG double branch_fgh(const BranchData& d, const double (&x)[6], double (&g)
     EXA_UNROLL
     for (int k = 0; k < 4; k++) {
         const double mk = (k < 2) ? m1 : m2;
-        w[k] = d.lam[k] + d.rho[k] * (phi[k] - d.xt[k]) + 2 * phi[k] * mk;
-        r[k] = d.rho[k] + 2 * mk;
+        w[k] = d.lam(k) + d.rho(k) * (phi[k] - d.xt(k)) + 2 * phi[k] * mk;
+        r[k] = d.rho(k) + 2 * mk;
     }
     double d1[3], d2[3], gr[3];
     EXA_UNROLL
@@ -158,13 +185,13 @@ EXA_BIG double branch_fgh(const BranchData& d, const double (&x)[6], double (&g)
         d2[i] = 2 * (phi[2] * J[2][i] + phi[3] * J[3][i]);
         gr[i] = w[0] * J[0][i] + w[1] * J[1][i] + w[2] * J[2][i] + w[3] * J[3][i];
     }
-    const double wvi = d.lam[4] + d.rho[4] * (t.vi2 - d.xt[4]);
-    const double wvj = d.lam[5] + d.rho[5] * (t.vj2 - d.xt[5]);
+    const double wvi = d.lam(4) + d.rho(4) * (t.vi2 - d.xt(4));
+    const double wvj = d.lam(5) + d.rho(5) * (t.vj2 - d.xt(5));
 
     g[0] = sc * (gr[0] + wvi * (2 * vi));
     g[1] = sc * (gr[1] + wvj * (2 * vj));
-    g[2] = sc * (gr[2] + (d.lam[6] + d.rho[6] * (x[2] - d.xt[6])));
-    g[3] = sc * (-gr[2] + (d.lam[7] + d.rho[7] * (x[3] - d.xt[7])));
+    g[2] = sc * (gr[2] + (d.lam(6) + d.rho(6) * (x[2] - d.xt(6))));
+    g[3] = sc * (-gr[2] + (d.lam(7) + d.rho(7) * (x[3] - d.xt(7))));
     g[4] = sc * m1;
     g[5] = sc * m2;
 
@@ -172,8 +199,8 @@ EXA_BIG double branch_fgh(const BranchData& d, const double (&x)[6], double (&g)
     const double WE = w[0] * E[0] + w[1] * E[1] + w[2] * E[2] + w[3] * E[3];
     const double WF = w[0] * F[0] + w[1] * F[1] + w[2] * F[2] + w[3] * F[3];
     double Hr[3][3];
-    Hr[0][0] = (w[0] * a2[0] + w[1] * a2[1]) + (2 * wvi + 4 * d.rho[4] * t.vi2);
-    Hr[1][1] = (w[2] * b2[2] + w[3] * b2[3]) + (2 * wvj + 4 * d.rho[5] * t.vj2);
+    Hr[0][0] = (w[0] * a2[0] + w[1] * a2[1]) + (2 * wvi + 4 * d.rho(4) * t.vi2);
+    Hr[1][1] = (w[2] * b2[2] + w[3] * b2[3]) + (2 * wvj + 4 * d.rho(5) * t.vj2);
     Hr[1][0] = WE;
     Hr[2][0] = vj * WF;
     Hr[2][1] = vi * WF;
@@ -196,9 +223,9 @@ EXA_BIG double branch_fgh(const BranchData& d, const double (&x)[6], double (&g)
     A.lo(2, 1) = sc * Hr[2][1];
     A.lo(3, 0) = -(sc * Hr[2][0]);
     A.lo(3, 1) = -(sc * Hr[2][1]);
-    A.lo(2, 2) = sc * (Hr[2][2] + d.rho[6]);
+    A.lo(2, 2) = sc * (Hr[2][2] + d.rho(6));
     A.lo(3, 2) = -(sc * Hr[2][2]);
-    A.lo(3, 3) = sc * (Hr[2][2] + d.rho[7]);
+    A.lo(3, 3) = sc * (Hr[2][2] + d.rho(7));
     const double smu = sc * mu;
     A.lo(4, 0) = smu * d1[0];
     A.lo(4, 1) = smu * d1[1];
@@ -227,15 +254,15 @@ struct BranchStats {
 // g, H when the previous tick moved x (or a new subproblem starts), then makes one
 // model step + ratio test.  Lanes of a wavefront therefore stay phase-aligned
 // whatever auglag/TRON iteration each of them is in.
-EXA_HD void branch_solve(BranchData& d, const BranchOptions& o, double (&x)[6], const double (&xl)[6],
-                         const double (&xu)[6], double (&phi)[4], BranchStats& stats)
+template <class D, class MA, class ML>
+EXA_HD void branch_solve(D& d, const BranchOptions& o, const MuPowTable& pw, double (&x)[6], const double (&xl)[6],
+                         const double (&xu)[6], MA& A, ML& L, double (&phi)[4], BranchStats& stats)
 {
     TronState<6> st;
-    SymMat<6> A;
     double g[6];
 
     double mu = d.mu;
-    double eta = 1.0 / mu_pow(o, mu, false);
+    double eta = 1.0 / mu_pow(pw, mu, false);
     int it = 0, minor_total = 0, ticks = 0;
     bool restart = true, need_gh = true, done = false;
     const int hard_cap = o.max_auglag * (o.max_feval + o.max_minor + 2) + 8;
@@ -264,7 +291,7 @@ EXA_HD void branch_solve(BranchData& d, const BranchOptions& o, double (&x)[6], 
             need_gh = false;
         }
         if (fin == TRON_RUN) {
-            tron_compute<6>(st, x, xl, xu, A, g, o.cgtol, 6);
+            tron_compute<6>(st, x, xl, xu, A, L, g, o.cgtol, 6);
             const double ftrial = branch_f(d, x);
             st.nfev++;
             if (st.nfev >= o.max_feval) {
@@ -293,11 +320,11 @@ EXA_HD void branch_solve(BranchData& d, const BranchOptions& o, double (&x)[6], 
                 } else {
                     d.ls1 += mu * cviol1;
                     d.ls2 += mu * cviol2;
-                    eta = eta / mu_pow(o, mu, true);
+                    eta = eta / mu_pow(pw, mu, true);
                 }
             } else {
                 mu = fmin(o.mu_max, mu * 10);
-                eta = 1.0 / mu_pow(o, mu, false);
+                eta = 1.0 / mu_pow(pw, mu, false);
                 d.mu = mu;
             }
             if (it >= o.max_auglag) terminate = true;

@@ -68,6 +68,8 @@ struct exaadmm_handle {
     Dev d;
     BranchOptions bo;
     Ctrl* d_ctrl = nullptr;
+    Dev* d_dev = nullptr;       // device copy of `d` for kernels that take it by pointer
+    bool dev_dirty = true;
     double* d_sums = nullptr;  // 4 doubles
     Ctrl* h_ctrl = nullptr;    // pinned
     double* h_sums = nullptr;  // pinned, 4 doubles
@@ -184,13 +186,20 @@ static void fill_branch_options(exaadmm_handle* h)
     o.fatol = 0.0;
     o.fmin = -1e32;
     o.cgtol = 0.1;
+}
+
+static int upload_mupow_table()
+{
+    MuPowTable t;
     double p = 1.0;
     for (int k = 0; k < 8; k++) {
         p *= 10.0;
-        o.pow10[k] = p;
-        o.pow01[k] = pow(p, 0.1);
-        o.pow09[k] = pow(p, 0.9);
+        t.pow10[k] = p;
+        t.pow01[k] = pow(p, 0.1);
+        t.pow09[k] = pow(p, 0.9);
     }
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_mupow), &t, sizeof(t)));
+    return 0;
 }
 
 template <class T>
@@ -284,6 +293,7 @@ extern "C" int exaadmm_create(const exaadmm_grid* g, const exaadmm_params* p, in
         return EXAADMM_ERR_HIP;
     }
     h->stream = h->own_stream;
+    TRY(upload_mupow_table());
 
     double** svecs[] = {&d.u, &d.v, &d.z, &d.zp, &d.l, &d.lz, &d.rho, &d.rp, &d.rd, &d.ax};
     for (auto pp : svecs) {
@@ -363,6 +373,7 @@ extern "C" int exaadmm_create(const exaadmm_grid* g, const exaadmm_params* p, in
     h->ew_blocks = std::min(2048, std::max(1, (h->N + EW_BLOCK - 1) / EW_BLOCK));
     TRY(dev_alloc(h, &d.partials, (size_t)h->ew_blocks * 4));
     TRY(dev_alloc(h, &h->d_ctrl, 1));
+    TRY(dev_alloc(h, &h->d_dev, 1));
     TRY(dev_alloc(h, &h->d_sums, 4));
     if (hipHostMalloc((void**)&h->h_ctrl, sizeof(Ctrl), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&h->h_sums, 4 * sizeof(double), hipHostMallocDefault) != hipSuccess) {
@@ -594,7 +605,11 @@ static void launch_gen(exaadmm_handle* h, const Ctrl* c)
 }
 static void launch_branch(exaadmm_handle* h, int major_iter, const Ctrl* c)
 {
-    hipLaunchKernelGGL(k_branch, grid_for(h->d.La, BR_BLOCK), dim3(BR_BLOCK), 0, h->stream, h->d, h->bo, h->par.scale, major_iter, c);
+    if (h->dev_dirty) {  // rare: after create / set_active / set_owned_mask
+        (void)hipMemcpyAsync(h->d_dev, &h->d, sizeof(Dev), hipMemcpyHostToDevice, h->stream);
+        h->dev_dirty = false;
+    }
+    hipLaunchKernelGGL(k_branch, grid_for(h->d.La, BR_BLOCK), dim3(BR_BLOCK), 0, h->stream, h->d_dev, h->bo, h->par.scale, major_iter, c);
 }
 static void launch_bus(exaadmm_handle* h, const Ctrl* c)
 {
@@ -981,6 +996,7 @@ extern "C" int exaadmm_set_active(exaadmm_handle* h, int64_t nbranch, int64_t nb
     REQUIRE(h && nbranch >= 0 && nbranch <= h->L && nbus >= 0 && nbus <= h->B, "active counts out of range");
     h->d.La = (int)nbranch;
     h->d.Ba = (int)nbus;
+    h->dev_dirty = true;
     return EXAADMM_OK;
 }
 
@@ -1042,6 +1058,7 @@ extern "C" int exaadmm_set_owned_mask(exaadmm_handle* h, const uint8_t* mask, in
 {
     REQUIRE(h, "null handle");
     HIPCHK(hipSetDevice(h->device));
+    h->dev_dirty = true;
     if (!mask) {
         h->d.owned = nullptr;
         return EXAADMM_OK;

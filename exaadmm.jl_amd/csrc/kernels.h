@@ -42,6 +42,8 @@ struct Dev {
     double* partials;  // [blocks][4]
 };
 
+__constant__ MuPowTable c_mupow;
+
 constexpr int EW_BLOCK = 256;   // elementwise kernels
 constexpr int BR_BLOCK = 64;    // branch kernel: one wavefront per block
 
@@ -64,9 +66,21 @@ __global__ void k_generator(Dev d, double baseMVA, const Ctrl* ctrl)
 
 // ---------------------------------------------------------------- branch
 // auglag_linelimit_two_level_alternative (acopf_auglag_linelimit_kernel_gpu.jl:1-151):
-// one lane per branch, 64 branches per wavefront, all solver state in registers.
-__global__ void __launch_bounds__(BR_BLOCK) k_branch(Dev d, BranchOptions o, double scale, int major_iter, const Ctrl* ctrl)
+// one lane per branch, 64 branches per wavefront.  Per lane, the 32 read-only problem
+// constants (l, rho, v-z, Y), the packed 6x6 Hessian and its Cholesky factor (21 doubles
+// each) are staged in LDS as [entry][lane] planes (74 x 64 doubles = 37 KB per wavefront,
+// every access conflict-free and with a compile-time offset); vectors and scalars of the
+// solver stay in registers.  (The reference keeps 1728 B of shared memory per BRANCH and one
+// 32-thread block per branch.)
+constexpr int BR_LDS_CONST = 32, BR_LDS_MAT = 21;
+constexpr int BR_LDS_DOUBLES = BR_LDS_CONST + 2 * BR_LDS_MAT;
+
+// The Dev block is read through a pointer (not by-value kernel arguments): its ~40 pointers would
+// otherwise sit in SGPRs across the whole solver and spill.
+__global__ void __launch_bounds__(BR_BLOCK) k_branch(const Dev* __restrict__ dp, BranchOptions o, double scale, int major_iter, const Ctrl* ctrl)
 {
+    __shared__ double lds[BR_LDS_DOUBLES * BR_BLOCK];
+    const Dev& d = *dp;
     if (ctrl != nullptr) {
         if (ctrl->done) return;
         major_iter = ctrl->inner + 1;
@@ -75,28 +89,32 @@ __global__ void __launch_bounds__(BR_BLOCK) k_branch(Dev d, BranchOptions o, dou
     if (b >= d.La) return;
     const int Lp = d.Lp;
     const int base = 2 * d.Gp + b;
+    double* my = lds + threadIdx.x;
 
     double ub[8], bnd[8];
-    BranchData bd;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         const int e = base + k * Lp;
         ub[k] = d.u[e];
-        bd.lam[k] = d.l[e];
-        bd.rho[k] = d.rho[e];
-        bd.xt[k] = d.v[e] - d.z[e];
-        bd.Y[k] = d.Y[b + k * Lp];
+        my[k * BR_BLOCK] = d.l[e];
+        my[(8 + k) * BR_BLOCK] = d.rho[e];
+        my[(16 + k) * BR_BLOCK] = d.v[e] - d.z[e];
+        my[(24 + k) * BR_BLOCK] = d.Y[b + k * Lp];
         bnd[k] = d.bnd[b + k * Lp];
     }
+    BranchDataRef<BR_BLOCK> bd;
+    bd.p = my;
     bd.ls1 = d.ls1[b];
     bd.ls2 = d.ls2[b];
     bd.mu = (major_iter == 1) ? 10.0 : d.mu[b];
     bd.scale = scale;
+    SymRef<6, BR_BLOCK> A{my + BR_LDS_CONST * BR_BLOCK};
+    SymRef<6, BR_BLOCK> L{my + (BR_LDS_CONST + BR_LDS_MAT) * BR_BLOCK};
 
     double x[6], xl[6], xu[6], phi[4];
     branch_start(ub, bnd, d.rateA[b], x, xl, xu);
     BranchStats st;
-    branch_solve(bd, o, x, xl, xu, phi, st);
+    branch_solve(bd, o, c_mupow, x, xl, xu, A, L, phi, st);
 
     d.u[base] = phi[0];
     d.u[base + Lp] = phi[1];

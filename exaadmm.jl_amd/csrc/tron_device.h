@@ -46,12 +46,23 @@ namespace exa {
 // task / termination codes (numbering of acopf_tron_linelimit_kernel.jl)
 enum { TRON_RUN = 0, TRON_CONV = 4, TRON_WARN = 10, TRON_MAXMINOR = 20, TRON_MAXFEVAL = 21 };
 
+// Packed lower triangle of a symmetric N x N matrix, (i,j) with i >= j at i(i+1)/2 + j.
+// SymMat owns its storage (registers / local memory); SymRef<N,STRIDE> views storage with an
+// element stride -- the GPU kernel points it into LDS laid out [entry][lane] (STRIDE = 64),
+// so lane-local matrices cost no VGPRs and every LDS access of a wave is conflict-free.
 template <int N>
-struct SymMat {  // packed lower triangle, (i,j) with i >= j at i(i+1)/2 + j
+struct SymMat {
     double a[N * (N + 1) / 2];
     EXA_HD double get(int i, int j) const { return i >= j ? a[i * (i + 1) / 2 + j] : a[j * (j + 1) / 2 + i]; }
     EXA_HD double& lo(int i, int j) { return a[i * (i + 1) / 2 + j]; }  // requires i >= j
     EXA_HD double lo(int i, int j) const { return a[i * (i + 1) / 2 + j]; }
+};
+
+template <int N, int STRIDE>
+struct SymRef {
+    double* a;
+    EXA_HD double get(int i, int j) const { return i >= j ? a[(i * (i + 1) / 2 + j) * STRIDE] : a[(j * (j + 1) / 2 + i) * STRIDE]; }
+    EXA_HD double& lo(int i, int j) const { return a[(i * (i + 1) / 2 + j) * STRIDE]; }
 };
 
 template <int N>
@@ -70,8 +81,8 @@ EXA_HD double nrm2(const double (&a)[N])
 }
 
 // w = A x (A symmetric, packed)
-template <int N>
-EXA_HD void symv(const SymMat<N>& A, const double (&x)[N], double (&w)[N])
+template <int N, class MA>
+EXA_HD void symv(const MA& A, const double (&x)[N], double (&w)[N])
 {
     EXA_UNROLL
     for (int i = 0; i < N; i++) {
@@ -138,8 +149,8 @@ EXA_HD void gpstep(const double (&x)[N], const double (&xl)[N], const double (&x
 }
 
 // q(s) = 1/2 s'As + g's and g's
-template <int N>
-EXA_HD void quad_model(const SymMat<N>& A, const double (&g)[N], const double (&s)[N], double& q, double& gts)
+template <int N, class MA>
+EXA_HD void quad_model(const MA& A, const double (&g)[N], const double (&s)[N], double& q, double& gts)
 {
     double wa[N];
     symv<N>(A, s, wa);
@@ -148,8 +159,8 @@ EXA_HD void quad_model(const SymMat<N>& A, const double (&g)[N], const double (&
 }
 
 // Cauchy step (TRON dcauchy).  alpha persists across calls.
-template <int N>
-EXA_BIG void cauchy(const double (&x)[N], const double (&xl)[N], const double (&xu)[N], const SymMat<N>& A,
+template <int N, class MA>
+EXA_BIG void cauchy(const double (&x)[N], const double (&xl)[N], const double (&xu)[N], const MA& A,
                    const double (&g)[N], double delta, double& alpha, double (&s)[N])
 {
     const double mu0 = 0.01, interpf = 0.1, extrapf = 10.0;
@@ -201,8 +212,8 @@ EXA_BIG void cauchy(const double (&x)[N], const double (&xl)[N], const double (&
 }
 
 // r <- L^{-1} r  (entries outside `fr` stay exactly 0 because their L row/column is the identity)
-template <int N>
-EXA_HD void trsol_n(const SymMat<N>& L, double (&r)[N])
+template <int N, class ML>
+EXA_HD void trsol_n(const ML& L, double (&r)[N])
 {
     EXA_UNROLL
     for (int j = 0; j < N; j++) {
@@ -214,8 +225,8 @@ EXA_HD void trsol_n(const SymMat<N>& L, double (&r)[N])
 }
 
 // r <- L^{-T} r
-template <int N>
-EXA_HD void trsol_t(const SymMat<N>& L, double (&r)[N])
+template <int N, class ML>
+EXA_HD void trsol_t(const ML& L, double (&r)[N])
 {
     r[N - 1] = r[N - 1] / L.lo(N - 1, N - 1);
     EXA_UNROLL
@@ -229,8 +240,8 @@ EXA_HD void trsol_t(const SymMat<N>& L, double (&r)[N])
 
 // Scaled / shifted Cholesky of the free block of A (TRON dicfs + dicf, dense).
 // fr: bit i set = variable i free.  Bound rows/cols of L are the identity.
-template <int N>
-EXA_BIG void icfs_masked(unsigned fr, const SymMat<N>& A, SymMat<N>& L)
+template <int N, class MA, class ML>
+EXA_BIG void icfs_masked(unsigned fr, const MA& A, ML& L)
 {
     const int nbmax = 3;
     const double alpham = 1.0e-3, nbfactor = 512.0;
@@ -332,8 +343,8 @@ EXA_HD void mask_vec(unsigned fr, double (&v)[N])
 
 // Preconditioned CG on the free block inside || L' w || <= delta  (TRON dtrpcg).
 // gf, w are zero on bound entries.  Returns info (1,2 converged; 3 neg. curvature; 4 boundary; 5 itermax).
-template <int N>
-EXA_BIG int trpcg_masked(unsigned fr, const SymMat<N>& A, const double (&gf)[N], double delta, const SymMat<N>& L,
+template <int N, class MA, class ML>
+EXA_BIG int trpcg_masked(unsigned fr, const MA& A, const double (&gf)[N], double delta, const ML& L,
                         double tol, double stol, int itermax, double (&w)[N], int& iters_out)
 {
     double p[N], q[N], r[N], t[N], z[N];
@@ -400,9 +411,9 @@ EXA_BIG int trpcg_masked(unsigned fr, const SymMat<N>& A, const double (&gf)[N],
 }
 
 // Projected search along w from x on the free block (TRON dprsrch); w <- actual step.
-template <int N>
+template <int N, class MA>
 EXA_BIG void prsrch_masked(unsigned fr, double (&x)[N], const double (&xl)[N], const double (&xu)[N],
-                          const SymMat<N>& A, const double (&gf)[N], double (&w)[N])
+                          const MA& A, const double (&gf)[N], double (&w)[N])
 {
     const double mu0 = 0.01, interpf = 0.5;
     double wa1[N], wa2[N];
@@ -435,12 +446,11 @@ EXA_BIG void prsrch_masked(unsigned fr, double (&x)[N], const double (&xl)[N], c
 
 // Subspace-projected CG from the Cauchy point (TRON dspcg).  On entry s = Cauchy step;
 // on exit x is the trial point and s = x - x0.
-template <int N>
-EXA_BIG void spcg(double (&x)[N], const double (&xl)[N], const double (&xu)[N], const SymMat<N>& A,
+template <int N, class MA, class ML>
+EXA_BIG void spcg(double (&x)[N], const double (&xl)[N], const double (&xu)[N], const MA& A, ML& L,
                  const double (&g)[N], double delta, double rtol, double (&s)[N], int itermax)
 {
     double w[N], gf[N];
-    SymMat<N> L;
     symv<N>(A, s, w);
     EXA_UNROLL
     for (int i = 0; i < N; i++) {
@@ -502,15 +512,15 @@ struct TronState {
 };
 
 // dtron, work = COMPUTE: model step from x (f, g, A valid at x).  x becomes the trial point.
-template <int N>
+template <int N, class MA, class ML>
 EXA_HD void tron_compute(TronState<N>& st, double (&x)[N], const double (&xl)[N], const double (&xu)[N],
-                         const SymMat<N>& A, const double (&g)[N], double cgtol, int cg_itermax)
+                         const MA& A, ML& L, const double (&g)[N], double cgtol, int cg_itermax)
 {
     st.fc = st.f;
     EXA_UNROLL
     for (int i = 0; i < N; i++) st.xc[i] = x[i];
     cauchy<N>(x, xl, xu, A, g, st.delta, st.alphac, st.s);
-    spcg<N>(x, xl, xu, A, g, st.delta, cgtol, st.s, cg_itermax);
+    spcg<N>(x, xl, xu, A, L, g, st.delta, cgtol, st.s, cg_itermax);
     double wa[N];
     symv<N>(A, st.s, wa);
     st.prered = -(dot<N>(st.s, g) + 0.5 * dot<N>(st.s, wa));

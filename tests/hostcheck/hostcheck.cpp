@@ -12,10 +12,10 @@ using namespace exa;
 static void fill(BranchData& d, const double* param, const double* Y, double scale)
 {
     for (int k = 0; k < 8; k++) {
-        d.lam[k] = param[k];
-        d.rho[k] = param[8 + k];
-        d.xt[k] = param[16 + k];
-        d.Y[k] = Y[k];
+        d.lam_[k] = param[k];
+        d.rho_[k] = param[8 + k];
+        d.xt_[k] = param[16 + k];
+        d.Y_[k] = Y[k];
     }
     d.ls1 = param[24];
     d.ls2 = param[25];
@@ -65,12 +65,13 @@ extern "C" int hostcheck_branch_solve(double* x_, const double* xl_, const doubl
     o.fatol = 0.0;
     o.fmin = -1e32;
     o.cgtol = 0.1;
+    MuPowTable pw;
     double p = 1.0;
     for (int k = 0; k < 8; k++) {
         p *= 10.0;
-        o.pow10[k] = p;
-        o.pow01[k] = pow(p, 0.1);
-        o.pow09[k] = pow(p, 0.9);
+        pw.pow10[k] = p;
+        pw.pow01[k] = pow(p, 0.1);
+        pw.pow09[k] = pow(p, 0.9);
     }
     double x[6], xl[6], xu[6], phi[4];
     for (int i = 0; i < 6; i++) {
@@ -79,7 +80,8 @@ extern "C" int hostcheck_branch_solve(double* x_, const double* xl_, const doubl
         xu[i] = xu_[i];
     }
     BranchStats st;
-    branch_solve(d, o, x, xl, xu, phi, st);
+    SymMat<6> A, Lm;
+    branch_solve(d, o, pw, x, xl, xu, A, Lm, phi, st);
     for (int i = 0; i < 6; i++) x_[i] = x[i];
     param[24] = d.ls1;
     param[25] = d.ls2;

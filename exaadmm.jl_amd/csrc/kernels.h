@@ -108,8 +108,16 @@ __global__ void __launch_bounds__(BR_BLOCK) k_branch(const Dev* __restrict__ dp,
     bd.ls2 = d.ls2[b];
     bd.mu = (major_iter == 1) ? 10.0 : d.mu[b];
     bd.scale = scale;
+#if defined(EXA_A_IN_REGS)
+    SymMat<6> A;
+#else
     SymRef<6, BR_BLOCK> A{my + BR_LDS_CONST * BR_BLOCK};
+#endif
+#if defined(EXA_L_IN_REGS)
+    SymMat<6> L;
+#else
     SymRef<6, BR_BLOCK> L{my + (BR_LDS_CONST + BR_LDS_MAT) * BR_BLOCK};
+#endif
 
     double x[6], xl[6], xu[6], phi[4];
     branch_start(ub, bnd, d.rateA[b], x, xl, xu);

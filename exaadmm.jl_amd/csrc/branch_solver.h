@@ -133,10 +133,9 @@ EXA_HD double objective_from_flows(const D& d, const double (&x)[6], const FlowT
 }
 
 template <class D>
-EXA_BIG double branch_f(const D& d, const double (&x)[6])
+EXA_BIG double branch_f(const D& d, const double (&x)[6], double (&phi)[4])
 {
     FlowTrig t;
-    double phi[4];
     flow_trig(d, x, t);
     flows_from_trig(d, t, phi);
     return objective_from_flows(d, x, t, phi);
@@ -144,10 +143,9 @@ EXA_BIG double branch_f(const D& d, const double (&x)[6])
 
 // objective, gradient and packed Hessian at x
 template <class D, class MA>
-EXA_BIG double branch_fgh(const D& d, const double (&x)[6], double (&g)[6], MA& A)
+EXA_BIG double branch_fgh(const D& d, const double (&x)[6], double (&g)[6], MA& A, double (&phi)[4])
 {
     FlowTrig t;
-    double phi[4];
     flow_trig(d, x, t);
     flows_from_trig(d, t, phi);
     const double f = objective_from_flows(d, x, t, phi);
@@ -241,7 +239,14 @@ EXA_BIG double branch_fgh(const D& d, const double (&x)[6], double (&g)[6], MA& 
     return f;
 }
 
+#if defined(EXA_PROFILE_PHASES) && defined(__HIP_DEVICE_COMPILE__)
+#define EXA_TICK() __builtin_amdgcn_s_memtime()
+#else
+#define EXA_TICK() 0ull
+#endif
+
 struct BranchStats {
+    unsigned long long cyc[5];  // diagnostic build only: fgh, model step, f(trial), ratio test, auglag step
     int auglag_it;
     int minor_it;  // TRON minor iterations summed over the augmented-Lagrangian iterations
     int ticks;     // trips of the lane's solver loop
@@ -260,6 +265,7 @@ EXA_HD void branch_solve(D& d, const BranchOptions& o, const MuPowTable& pw, dou
 {
     TronState<6> st;
     double g[6];
+    double phit[4];  // flows at the trial point; phi always holds the flows at the accepted x
 
     double mu = d.mu;
     double eta = 1.0 / mu_pow(pw, mu, false);
@@ -267,14 +273,17 @@ EXA_HD void branch_solve(D& d, const BranchOptions& o, const MuPowTable& pw, dou
     bool restart = true, need_gh = true, done = false;
     const int hard_cap = o.max_auglag * (o.max_feval + o.max_minor + 2) + 8;
 
+    EXA_UNROLL
+    for (int k = 0; k < 5; k++) stats.cyc[k] = 0;
     while (!done && ticks < hard_cap) {
         ticks++;
         int fin = TRON_RUN;
+        unsigned long long t0 = EXA_TICK();
         if (need_gh) {
             if (restart) {
                 // task START: f, g, H at x; delta0 = ||g||  (tron_linelimit_kernel.jl:66-106)
                 it++;
-                st.f = branch_fgh(d, x, g, A);
+                st.f = branch_fgh(d, x, g, A, phi);
                 st.delta = nrm2<6>(g);
                 st.iter = 1;
                 st.alphac = 1.0;
@@ -283,33 +292,48 @@ EXA_HD void branch_solve(D& d, const BranchOptions& o, const MuPowTable& pw, dou
                 restart = false;
             } else {
                 // task GH then NEWX  (tron_linelimit_kernel.jl:86-135)
-                (void)branch_fgh(d, x, g, A);
+                (void)branch_fgh(d, x, g, A, phi);
                 st.minor_iter++;
                 if (gpnorm<6>(x, xl, xu, g) <= o.gtol) fin = TRON_CONV;
                 if (st.minor_iter >= o.max_minor) fin = TRON_MAXMINOR;
             }
             need_gh = false;
         }
+        unsigned long long t1 = EXA_TICK();
+        stats.cyc[0] += t1 - t0;
         if (fin == TRON_RUN) {
             tron_compute<6>(st, x, xl, xu, A, L, g, o.cgtol, 6);
-            const double ftrial = branch_f(d, x);
+            unsigned long long t2 = EXA_TICK();
+            stats.cyc[1] += t2 - t1;
+            const double ftrial = branch_f(d, x, phit);
+            unsigned long long t3 = EXA_TICK();
+            stats.cyc[2] += t3 - t2;
+            t1 = t3;
             st.nfev++;
             if (st.nfev >= o.max_feval) {
                 fin = TRON_MAXFEVAL;  // search stops before the ratio test (tron_linelimit_kernel.jl:76-78)
+                EXA_UNROLL
+                for (int k = 0; k < 4; k++) phi[k] = phit[k];
             } else {
                 int task;
                 const bool success = tron_evaluate<6>(st, ftrial, x, g, o.frtol, o.fatol, o.fmin, task);
+                if (success) {
+                    EXA_UNROLL
+                    for (int k = 0; k < 4; k++) phi[k] = phit[k];
+                }
                 if (task != TRON_RUN)
                     fin = task;
                 else
                     need_gh = success;
             }
         }
+        unsigned long long t4 = EXA_TICK();
+        stats.cyc[3] += t4 - t1;
         if (fin != TRON_RUN) {
             // end of one TRON solve: augmented-Lagrangian update
             // (acopf_auglag_linelimit_kernel_gpu.jl:99-131)
             minor_total += st.minor_iter;
-            branch_flows(d, x, phi);
+            // phi = flows at x: the same inline code evaluated them when x was accepted
             const double cviol1 = phi[0] * phi[0] + phi[1] * phi[1] + x[4];
             const double cviol2 = phi[2] * phi[2] + phi[3] * phi[3] + x[5];
             const double cnorm = fmax(fabs(cviol1), fabs(cviol2));
@@ -335,6 +359,7 @@ EXA_HD void branch_solve(D& d, const BranchOptions& o, const MuPowTable& pw, dou
                 need_gh = true;
             }
         }
+        stats.cyc[4] += EXA_TICK() - t4;
     }
     d.mu = mu;
     stats.auglag_it = it;

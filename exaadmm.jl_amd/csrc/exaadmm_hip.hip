@@ -83,6 +83,7 @@ struct exaadmm_handle {
     HaloSlot halo[8];
     bool residual_vectors_valid = false;
     bool async_mode = false;
+    bool bus_lane_kernel = false;
     bool ctrl_mode = false;
     exaadmm_info info;
     std::vector<hipEvent_t> ev;
@@ -293,6 +294,10 @@ extern "C" int exaadmm_create(const exaadmm_grid* g, const exaadmm_params* p, in
         return EXAADMM_ERR_HIP;
     }
     h->stream = h->own_stream;
+    {
+        const char* e = getenv("EXAADMM_BUS_KERNEL");
+        h->bus_lane_kernel = (e != nullptr && strcmp(e, "lane") == 0);
+    }
     TRY(upload_mupow_table());
 
     double** svecs[] = {&d.u, &d.v, &d.z, &d.zp, &d.l, &d.lz, &d.rho, &d.rp, &d.rd, &d.ax};
@@ -334,6 +339,7 @@ extern "C" int exaadmm_create(const exaadmm_grid* g, const exaadmm_params* p, in
         TRY(dev_alloc(h, &d.st_auglag, (size_t)h->Lp));
         TRY(dev_alloc(h, &d.st_minor, (size_t)h->Lp));
         TRY(dev_alloc(h, &d.st_ticks, (size_t)h->Lp));
+        TRY(dev_alloc(h, &d.st_cyc, (size_t)5 * h->Lp));
         (void)hipMemset(d.st_auglag, 0, h->Lp * sizeof(int));
         (void)hipMemset(d.st_minor, 0, h->Lp * sizeof(int));
         (void)hipMemset(d.st_ticks, 0, h->Lp * sizeof(int));
@@ -368,6 +374,28 @@ extern "C" int exaadmm_create(const exaadmm_grid* g, const exaadmm_params* p, in
         TRY(build_csr(h, g->FrStart, g->FrIdx, base, h->B, h->L, &d.FrStart, &d.FrIdx, h->L));
         TRY(build_csr(h, g->ToStart, g->ToIdx, base, h->B, h->L, &d.ToStart, &d.ToIdx, h->L));
         TRY(build_csr(h, g->GenStart, g->GenIdx, base, h->B, h->G, &d.GenStart, &d.GenIdx, std::max(h->G, 1)));
+        // combined per-bus component list for the lane-group bus kernel: generators, from-ends, to-ends
+        {
+            std::vector<int> es(h->B + 1, 0), ec;
+            ec.reserve((size_t)2 * h->L + h->G);
+            for (int I = 0; I < h->B; I++) {
+                es[I] = (int)ec.size();
+                for (int64_t k = g->GenStart[I] - base; k < g->GenStart[I + 1] - base; k++)
+                    ec.push_back((END_GEN << 28) | (int)(g->GenIdx[k] - base));
+                for (int64_t k = g->FrStart[I] - base; k < g->FrStart[I + 1] - base; k++)
+                    ec.push_back((END_FROM << 28) | (int)(g->FrIdx[k] - base));
+                for (int64_t k = g->ToStart[I] - base; k < g->ToStart[I + 1] - base; k++)
+                    ec.push_back((END_TO << 28) | (int)(g->ToIdx[k] - base));
+            }
+            es[h->B] = (int)ec.size();
+            int *des, *dec;
+            TRY(dev_alloc(h, &des, es.size()));
+            TRY(dev_alloc(h, &dec, ec.size()));
+            TRY(upload_vec(h, des, es));
+            TRY(upload_vec(h, dec, ec));
+            d.EndStart = des;
+            d.EndCode = dec;
+        }
     }
     // reduction scratch + loop control
     h->ew_blocks = std::min(2048, std::max(1, (h->N + EW_BLOCK - 1) / EW_BLOCK));
@@ -603,17 +631,22 @@ static void launch_gen(exaadmm_handle* h, const Ctrl* c)
 {
     if (h->G > 0) hipLaunchKernelGGL(k_generator, grid_for(h->G, 64), dim3(64), 0, h->stream, h->d, h->baseMVA, c);
 }
-static void launch_branch(exaadmm_handle* h, int major_iter, const Ctrl* c)
+static void launch_branch(exaadmm_handle* h, int major_iter, const Ctrl* c, bool with_generators = false)
 {
     if (h->dev_dirty) {  // rare: after create / set_active / set_owned_mask
         (void)hipMemcpyAsync(h->d_dev, &h->d, sizeof(Dev), hipMemcpyHostToDevice, h->stream);
         h->dev_dirty = false;
     }
-    hipLaunchKernelGGL(k_branch, grid_for(h->d.La, BR_BLOCK), dim3(BR_BLOCK), 0, h->stream, h->d_dev, h->bo, h->par.scale, major_iter, c);
+    const int nb = (int)grid_for(h->d.La, BR_BLOCK).x;
+    const int ng = (with_generators && h->G > 0) ? (int)grid_for(h->G, BR_BLOCK).x : 0;
+    hipLaunchKernelGGL(k_branch, dim3(nb + ng), dim3(BR_BLOCK), 0, h->stream, h->d_dev, h->bo, h->par.scale, major_iter, c, ng, h->baseMVA);
 }
 static void launch_bus(exaadmm_handle* h, const Ctrl* c)
 {
-    hipLaunchKernelGGL(k_bus, grid_for(h->d.Ba, 64), dim3(64), 0, h->stream, h->d, h->baseMVA, c);
+    if (h->bus_lane_kernel)  // A/B switch (EXAADMM_BUS_KERNEL=lane): one lane per bus
+        hipLaunchKernelGGL(k_bus, grid_for(h->d.Ba, 64), dim3(64), 0, h->stream, h->d, h->baseMVA, c);
+    else
+        hipLaunchKernelGGL(k_bus_group, grid_for(h->d.Ba, BUS_BLOCK / BUS_W), dim3(BUS_BLOCK), 0, h->stream, h->d, h->baseMVA, c);
 }
 static void launch_fused_zl(exaadmm_handle* h, double beta, const Ctrl* c)
 {
@@ -801,11 +834,20 @@ extern "C" int exaadmm_download_branch_counters(exaadmm_handle* h, int32_t* a, i
     return EXAADMM_OK;
 }
 
+// diagnostic builds only (-DEXA_PROFILE_PHASES): per-branch cycle counters of the solver phases
+extern "C" int exaadmm_debug_phase_cycles(exaadmm_handle* h, unsigned long long* out, int64_t n)
+{
+    REQUIRE(h && out && n == 5 * (int64_t)h->Lp, "buffer must hold 5 x Lp counters");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(out, h->d.st_cyc, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return EXAADMM_OK;
+}
+
 // ------------------------------------------------------------------ fused loops
 static void enqueue_iteration(exaadmm_handle* h, Ctrl* c)
 {
-    launch_gen(h, c);
-    launch_branch(h, 0, c);
+    launch_branch(h, 0, c, true);   // generators ride in the same launch
     launch_bus(h, c);
     launch_fused_zl(h, 0.0, c);
     launch_final(h, c);
@@ -909,9 +951,8 @@ extern "C" int exaadmm_run_fixed(exaadmm_handle* h, int iters, int first_major_i
     h->residual_vectors_valid = false;
     HIPCHK(hipEventRecord(h->ev[0], h->stream));
     for (int i = 0; i < iters; i++) {
-        launch_gen(h, nullptr);
         if (time_branch) HIPCHK(hipEventRecord(h->ev[2 + 2 * i], h->stream));
-        launch_branch(h, first_major_iter + i, nullptr);
+        launch_branch(h, first_major_iter + i, nullptr, true);
         if (time_branch) HIPCHK(hipEventRecord(h->ev[3 + 2 * i], h->stream));
         launch_bus(h, nullptr);
         launch_fused_zl(h, beta, nullptr);

@@ -37,8 +37,10 @@ struct Dev {
     const double *pgmin, *pgmax, *qgmin, *qgmax, *c2, *c1;
     const double *Pd, *Qd, *YshR, *YshI;
     const int *FrStart, *FrIdx, *ToStart, *ToIdx, *GenStart, *GenIdx;
+    const int *EndStart, *EndCode;  // per bus: generators, from-branches, to-branches (kind << 28 | index)
     const unsigned char* owned;  // SoA order; nullptr = all owned
     int *st_auglag, *st_minor, *st_ticks;
+    unsigned long long* st_cyc;  // diagnostic build (EXA_PROFILE_PHASES): 5 x Lp phase cycle counters
     double* partials;  // [blocks][4]
 };
 
@@ -51,10 +53,8 @@ __device__ __forceinline__ bool loop_done(const Ctrl* c) { return c != nullptr &
 
 // ---------------------------------------------------------------- generator
 // generator_kernel_two_level (acopf_generator_kernel_gpu.jl:1-22), one lane per generator
-__global__ void k_generator(Dev d, double baseMVA, const Ctrl* ctrl)
+__device__ __forceinline__ void generator_update(const Dev& d, double baseMVA, int i)
 {
-    if (loop_done(ctrl)) return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= d.G) return;
     const int pg = i, qg = d.Gp + i;
     const double M = baseMVA;
@@ -62,6 +62,12 @@ __global__ void k_generator(Dev d, double baseMVA, const Ctrl* ctrl)
     d.u[pg] = fmax(d.pgmin[i], fmin(d.pgmax[i], t));
     t = (-(d.l[qg] + d.rho[qg] * (-d.v[qg] + d.z[qg]))) / d.rho[qg];
     d.u[qg] = fmax(d.qgmin[i], fmin(d.qgmax[i], t));
+}
+
+__global__ void k_generator(Dev d, double baseMVA, const Ctrl* ctrl)
+{
+    if (loop_done(ctrl)) return;
+    generator_update(d, baseMVA, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // ---------------------------------------------------------------- branch
@@ -77,13 +83,21 @@ constexpr int BR_LDS_DOUBLES = BR_LDS_CONST + 2 * BR_LDS_MAT;
 
 // The Dev block is read through a pointer (not by-value kernel arguments): its ~40 pointers would
 // otherwise sit in SGPRs across the whole solver and spill.
-__global__ void __launch_bounds__(BR_BLOCK) k_branch(const Dev* __restrict__ dp, BranchOptions o, double scale, int major_iter, const Ctrl* ctrl)
+__global__ void __launch_bounds__(BR_BLOCK) k_branch(const Dev* __restrict__ dp, BranchOptions o, double scale, int major_iter, const Ctrl* ctrl,
+                                                     int gen_blocks, double baseMVA)
 {
     __shared__ double lds[BR_LDS_DOUBLES * BR_BLOCK];
     const Dev& d = *dp;
     if (ctrl != nullptr) {
         if (ctrl->done) return;
         major_iter = ctrl->inner + 1;
+    }
+    // blocks past the branch range do the generator update (independent of the branches; one
+    // launch and one inter-kernel gap less per iteration).  gen_blocks = 0: branches only.
+    const int nbr_blocks = gridDim.x - gen_blocks;
+    if ((int)blockIdx.x >= nbr_blocks) {
+        generator_update(d, baseMVA, ((int)blockIdx.x - nbr_blocks) * BR_BLOCK + threadIdx.x);
+        return;
     }
     const int b = blockIdx.x * BR_BLOCK + threadIdx.x;
     if (b >= d.La) return;
@@ -138,6 +152,9 @@ __global__ void __launch_bounds__(BR_BLOCK) k_branch(const Dev* __restrict__ dp,
     d.st_auglag[b] = st.auglag_it;
     d.st_minor[b] = st.minor_it;
     d.st_ticks[b] = st.ticks;
+#if defined(EXA_PROFILE_PHASES)
+    for (int q = 0; q < 5; q++) d.st_cyc[q * d.Lp + b] = st.cyc[q];
+#endif
 }
 
 // ---------------------------------------------------------------- bus
@@ -232,6 +249,168 @@ __global__ void k_bus(Dev d, double baseMVA, const Ctrl* ctrl)
         v[eq] = (u[eq] + z[eq]) + (l[eq] + mu2) / rho[eq];
         v[e0 + 5 * Lp] = wi;
         v[e0 + 7 * Lp] = ti;
+    }
+}
+
+// ---------------------------------------------------------------- bus, lane-group version
+// Same arithmetic, in the same order, as k_bus / bus_kernel_two_level_alternative
+// (acopf_bus_kernel_gpu.jl:1-119), organised for latency: BUS_W lanes serve one bus.
+//   * every lane fetches ONE incident component (generator / from-end / to-end) of the bus --
+//     the gathers of a bus are issued in parallel instead of one dependent loop per lane;
+//   * the records are parked in LDS ([entry][lane] inside the group) and the group leader
+//     accumulates them in the reference's order (generators, -Pd, from-ends, to-ends), so the
+//     floating-point result is identical to the one-lane-per-bus kernel;
+//   * the leader publishes mu1, mu2, w, theta through LDS and every lane writes the v entries
+//     of its own component from the registers it already holds.
+// Buses with more than BUS_W incident components are processed in chunks.
+constexpr int BUS_W = 8;
+constexpr int BUS_BLOCK = 256;
+constexpr int BUS_REC = 16;  // doubles per record: (u,z,l,rho) x (p,q,w,theta) or (u,z,l,rho) x (pg,qg)
+enum { END_GEN = 0, END_FROM = 1, END_TO = 2 };
+
+__device__ __forceinline__ void bus_load_end(const Dev& d, int code, double (&r)[BUS_REC], int (&idx)[4])
+{
+    const int kind = code >> 28, c = code & 0x0fffffff;
+    const int Lp = d.Lp;
+    if (kind == END_GEN) {
+        idx[0] = c;
+        idx[1] = d.Gp + c;
+        idx[2] = idx[3] = -1;
+    } else {
+        const int e = 2 * d.Gp + c;
+        const int off = (kind == END_FROM) ? 0 : 2;
+        idx[0] = e + off * Lp;                          // p
+        idx[1] = e + (off + 1) * Lp;                    // q
+        idx[2] = e + ((kind == END_FROM) ? 4 : 5) * Lp; // w
+        idx[3] = e + ((kind == END_FROM) ? 6 : 7) * Lp; // theta
+    }
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const int i = idx[m];
+        if (i >= 0) {
+            r[4 * m] = d.u[i];
+            r[4 * m + 1] = d.z[i];
+            r[4 * m + 2] = d.l[i];
+            r[4 * m + 3] = d.rho[i];
+        } else {
+            r[4 * m] = r[4 * m + 1] = r[4 * m + 2] = 0.0;
+            r[4 * m + 3] = 1.0;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(BUS_BLOCK) k_bus_group(Dev d, double baseMVA, const Ctrl* ctrl)
+{
+    // per component the lane computes the TERMS the reference adds up (each term is evaluated
+    // exactly as written there: l + rho*(u+z), 1/rho, (u+z) + l/rho); the leader only adds them
+    // in the reference's order, so its dependent chain contains no division.
+    constexpr int T_W = 0, T_T = 1, T_IP = 2, T_IQ = 3, T_RW = 4, T_RT = 5, T_P = 6, T_Q = 7, NTERM = 8;
+    __shared__ double term[BUS_BLOCK / BUS_W][NTERM][BUS_W];
+    __shared__ int kinds[BUS_BLOCK / BUS_W][BUS_W];
+    __shared__ double res[BUS_BLOCK / BUS_W][4];
+    if (loop_done(ctrl)) return;
+    const int grp = threadIdx.x / BUS_W, lane = threadIdx.x % BUS_W;
+    const int I = blockIdx.x * (BUS_BLOCK / BUS_W) + grp;
+    if (I >= d.Ba) return;   // whole groups leave together
+    const int e0 = d.EndStart[I], n = d.EndStart[I + 1] - e0;
+
+    // leader state (meaningful in lane 0 only)
+    double common_wi = 0.0, common_ti = 0.0, inv_rhosum_p = 0.0, inv_rhosum_q = 0.0;
+    double rhosum_w = 0.0, rhosum_t = 0.0, rhs1 = 0.0, rhs2 = 0.0, inv_rhosum_pg = 0.0, inv_rhosum_qg = 0.0;
+    bool load_subtracted = false;
+    const double pd = d.Pd[I] / baseMVA, qd = d.Qd[I] / baseMVA;
+
+    double r[BUS_REC];
+    int idx[4], kind = -1;
+    for (int c0 = 0; c0 < n; c0 += BUS_W) {
+        const int m = min(BUS_W, n - c0);
+        if (lane < m) {
+            const int code = d.EndCode[e0 + c0 + lane];
+            kind = code >> 28;
+            bus_load_end(d, code, r, idx);
+            kinds[grp][lane] = kind;
+            term[grp][T_P][lane] = (r[0] + r[1]) + (r[2] / r[3]);
+            term[grp][T_Q][lane] = (r[4] + r[5]) + (r[6] / r[7]);
+            term[grp][T_IP][lane] = 1.0 / r[3];
+            term[grp][T_IQ][lane] = 1.0 / r[7];
+            term[grp][T_W][lane] = r[10] + r[11] * (r[8] + r[9]);
+            term[grp][T_T][lane] = r[14] + r[15] * (r[12] + r[13]);
+            term[grp][T_RW][lane] = r[11];
+            term[grp][T_RT][lane] = r[15];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane == 0) {
+            for (int k = 0; k < m; k++) {
+                if (kinds[grp][k] == END_GEN) {
+                    rhs1 += term[grp][T_P][k];
+                    rhs2 += term[grp][T_Q][k];
+                    inv_rhosum_pg += term[grp][T_IP][k];
+                    inv_rhosum_qg += term[grp][T_IQ][k];
+                } else {
+                    if (!load_subtracted) {
+                        rhs1 -= pd;
+                        rhs2 -= qd;
+                        load_subtracted = true;
+                    }
+                    common_wi += term[grp][T_W][k];
+                    common_ti += term[grp][T_T][k];
+                    inv_rhosum_p += term[grp][T_IP][k];
+                    inv_rhosum_q += term[grp][T_IQ][k];
+                    rhosum_w += term[grp][T_RW][k];
+                    rhosum_t += term[grp][T_RT][k];
+                    rhs1 -= term[grp][T_P][k];
+                    rhs2 -= term[grp][T_Q][k];
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) {
+        if (!load_subtracted) {
+            rhs1 -= pd;
+            rhs2 -= qd;
+        }
+        common_wi /= rhosum_w;
+        const double ysr = d.YshR[I], ysi = d.YshI[I];
+        rhs1 -= ysr * common_wi;
+        rhs2 += ysi * common_wi;
+        const double A11 = (inv_rhosum_pg + inv_rhosum_p) + (ysr * ysr / rhosum_w);
+        const double A12 = -ysr * (ysi / rhosum_w);
+        const double A21 = A12;
+        const double A22 = (inv_rhosum_qg + inv_rhosum_q) + (ysi * ysi / rhosum_w);
+        const double mu2 = (rhs2 - (A21 / A11) * rhs1) / (A22 - (A21 / A11) * A12);
+        const double mu1 = (rhs1 - A12 * mu2) / A11;
+        res[grp][0] = mu1;
+        res[grp][1] = mu2;
+        res[grp][2] = common_wi + ((ysr * mu1 - ysi * mu2) / rhosum_w);
+        res[grp][3] = common_ti / rhosum_t;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const double mu1 = res[grp][0], mu2 = res[grp][1], wi = res[grp][2], ti = res[grp][3];
+
+    for (int c0 = 0; c0 < n; c0 += BUS_W) {
+        const int m = min(BUS_W, n - c0);
+        if (lane < m) {
+            if (n > BUS_W) {  // registers only hold the last chunk: fetch this one again
+                const int code = d.EndCode[e0 + c0 + lane];
+                kind = code >> 28;
+                bus_load_end(d, code, r, idx);
+            }
+            if (kind == END_GEN) {
+                d.v[idx[0]] = (r[0] + r[1]) + (r[2] - mu1) / r[3];
+                d.v[idx[1]] = (r[4] + r[5]) + (r[6] - mu2) / r[7];
+            } else {
+                d.v[idx[0]] = (r[0] + r[1]) + (r[2] + mu1) / r[3];
+                d.v[idx[1]] = (r[4] + r[5]) + (r[6] + mu2) / r[7];
+                d.v[idx[2]] = wi;
+                d.v[idx[3]] = ti;
+            }
+        }
     }
 }
 

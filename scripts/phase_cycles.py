@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Diagnostic (needs a library built with -DEXA_PROFILE_PHASES, EXAADMM_HIP_LIB=...): where do the
+cycles of a branch-solver tick go?  Prints per-phase shader-clock cycles for light and heavy branches."""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import exaadmm_loader
+pkg = exaadmm_loader.load_package()
+syn = exaadmm_loader.load_submodule("synthetic")
+L = pkg.library()
+L.exaadmm_debug_phase_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int64]
+g = syn.sized_like("case13659pegase", seed=0)
+env = pkg.AdmmEnv("syn", 5e1, 5e3, verbose=0, grid=g)
+mod = pkg.ModelAcopf(env)
+mod.run_fixed(30, first_major_iter=1, beta=1e3)
+for rep in range(2):
+    norms, ms, msb = mod.run_fixed(1, first_major_iter=40 + rep, beta=1e3, time_branch=True)
+    a, m, t = mod.branch_counters()
+    Lp = ((g["nline"] + 63) // 64) * 64
+    buf = np.zeros(5 * Lp, dtype=np.uint64)
+    pkg._check(L.exaadmm_debug_phase_cycles(mod.handle, buf.ctypes.data_as(C.POINTER(C.c_uint64)), buf.size), "phase cycles")
+    cyc = buf.reshape(5, Lp)[:, :g["nline"]].astype(np.float64)
+    names = ["fgh+newx", "model step", "f(trial)", "ratio test", "auglag step"]
+    print("k_branch %.3f ms; ticks: median %d max %d; auglag max %d" % (msb, np.median(t), t.max(), a.max()))
+    light = t == np.median(t)
+    heavy = t >= np.quantile(t, 0.999)
+    for nm, sel in (("median-tick branches", light), ("heaviest 0.1%", heavy)):
+        tot = cyc[:, sel].sum(axis=0).mean()
+        print("  %-22s n=%5d ticks %.1f total cyc %.0f (%.1f us @2.4GHz)  per tick %.0f | " % (nm, sel.sum(), t[sel].mean(), tot, tot / 2400.0, tot / t[sel].mean())
+              + ", ".join("%s %.0f" % (names[q], cyc[q, sel].mean()) for q in range(5)))

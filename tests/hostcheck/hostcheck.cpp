@@ -31,7 +31,8 @@ extern "C" double hostcheck_fgh(const double* x_, const double* param, const dou
     double x[6], g[6];
     for (int i = 0; i < 6; i++) x[i] = x_[i];
     SymMat<6> A;
-    double f = branch_fgh(d, x, g, A);
+    double phi[4];
+    double f = branch_fgh(d, x, g, A, phi);
     for (int i = 0; i < 6; i++) {
         g_[i] = g[i];
         for (int j = 0; j < 6; j++) Afull[i + 6 * j] = A.get(i, j);
@@ -45,7 +46,8 @@ extern "C" double hostcheck_f(const double* x_, const double* param, const doubl
     fill(d, param, Y, scale);
     double x[6];
     for (int i = 0; i < 6; i++) x[i] = x_[i];
-    return branch_f(d, x);
+    double phi[4];
+    return branch_f(d, x, phi);
 }
 
 // same contract as oracle_branch_solve

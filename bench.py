@@ -122,6 +122,14 @@ def main():
 
     its = args.steps / dt
     a_it, m_it = mod.branch_stats()
+    # HBM traffic of the dominant kernel from the PMC passes committed under profiles/ (collected
+    # with rocprofv3 on this same command; bench.py itself cannot collect counters)
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+        traffic = pmc.get(workload, {}).get("k_branch", {}).get("traffic_bytes")
+    except Exception:
+        traffic = None
     branch_bytes = BYTES_PER_BRANCH_SOLVE * L
     achieved = branch_bytes / (ms_branch * 1e-3) / 1e9
     out = {
@@ -132,7 +140,7 @@ def main():
                    "rho_va": params["rho_va"], "scale": params["scale"], "tight_factor": 0.99,
                    "mode": "fixed-count inner iterations, no early break", "parallelism": "1 GPU"},
         "roofline": {"bound": "hbm", "kernel": "k_branch", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": branch_bytes, "kernel_ms": ms_branch,
                      "iteration_bytes": BYTES_PER_ITER(G, L, B),
                      "iteration_frac": BYTES_PER_ITER(G, L, B) * its / 1e9 / HBM_PEAK_GBS,

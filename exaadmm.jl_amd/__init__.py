@@ -44,7 +44,8 @@ class Grid(C.Structure):
     _fields_ = ([("ngen", C.c_int64), ("nline", C.c_int64), ("nbus", C.c_int64),
                  ("index_base", C.c_int32), ("baseMVA", C.c_double)] +
                 [(n, c_double_p) for n in _F64] + [("brBusIdx", c_i64_p)] +
-                [(n, c_double_p) for n in _BUS] + [(n, c_i64_p) for n in _IDX])
+                [(n, c_double_p) for n in _BUS] + [(n, c_i64_p) for n in _IDX] +
+                [("nline_active", C.c_int64), ("nbus_active", C.c_int64)])
 
 
 class Parameters(C.Structure):
@@ -163,6 +164,8 @@ def _as_grid_arrays(g):
         out[k] = np.ascontiguousarray(g[k], dtype=np.int64)
     out["ngen"], out["nline"], out["nbus"] = int(g["ngen"]), int(g["nline"]), int(g["nbus"])
     out["baseMVA"] = float(g["baseMVA"])
+    out["nline_active"] = int(g.get("nline_active", 0))
+    out["nbus_active"] = int(g.get("nbus_active", 0))
     return out
 
 
@@ -250,6 +253,7 @@ class ModelAcopf:
         self.gen_start, self.line_start = 1, 2 * self.ngen + 1   # 1-based like the reference
         cg = Grid()
         cg.ngen, cg.nline, cg.nbus, cg.index_base, cg.baseMVA = self.ngen, self.nline, self.nbus, 0, g["baseMVA"]
+        cg.nline_active, cg.nbus_active = g.get("nline_active", 0), g.get("nbus_active", 0)
         for k in Grid._F64 + Grid._BUS:
             setattr(cg, k, _dp(g[k]))
         for k in Grid._IDX + ("brBusIdx",):

@@ -6,6 +6,7 @@
 #include "exaadmm_hip.h"
 #include "kernels.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -79,6 +80,10 @@ struct exaadmm_handle {
     std::vector<double> c2, c1, c0;  // host copies for the objective
     std::vector<double> stage;       // host staging, N doubles
     std::vector<double> rateA_h;
+    // device position of reference branch b.  Branches are stored sorted by the bus they are
+    // gathered from (from-bus for own branches, to-bus for ghosts) so that the bus kernel's
+    // gathers of consecutive buses hit consecutive elements of the planes.
+    std::vector<int> perm;
     unsigned char* d_owned = nullptr;
     HaloSlot halo[8];
     bool residual_vectors_valid = false;
@@ -107,7 +112,7 @@ static inline int soa_index(const exaadmm_handle* h, int64_t r)
 {
     if (r < 2 * (int64_t)h->G) return (int)((r & 1) * h->Gp + (r >> 1));
     const int64_t q = r - 2 * (int64_t)h->G;
-    return (int)(2 * h->Gp + (q & 7) * h->Lp + (q >> 3));
+    return (int)(2 * h->Gp + (q & 7) * h->Lp + h->perm[q >> 3]);
 }
 
 static void ref_to_soa(const exaadmm_handle* h, const double* ref, double* soa, double pad)
@@ -120,7 +125,7 @@ static void ref_to_soa(const exaadmm_handle* h, const double* ref, double* soa, 
     const double* rb = ref + 2 * (size_t)h->G;
     for (int k = 0; k < 8; k++) {
         double* plane = soa + 2 * h->Gp + (size_t)k * h->Lp;
-        for (int b = 0; b < h->L; b++) plane[b] = rb[8 * (size_t)b + k];
+        for (int b = 0; b < h->L; b++) plane[h->perm[b]] = rb[8 * (size_t)b + k];
     }
 }
 
@@ -133,7 +138,7 @@ static void soa_to_ref(const exaadmm_handle* h, const double* soa, double* ref)
     double* rb = ref + 2 * (size_t)h->G;
     for (int k = 0; k < 8; k++) {
         const double* plane = soa + 2 * h->Gp + (size_t)k * h->Lp;
-        for (int b = 0; b < h->L; b++) rb[8 * (size_t)b + k] = plane[b];
+        for (int b = 0; b < h->L; b++) rb[8 * (size_t)b + k] = plane[h->perm[b]];
     }
 }
 
@@ -211,7 +216,7 @@ static int upload_vec(exaadmm_handle* h, T* dst, const std::vector<T>& src)
 }
 
 static int build_csr(exaadmm_handle* h, const int64_t* start, const int64_t* idx, int base, int nbus, int64_t nnz_expected,
-                     const int** d_start, const int** d_idx, int idx_limit)
+                     const int** d_start, const int** d_idx, int idx_limit, const std::vector<int>* map = nullptr)
 {
     std::vector<int> s(nbus + 1), ix((size_t)std::max<int64_t>(nnz_expected, 0));
     for (int i = 0; i <= nbus; i++) s[i] = (int)(start[i] - base);
@@ -233,6 +238,7 @@ static int build_csr(exaadmm_handle* h, const int64_t* start, const int64_t* idx
             set_err("CSR index out of range");
             return EXAADMM_ERR_INVALID;
         }
+        if (map) ix[k] = (*map)[ix[k]];
     }
     int *ds = nullptr, *di = nullptr;
     int rc;
@@ -280,11 +286,32 @@ extern "C" int exaadmm_create(const exaadmm_grid* g, const exaadmm_params* p, in
     else
         exaadmm_default_params(&h->par);
     fill_branch_options(h);
+    {
+        const int64_t la = g->nline_active > 0 ? g->nline_active : g->nline;
+        const int64_t ba = g->nbus_active > 0 ? g->nbus_active : g->nbus;
+        REQUIRE(la <= g->nline && ba <= g->nbus, "nline_active / nbus_active out of range");
+        const char* e = getenv("EXAADMM_BRANCH_ORDER");
+        const bool by_bus = !(e != nullptr && strcmp(e, "input") == 0);
+        std::vector<int> order(h->L);
+        for (int b = 0; b < h->L; b++) order[b] = b;
+        if (by_bus) {
+            std::vector<int64_t> key(h->L);
+            for (int b = 0; b < h->L; b++) {
+                const bool own = b < la;
+                const int64_t bus = g->brBusIdx[2 * (size_t)b + (own ? 0 : 1)] - g->index_base;
+                key[b] = (own ? 0 : ((int64_t)1 << 40)) + bus;
+            }
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key[a] < key[b]; });
+        }
+        h->perm.assign(h->L, 0);
+        for (int pos = 0; pos < h->L; pos++) h->perm[order[pos]] = pos;
+    }
     memset(&h->info, 0, sizeof(h->info));
     memset(&h->d, 0, sizeof(h->d));
     Dev& d = h->d;
     d.G = h->G; d.L = h->L; d.B = h->B; d.Gp = h->Gp; d.Lp = h->Lp; d.N = h->N;
-    d.La = h->L; d.Ba = h->B;
+    d.La = g->nline_active > 0 ? (int)g->nline_active : h->L;
+    d.Ba = g->nbus_active > 0 ? (int)g->nbus_active : h->B;
     const int base = g->index_base;
     int rc = 0;
 #define TRY(x) do { if ((rc = (x))) { exaadmm_destroy(h); return rc; } } while (0)
@@ -313,13 +340,13 @@ extern "C" int exaadmm_create(const exaadmm_grid* g, const exaadmm_params* p, in
         const double* Ysrc[8] = {g->YffR, g->YffI, g->YftR, g->YftI, g->YttR, g->YttI, g->YtfR, g->YtfI};
         const double* Bsrc[4] = {g->FrVmBound, g->ToVmBound, g->FrVaBound, g->ToVaBound};
         for (int k = 0; k < 8; k++)
-            for (int b = 0; b < h->L; b++) Y[(size_t)k * h->Lp + b] = Ysrc[k][b];
+            for (int b = 0; b < h->L; b++) Y[(size_t)k * h->Lp + h->perm[b]] = Ysrc[k][b];
         for (int k = 0; k < 4; k++)
             for (int b = 0; b < h->L; b++) {
-                bnd[(size_t)(2 * k) * h->Lp + b] = Bsrc[k][2 * b];
-                bnd[(size_t)(2 * k + 1) * h->Lp + b] = Bsrc[k][2 * b + 1];
+                bnd[(size_t)(2 * k) * h->Lp + h->perm[b]] = Bsrc[k][2 * b];
+                bnd[(size_t)(2 * k + 1) * h->Lp + h->perm[b]] = Bsrc[k][2 * b + 1];
             }
-        for (int b = 0; b < h->L; b++) rate[b] = g->rateA[b];
+        for (int b = 0; b < h->L; b++) rate[h->perm[b]] = g->rateA[b];
         h->rateA_h.assign(g->rateA, g->rateA + h->L);
         double *dY, *dB, *dR;
         TRY(dev_alloc(h, &dY, Y.size()));
@@ -371,8 +398,8 @@ extern "C" int exaadmm_create(const exaadmm_grid* g, const exaadmm_params* p, in
             TRY(upload_vec(h, dp, t));
             *dst[k] = dp;
         }
-        TRY(build_csr(h, g->FrStart, g->FrIdx, base, h->B, h->L, &d.FrStart, &d.FrIdx, h->L));
-        TRY(build_csr(h, g->ToStart, g->ToIdx, base, h->B, h->L, &d.ToStart, &d.ToIdx, h->L));
+        TRY(build_csr(h, g->FrStart, g->FrIdx, base, h->B, h->L, &d.FrStart, &d.FrIdx, h->L, &h->perm));
+        TRY(build_csr(h, g->ToStart, g->ToIdx, base, h->B, h->L, &d.ToStart, &d.ToIdx, h->L, &h->perm));
         TRY(build_csr(h, g->GenStart, g->GenIdx, base, h->B, h->G, &d.GenStart, &d.GenIdx, std::max(h->G, 1)));
         // combined per-bus component list for the lane-group bus kernel: generators, from-ends, to-ends
         {
@@ -383,9 +410,9 @@ extern "C" int exaadmm_create(const exaadmm_grid* g, const exaadmm_params* p, in
                 for (int64_t k = g->GenStart[I] - base; k < g->GenStart[I + 1] - base; k++)
                     ec.push_back((END_GEN << 28) | (int)(g->GenIdx[k] - base));
                 for (int64_t k = g->FrStart[I] - base; k < g->FrStart[I + 1] - base; k++)
-                    ec.push_back((END_FROM << 28) | (int)(g->FrIdx[k] - base));
+                    ec.push_back((END_FROM << 28) | h->perm[(size_t)(g->FrIdx[k] - base)]);
                 for (int64_t k = g->ToStart[I] - base; k < g->ToStart[I + 1] - base; k++)
-                    ec.push_back((END_TO << 28) | (int)(g->ToIdx[k] - base));
+                    ec.push_back((END_TO << 28) | h->perm[(size_t)(g->ToIdx[k] - base)]);
             }
             es[h->B] = (int)ec.size();
             int *des, *dec;
@@ -507,10 +534,11 @@ extern "C" int exaadmm_upload_membuf(exaadmm_handle* h, const double* host, int6
     HIPCHK(hipSetDevice(h->device));
     std::vector<double> a(h->Lp, 0.0), b(h->Lp, 0.0), c(h->Lp, 0.0), r(h->Lp, 0.0);
     for (int i = 0; i < h->L; i++) {
-        a[i] = host[24 + 31 * (size_t)i];
-        b[i] = host[25 + 31 * (size_t)i];
-        c[i] = host[26 + 31 * (size_t)i];
-        r[i] = host[28 + 31 * (size_t)i];
+        const int q = h->perm[i];
+        a[q] = host[24 + 31 * (size_t)i];
+        b[q] = host[25 + 31 * (size_t)i];
+        c[q] = host[26 + 31 * (size_t)i];
+        r[q] = host[28 + 31 * (size_t)i];
     }
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(h->d.ls1, a.data(), a.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -533,10 +561,11 @@ extern "C" int exaadmm_download_membuf(exaadmm_handle* h, double* host, int64_t 
     HIPCHK(hipMemcpy(r.data(), h->d.rateA, r.size() * sizeof(double), hipMemcpyDeviceToHost));
     memset(host, 0, sizeof(double) * 31 * (size_t)h->L);
     for (int i = 0; i < h->L; i++) {
-        host[24 + 31 * (size_t)i] = a[i];
-        host[25 + 31 * (size_t)i] = b[i];
-        host[26 + 31 * (size_t)i] = c[i];
-        host[28 + 31 * (size_t)i] = r[i];
+        const int q = h->perm[i];
+        host[24 + 31 * (size_t)i] = a[q];
+        host[25 + 31 * (size_t)i] = b[q];
+        host[26 + 31 * (size_t)i] = c[q];
+        host[28 + 31 * (size_t)i] = r[q];
     }
     return EXAADMM_OK;
 }
@@ -828,9 +857,14 @@ extern "C" int exaadmm_download_branch_counters(exaadmm_handle* h, int32_t* a, i
     REQUIRE(h && nline == h->L, "nline mismatch");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
-    if (a) HIPCHK(hipMemcpy(a, h->d.st_auglag, (size_t)h->L * sizeof(int), hipMemcpyDeviceToHost));
-    if (m) HIPCHK(hipMemcpy(m, h->d.st_minor, (size_t)h->L * sizeof(int), hipMemcpyDeviceToHost));
-    if (t) HIPCHK(hipMemcpy(t, h->d.st_ticks, (size_t)h->L * sizeof(int), hipMemcpyDeviceToHost));
+    std::vector<int> tmp(h->L);
+    int32_t* outs[3] = {a, m, t};
+    const int* srcs[3] = {h->d.st_auglag, h->d.st_minor, h->d.st_ticks};
+    for (int q = 0; q < 3; q++) {
+        if (!outs[q]) continue;
+        HIPCHK(hipMemcpy(tmp.data(), srcs[q], (size_t)h->L * sizeof(int), hipMemcpyDeviceToHost));
+        for (int b = 0; b < h->L; b++) outs[q][b] = tmp[h->perm[b]];   // back to reference branch order
+    }
     return EXAADMM_OK;
 }
 
@@ -1035,6 +1069,8 @@ extern "C" int exaadmm_set_async(exaadmm_handle* h, int async)
 extern "C" int exaadmm_set_active(exaadmm_handle* h, int64_t nbranch, int64_t nbus)
 {
     REQUIRE(h && nbranch >= 0 && nbranch <= h->L && nbus >= 0 && nbus <= h->B, "active counts out of range");
+    REQUIRE(nbranch == h->d.La || getenv("EXAADMM_BRANCH_ORDER") != nullptr,
+            "active branch count must be given at create time (exaadmm_grid.nline_active): branches are stored bus-sorted");
     h->d.La = (int)nbranch;
     h->d.Ba = (int)nbus;
     h->dev_dirty = true;

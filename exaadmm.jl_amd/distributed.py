@@ -128,7 +128,8 @@ class Partition:
         self.n_cut = len(cut_out)
 
         # local grid
-        g = {"ngen": Gl, "nline": Ll, "nbus": Bl, "baseMVA": float(grid["baseMVA"])}
+        g = {"ngen": Gl, "nline": Ll, "nbus": Bl, "baseMVA": float(grid["baseMVA"]),
+             "nline_active": self.n_native, "nbus_active": Bl}
         for k in ("pgmin", "pgmax", "qgmin", "qgmax", "c2", "c1", "c0"):
             g[k] = np.ascontiguousarray(np.asarray(grid[k])[self.gens])
         for k in ("YffR", "YffI", "YftR", "YftI", "YttR", "YttI", "YtfR", "YtfI", "rateA"):
@@ -139,7 +140,9 @@ class Partition:
             g[k] = np.ascontiguousarray(np.asarray(grid[k])[self.buses])
         lfr = bus_l[bb[self.branches, 0]]     # -1 where the end is remote
         lto = bus_l[bb[self.branches, 1]]
-        g["brBusIdx"] = np.stack([np.maximum(lfr, 0), np.maximum(lto, 0)], 1).ravel()   # only used by init (overridden)
+        # remote ends point at local bus 0: only the OWN end is used (bus-sorted storage order);
+        # the values init_solution! derives from them are overridden by the uploaded global state
+        g["brBusIdx"] = np.stack([np.maximum(lfr, 0), np.maximum(lto, 0)], 1).ravel()
 
         def csr(owner, n):
             keep = np.flatnonzero(owner >= 0)

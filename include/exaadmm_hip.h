@@ -57,6 +57,9 @@ typedef struct {
     const int64_t *brBusIdx;                                              /* 2*nline (from,to) */
     const double *Pd, *Qd, *Vmin, *Vmax, *YshR, *YshI;                    /* nbus */
     const int64_t *FrStart, *FrIdx, *ToStart, *ToIdx, *GenStart, *GenIdx; /* CSR bus -> branch/gen */
+    /* partitions only (multi-GPU): the first nline_active branches / nbus_active buses are this
+     * rank's own, the rest are ghost copies; 0 = everything is active (single GPU) */
+    int64_t nline_active, nbus_active;
 } exaadmm_grid;
 
 /* Mirrors Parameters (src/utils/environment.jl:6-76), fields the path reads. */

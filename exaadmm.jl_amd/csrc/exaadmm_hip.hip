@@ -482,7 +482,8 @@ extern "C" int64_t exaadmm_nvar(exaadmm_handle* h) { return h ? h->nvar : -1; }
 extern "C" int exaadmm_set_stream(exaadmm_handle* h, void* hip_stream)
 {
     REQUIRE(h, "null handle");
-    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    // NULL is a real stream (the null stream, torch's default); the sentinel selects the private one
+    h->stream = (hip_stream == EXAADMM_OWN_STREAM) ? h->own_stream : (hipStream_t)hip_stream;
     return EXAADMM_OK;
 }
 

@@ -157,7 +157,10 @@ int exaadmm_run_fixed(exaadmm_handle *h, int iters, int first_major_iter, double
                       double *ms_total, double *ms_branch);
 
 /* ---- multi-GPU helpers (one handle = one partition of the grid) ---- */
-/* run on a caller-provided HIP stream (e.g. torch's current stream); NULL = library stream */
+/* run on a caller-provided HIP stream (e.g. torch's current stream).  NULL is the device's
+ * default (null) stream -- which is what torch.cuda.current_stream().cuda_stream returns unless a
+ * side stream is active; EXAADMM_OWN_STREAM switches back to the handle's private stream. */
+#define EXAADMM_OWN_STREAM ((void *)(~(uintptr_t)0))
 int exaadmm_set_stream(exaadmm_handle *h, void *hip_stream);
 /* async != 0: step-wise entry points only enqueue (no stream synchronisation on return);
  * the caller orders them against its collectives through the stream */

@@ -468,3 +468,66 @@ def solve_acopf(case, case_format="matpower", outer_iterlim=20, inner_iterlim=10
     env.params.check_every = check_every
     admm_two_level(env, mod, fused=fused)
     return env, mod
+
+
+# --------------------------------------------------------------------------- rolling horizon
+def get_load(load_prefix, load_scale=1.0):
+    """get_load (utils/opfdata.jl:121-130): <prefix>.Pd / <prefix>.Qd, whitespace matrices nbus x T."""
+    pd = np.atleast_2d(np.loadtxt(load_prefix + ".Pd")) * load_scale
+    qd = np.atleast_2d(np.loadtxt(load_prefix + ".Qd")) * load_scale
+    if pd.shape != qd.shape:
+        raise ExaAdmmError("Pd / Qd load files differ in shape")
+    return pd, qd
+
+
+def update_real_power_current_bounds(mod, x_curr=None):
+    """acopf_admm_rolling_cpu.jl:1-14: ramp-limited generation bounds around the last dispatch."""
+    x = mod.solution.u_curr if x_curr is None else x_curr
+    pg = x[0:2 * mod.ngen:2]
+    lo = np.maximum(mod.grid_data["pgmin"], pg - mod.ramp_rate)
+    hi = np.minimum(mod.grid_data["pgmax"], pg + mod.ramp_rate)
+    mod.set_pg_bounds(lo, hi)
+
+
+def admm_restart_rolling(env, mod, load, start_period=1, end_period=6, update_start_period_bounds=False,
+                         fused=True, on_period=None):
+    """admm_restart_rolling (acopf_admm_rolling_cpu.jl:16-48): per period swap Pd/Qd, warm-start
+    admm_two_level on the same model (lz, z, l, u, v and the branch multipliers persist; beta is
+    reset inside admm_two_level), then tighten the pg bounds by the ramp rate."""
+    pd, qd = load
+    if not (start_period >= 1 and end_period <= pd.shape[1]):
+        raise ExaAdmmError("period range outside the load profile")
+    if update_start_period_bounds:
+        update_real_power_current_bounds(mod)
+    results = []
+    for t in range(start_period, end_period + 1):
+        mod.set_load(pd[:, t - 1], qd[:, t - 1])
+        admm_two_level(env, mod, fused=fused)
+        results.append(dict(period=t, status=mod.info.status, objval=mod.info.objval, mismatch=mod.info.mismatch,
+                            cumul=mod.info.cumul, outer=mod.info.outer, time=mod.info.time_overall))
+        if on_period:
+            on_period(results[-1])
+        update_real_power_current_bounds(mod)
+    return results
+
+
+def solve_acopf_rolling(case, load_prefix=None, load=None, case_format="matpower", outer_iterlim=20,
+                        inner_iterlim=1000, rho_pq=400.0, rho_va=40000.0, obj_scale=1.0, scale=1e-4,
+                        tight_factor=0.99, outer_eps=2e-4, gpu_no=0, verbose=0, ramp_ratio=0.02,
+                        start_period=1, end_period=6, grid=None, fused=True):
+    """solve_acopf_rolling (interface/solve_acopf_rolling.jl:2-30).  `load` may be given directly as
+    (Pd, Qd) matrices instead of a file prefix.  Returns (env, mod, per-period results)."""
+    env = AdmmEnv(case, rho_pq, rho_va, case_format=case_format, tight_factor=tight_factor, gpu_no=gpu_no,
+                  verbose=verbose, grid=grid)
+    mod = ModelAcopf(env)
+    mod.ramp_rate = ramp_ratio * mod.grid_data["pgmax"]     # acopf_model.jl:66-67
+    env.params.scale = scale
+    env.params.outer_eps = outer_eps
+    env.params.outer_iterlim = outer_iterlim
+    env.params.inner_iterlim = inner_iterlim
+    if load is None:
+        if load_prefix is None:
+            raise ExaAdmmError("load profile required (load_prefix or load=(Pd, Qd))")
+        load = get_load(load_prefix)
+    results = admm_restart_rolling(env, mod, load, start_period=start_period, end_period=end_period, fused=fused)
+    return env, mod, results

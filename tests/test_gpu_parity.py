@@ -365,3 +365,34 @@ def test_long_run_does_not_drift_from_oracle(pkg, oracle, syn):
         inherent = np.abs(ref2.sol[name] - b).max()
         assert np.abs(a - b).max() <= 10 * inherent + 1e-9 * max(1.0, np.abs(b).max()), (name, inherent)
         assert np.abs(a - b).max() <= 1e-3 * max(1.0, np.abs(b).max()), name
+
+
+def test_rolling_horizon_matches_oracle(pkg, oracle, case9_grid, tmp_path):
+    """solve_acopf_rolling (row f3): 4 periods of case9 with a load profile read from .Pd/.Qd
+    files, ramp-limited generator bounds and warm starts; per-period status, iteration counts
+    and objective against the same procedure on the CPU oracle."""
+    T = 4
+    fac = np.array([1.0, 1.01, 0.995, 1.015])   # within the 2 %-of-Pmax ramp capability
+    pd = np.outer(case9_grid["Pd"], fac)
+    qd = np.outer(case9_grid["Qd"], fac)
+    np.savetxt(str(tmp_path / "load.Pd"), pd)
+    np.savetxt(str(tmp_path / "load.Qd"), qd)
+    kw = dict(rho_pq=4e2, rho_va=4e4, outer_iterlim=25, outer_eps=2e-5, tight_factor=1.0)
+    env, mod, res = pkg.solve_acopf_rolling(CASE9, load_prefix=str(tmp_path / "load"), start_period=1, end_period=T,
+                                            ramp_ratio=0.02, **kw)
+    # the same procedure on the oracle (acopf_admm_rolling_cpu.jl:16-48)
+    g = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in case9_grid.items()}
+    ref = oracle.OracleModel(g, 4e2, 4e4, outer_iterlim=25, outer_eps=2e-5)
+    ramp = 0.02 * g["pgmax"]
+    for t in range(T):
+        ref.g["Pd"][:] = pd[:, t]
+        ref.g["Qd"][:] = qd[:, t]
+        info = ref.admm_two_level()
+        assert res[t]["status"] == ("Solved" if info.status == 1 else "IterationLimit")
+        assert (res[t]["outer"], res[t]["cumul"]) == (info.outer, info.cumul), t
+        assert abs(res[t]["objval"] - info.objval) <= 1e-6 * abs(info.objval)
+        pg = ref.sol["u_curr"][0:2 * g["ngen"]:2]
+        ref.pgmin_curr[:] = np.maximum(g["pgmin"], pg - ramp)
+        ref.pgmax_curr[:] = np.minimum(g["pgmax"], pg + ramp)
+    assert np.abs(mod.solution.u_curr - ref.sol["u_curr"]).max() <= 1e-6
+    assert np.allclose(mod.pgmin_curr, ref.pgmin_curr, atol=1e-8) and np.allclose(mod.pgmax_curr, ref.pgmax_curr, atol=1e-8)

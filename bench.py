@@ -60,7 +60,7 @@ def cpu_baseline(grid, params, budget_s=15.0, nthreads=1):
     for _ in range(2):
         it += 1
         m.inner_prestep(); m.update_x(it); m.update_xbar(); m.update_z(); m.update_l(); m.update_residual()
-    while t_used < budget_s and n_done < 200:
+    while t_used < budget_s and n_done < 500:
         it += 1
         t0 = time.perf_counter()
         m.inner_prestep(); m.update_x(it); m.update_xbar(); m.update_z(); m.update_l(); m.update_residual()

@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--case", default=CASE)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--full-solve", action="store_true",
+                    help="also run a whole solve_acopf (outer 20 x inner 1000) and report cumul/time_overall; minutes on a non-converging instance")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU code path even with one rank")
     args = ap.parse_args()
 
@@ -150,6 +152,14 @@ def main():
         "solver": {"avg_auglag_it": a_it, "avg_tron_minor_it": m_it, "primres": float(norms[0]),
                    "device_ms_total": ms_total},
     }
+    if args.full_solve:
+        # the reference's own definition of the metric (print_statistics.jl:12): cumul / time_overall
+        # of a whole solve_acopf with the README settings (outer 20, inner 1000, early breaks active)
+        env2, mod2 = pkg.solve_acopf(args.case, grid=grid, rho_pq=params["rho_pq"], rho_va=params["rho_va"],
+                                     scale=params["scale"], tight_factor=0.99, outer_iterlim=20, inner_iterlim=1000, verbose=0)
+        i2 = mod2.info
+        out["full_solve"] = {"status": i2.status, "outer": i2.outer, "cumul": i2.cumul, "time_overall_s": i2.time_overall,
+                             "iterations_per_s": i2.cumul / i2.time_overall, "objval": i2.objval, "mismatch": i2.mismatch}
     if not args.no_cpu_baseline:
         cb = cpu_baseline(grid, params)
         out["cpu_baseline"] = cb

@@ -144,15 +144,18 @@ class Partition:
         # the values init_solution! derives from them are overridden by the uploaded global state
         g["brBusIdx"] = np.stack([np.maximum(lfr, 0), np.maximum(lto, 0)], 1).ravel()
 
-        def csr(owner, n):
+        def csr(owner, n, gid=None):
+            # within a bus keep the GLOBAL component order (ghosts interleave with natives), so the
+            # bus update adds its terms in exactly the order of the unpartitioned grid
             keep = np.flatnonzero(owner >= 0)
-            order = keep[np.argsort(owner[keep], kind="stable")]
+            key2 = keep if gid is None else gid[keep]
+            order = keep[np.lexsort((key2, owner[keep]))]
             start = np.zeros(n + 1, dtype=np.int64)
             np.add.at(start, owner[keep] + 1, 1)
             return np.cumsum(start), order.astype(np.int64)
 
-        g["FrStart"], g["FrIdx"] = csr(lfr, Bl)
-        g["ToStart"], g["ToIdx"] = csr(lto, Bl)
+        g["FrStart"], g["FrIdx"] = csr(lfr, Bl, self.branches)
+        g["ToStart"], g["ToIdx"] = csr(lto, Bl, self.branches)
         g["GenStart"], g["GenIdx"] = csr(bus_l[gen_bus[self.gens]], Bl)
         self.grid = g
         self.Gl, self.Ll, self.Bl = Gl, Ll, Bl

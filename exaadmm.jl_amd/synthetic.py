@@ -18,11 +18,16 @@ CASE_SIZES = {
 }
 
 
-def synthetic_grid(ngen, nline, nbus, seed=0, tight_factor=0.99, locality=64):
+def synthetic_grid(ngen, nline, nbus, seed=0, tight_factor=0.99, locality=64, feasible=True):
     """Random connected grid: spanning tree over the buses (each bus attaches to one of the
     `locality` previous buses, which gives the banded structure of real networks) plus
     extra local edges up to nline.  Returns the dict layout used by AdmmEnv(grid=...),
-    zero-based indices."""
+    zero-based indices.
+
+    feasible=True (default) makes the instance a solvable OPF like the real cases instead of
+    random numbers: every load is supplied by the electrically nearest generator (capacities
+    are raised where needed), a DC power flow of that dispatch gives the line flows, and the
+    thermal limits are set with margin above those flows."""
     assert nline >= nbus - 1 and ngen >= 1
     rng = np.random.default_rng(seed)
     M = 100.0
@@ -44,11 +49,12 @@ def synthetic_grid(ngen, nline, nbus, seed=0, tight_factor=0.99, locality=64):
 
     r = rng.uniform(1e-3, 3e-2, nline)
     x = rng.uniform(1e-2, 2e-1, nline)
-    bc = rng.uniform(0.0, 0.3, nline)
+    bc = rng.uniform(0.0, 0.3 if not feasible else 0.06, nline)
     Ys = 1.0 / (r + 1j * x)
     Ytt = Ys + 1j * bc / 2
     Yff, Yft, Ytf = Ytt, -Ys, -Ys
-    rate = np.where(rng.random(nline) < 0.3, 0.0, rng.uniform(100.0, 900.0, nline))
+    unlimited = rng.random(nline) < 0.3
+    rate = np.where(unlimited, 0.0, rng.uniform(100.0, 900.0, nline))
 
     Vmin, Vmax = np.full(nbus, 0.9), np.full(nbus, 1.1)
     has_load = rng.random(nbus) < 0.6
@@ -59,6 +65,26 @@ def synthetic_grid(ngen, nline, nbus, seed=0, tight_factor=0.99, locality=64):
     need = 1.3 * Pd.sum()
     if Pmax.sum() < need:
         Pmax *= need / Pmax.sum()
+    if feasible:
+        import scipy.sparse as sp
+        import scipy.sparse.linalg as spla
+        Qd = 0.25 * Pd
+        # nearest generator in bus-index space (the grid is banded in that order)
+        k = np.clip(np.searchsorted(gbus, np.arange(nbus)), 1, ngen - 1) if ngen > 1 else np.zeros(nbus, dtype=np.int64)
+        if ngen > 1:
+            left = np.abs(gbus[k - 1] - np.arange(nbus)) <= np.abs(gbus[k] - np.arange(nbus))
+            k = np.where(left, k - 1, k)
+        Pg = 1.02 * np.bincount(k, weights=Pd, minlength=ngen)
+        Pmax = np.maximum(Pmax, Pg / 0.6)
+        inj = (np.bincount(gbus, weights=Pg, minlength=nbus) - Pd) / M
+        inj[0] -= inj.sum()                      # slack at the reference bus
+        w = 1.0 / x
+        Bm = sp.coo_matrix((np.concatenate([w, w, -w, -w]), (np.concatenate([fr, to, fr, to]), np.concatenate([fr, to, to, fr]))),
+                           shape=(nbus, nbus)).tocsr()
+        theta = np.zeros(nbus)
+        theta[1:] = spla.spsolve(Bm[1:, 1:].tocsc(), inj[1:])
+        flow = np.abs((theta[fr] - theta[to]) * w) * M                     # MW
+        rate = np.where(unlimited, 0.0, np.maximum(1.6 * flow, 60.0) * rng.uniform(1.0, 1.5, nline))
     g = {"ngen": ngen, "nline": nline, "nbus": nbus, "baseMVA": M, "bus_ref": 0}
     g["pgmin"] = np.zeros(ngen)
     g["pgmax"] = Pmax / M

@@ -96,3 +96,28 @@ def test_synthetic_grid_is_connected_and_sized(pkg):
     assert len({find(i) for i in range(g["nbus"])}) == 1
     assert g["FrStart"][-1] == g["nline"] and g["GenStart"][-1] == g["ngen"]
     assert (bb[:, 0] != bb[:, 1]).all()
+
+
+def test_argument_errors_are_reported_not_thrown(pkg):
+    """error convention of the boundary: negative status + message, no exception / abort"""
+    import ctypes as C
+    L = pkg.library()
+    h = C.c_void_p()
+    g = pkg.Grid()          # all-zero grid: nline == 0
+    p = pkg.Parameters()
+    L.exaadmm_default_params(C.byref(p))
+    assert (p.mu_max, p.max_auglag, p.initial_beta, p.inc_c, p.theta) == (1e8, 50, 1e3, 6.0, 0.8)
+    assert (p.outer_iterlim, p.inner_iterlim, p.scale, p.MAX_MULTIPLIER) == (20, 1000, 1e-4, 1e12)
+    rc = L.exaadmm_create(C.byref(g), C.byref(p), 0, C.byref(h))
+    assert rc == -1 and b"empty grid" in L.exaadmm_last_error()
+    assert L.exaadmm_update_x(None, 1) == -1
+    assert L.exaadmm_nvar(None) == -1
+    assert L.exaadmm_destroy(None) == 0
+    assert L.exaadmm_version().decode().startswith("exaadmm-hip")
+
+
+def test_dead_reference_options_are_rejected(pkg):
+    with pytest.raises(pkg.ExaAdmmError, match="use_linelimit"):
+        pkg.AdmmEnv(CASE9, 4e2, 4e4, use_linelimit=False)
+    with pytest.raises(pkg.ExaAdmmError, match="use_projection"):
+        pkg.AdmmEnv(CASE9, 4e2, 4e4, use_projection=True)

@@ -450,6 +450,24 @@ def admm_two_level(env, mod, device=None, fused=True):
     admm_poststep(env, mod, device)
 
 
+def print_statistics(env, mod, file=None):
+    """print_statistics (utils/print_statistics.jl:1-21).  Step times of a fused solve are sampled
+    device times (one iteration in eight); generators run inside the branch launch."""
+    info = mod.info
+    out = file or __import__("sys").stdout
+    w = out.write
+    w(" ** Statistics\n")
+    w("Objective value  . . . . . . . . . %12.6e\n" % info.objval)
+    w("Residual . . . . . . . . . . . . . %12.6e\n" % info.mismatch)
+    w("Outer iterations . . . . . . . . . %12d\n" % info.outer)
+    w("Cumulative iterations  . . . . . . %12d\n" % info.cumul)
+    w("Time per iteration . . . . . . . . %12.6f (secs/iter)\n" % (info.time_overall / max(info.cumul, 1)))
+    w("Overall time . . . . . . . . . . . %12.3f (secs)\n" % info.time_overall)
+    w("Generator + branch time  . . . . . %12.3f (secs)\n" % info.time_x_update)
+    w("Bus time . . . . . . . . . . . . . %12.3f (secs)\n" % info.time_xbar_update)
+    w("z, l, residual time  . . . . . . . %12.3f (secs)\n" % info.time_zl_update)
+
+
 def solve_acopf(case, case_format="matpower", outer_iterlim=20, inner_iterlim=1000, rho_pq=400.0,
                 rho_va=40000.0, obj_scale=1.0, scale=1e-4, use_linelimit=True, use_projection=False,
                 tight_factor=1.0, outer_eps=2e-4, gpu_no=0, verbose=0, grid=None, fused=True,
@@ -467,6 +485,8 @@ def solve_acopf(case, case_format="matpower", outer_iterlim=20, inner_iterlim=10
     env.params.inner_iterlim = inner_iterlim
     env.params.check_every = check_every
     admm_two_level(env, mod, fused=fused)
+    if verbose > 0:
+        print_statistics(env, mod)
     return env, mod
 
 

@@ -92,6 +92,8 @@ struct exaadmm_handle {
     bool ctrl_mode = false;
     exaadmm_info info;
     std::vector<hipEvent_t> ev;
+    hipEvent_t tev[4] = {nullptr, nullptr, nullptr, nullptr};  // sampled per-step timing of the fused loop
+    double acc_ms[3] = {0.0, 0.0, 0.0};                          // x-update, xbar-update, z/l/residual
     InitData init;
 };
 
@@ -457,6 +459,8 @@ extern "C" int exaadmm_destroy(exaadmm_handle* h)
     if (h->h_ctrl) (void)hipHostFree(h->h_ctrl);
     if (h->h_sums) (void)hipHostFree(h->h_sums);
     for (auto e : h->ev) (void)hipEventDestroy(e);
+    for (auto e : h->tev)
+        if (e) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return EXAADMM_OK;
@@ -880,12 +884,16 @@ extern "C" int exaadmm_debug_phase_cycles(exaadmm_handle* h, unsigned long long*
 }
 
 // ------------------------------------------------------------------ fused loops
-static void enqueue_iteration(exaadmm_handle* h, Ctrl* c)
+static void enqueue_iteration(exaadmm_handle* h, Ctrl* c, bool sample = false)
 {
+    if (sample) (void)hipEventRecord(h->tev[0], h->stream);
     launch_branch(h, 0, c, true);   // generators ride in the same launch
+    if (sample) (void)hipEventRecord(h->tev[1], h->stream);
     launch_bus(h, c);
+    if (sample) (void)hipEventRecord(h->tev[2], h->stream);
     launch_fused_zl(h, 0.0, c);
     launch_final(h, c);
+    if (sample) (void)hipEventRecord(h->tev[3], h->stream);
 }
 
 extern "C" int exaadmm_run_inner(exaadmm_handle* h, int outer, int max_inner, double beta, int* inner_done, double out[4])
@@ -906,13 +914,25 @@ extern "C" int exaadmm_run_inner(exaadmm_handle* h, int outer, int max_inner, do
     // without a host round trip per iteration.
     const int batch = 8;
     int enq = 0;
+    for (auto& e : h->tev)
+        if (!e) HIPCHK(hipEventCreate(&e));
+    int inner_before = 0;
     while (enq < max_inner) {
         const int nb = std::min(batch, max_inner - enq);
-        for (int i = 0; i < nb; i++) enqueue_iteration(h, h->d_ctrl);
+        // the first iteration of every batch is timed with events; its step times stand for the
+        // iterations the batch executed (mod.info.time_*_update of the reference, sampled)
+        for (int i = 0; i < nb; i++) enqueue_iteration(h, h->d_ctrl, i == 0);
         enq += nb;
         HIPCHK(hipMemcpyAsync(hc, h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
         int rc = sync_check(h, true);
         if (rc) return rc;
+        const int executed = hc->inner - inner_before;
+        inner_before = hc->inner;
+        if (executed > 0) {
+            float ms;
+            for (int q = 0; q < 3; q++)
+                if (hipEventElapsedTime(&ms, h->tev[q], h->tev[q + 1]) == hipSuccess) h->acc_ms[q] += (double)ms * executed;
+        }
         if (hc->done) break;
     }
     if (inner_done) *inner_done = hc->inner;
@@ -935,6 +955,7 @@ extern "C" int exaadmm_solve_two_level(exaadmm_handle* h, exaadmm_info* out)
     info.norm_z_prev = info.norm_z_curr = INFINITY;
     par.beta = par.initial_beta;
     info.status = 0;
+    h->acc_ms[0] = h->acc_ms[1] = h->acc_ms[2] = 0.0;
     int rc;
 
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -965,6 +986,9 @@ extern "C" int exaadmm_solve_two_level(exaadmm_handle* h, exaadmm_info* out)
     }
     HIPCHK(hipStreamSynchronize(h->stream));
     info.time_overall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    info.time_x_update = 1e-3 * h->acc_ms[0];
+    info.time_xbar_update = 1e-3 * h->acc_ms[1];
+    info.time_zl_update = 1e-3 * h->acc_ms[2];
     if ((rc = exaadmm_objective(h, &info.objval))) return rc;  // admm_poststep
     exaadmm_branch_stats(h, &info.avg_auglag_it, &info.avg_minor_it);
     if (out) *out = info;

@@ -27,7 +27,7 @@ def hc():
     srcs = [os.path.join(HC_DIR, "hostcheck.cpp"), os.path.join(CSRC, "tron_device.h"),
             os.path.join(CSRC, "branch_solver.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mfma",
                                "-I", CSRC, srcs[0], "-o", so, "-lm"])
     L = C.CDLL(so)
     L.hostcheck_fgh.restype = C.c_double

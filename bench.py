@@ -164,8 +164,8 @@ def main():
         cb = cpu_baseline(grid, params)
         out["cpu_baseline"] = cb
         out["speedup_vs_cpu_baseline"] = its / cb["value"]
-        ncpu = os.cpu_count() or 1
-        if ncpu > 1:   # extra: the same port with OpenMP over the branch loop on every host core
+        ncpu = min(os.cpu_count() or 1, 16)
+        if ncpu > 1:   # extra: the same port with OpenMP over the branch loop (capped: more threads are slower)
             out["cpu_baseline_all_cores"] = cpu_baseline(grid, params, budget_s=8.0, nthreads=ncpu)
     print(json.dumps(out))
 

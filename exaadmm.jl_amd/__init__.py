@@ -120,6 +120,7 @@ def library():
     L.exaadmm_branch_stats.argtypes = [H, c_double_p, c_double_p]
     L.exaadmm_download_branch_counters.argtypes = [H, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                                    C.POINTER(C.c_int32), C.c_int64]
+    L.exaadmm_set_branch_lane_order.argtypes = [H, C.POINTER(C.c_int32), C.c_int64]
     L.exaadmm_run_inner.argtypes = [H, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int), c_double_p]
     L.exaadmm_solve_two_level.argtypes = [H, C.POINTER(Info)]
     L.exaadmm_run_fixed.argtypes = [H, C.c_int, C.c_int, C.c_double, c_double_p, c_double_p, c_double_p]
@@ -328,6 +329,13 @@ class ModelAcopf:
         _check(library().exaadmm_download_branch_counters(self._h, a.ctypes.data_as(ip), m.ctypes.data_as(ip),
                                                           t.ctypes.data_as(ip), self.nline), "branch counters")
         return a, m, t
+
+    def set_branch_lane_order(self, order):
+        if order is None:
+            _check(library().exaadmm_set_branch_lane_order(self._h, None, 0), "lane order")
+            return
+        o = np.ascontiguousarray(order, dtype=np.int32)
+        _check(library().exaadmm_set_branch_lane_order(self._h, o.ctypes.data_as(C.POINTER(C.c_int32)), o.size), "lane order")
 
     def run_fixed(self, iters, first_major_iter=2, beta=None, time_branch=False):
         """K inner iterations without convergence test; returns (norms, ms_total, ms_branch)."""

@@ -85,6 +85,7 @@ struct exaadmm_handle {
     // gathers of consecutive buses hit consecutive elements of the planes.
     std::vector<int> perm;
     unsigned char* d_owned = nullptr;
+    int* d_lane_order = nullptr;
     HaloSlot halo[8];
     bool residual_vectors_valid = false;
     bool async_mode = false;
@@ -456,6 +457,7 @@ extern "C" int exaadmm_destroy(exaadmm_handle* h)
         if (s.d_which) (void)hipFree(s.d_which);
     }
     if (h->d_owned) (void)hipFree(h->d_owned);
+    if (h->d_lane_order) (void)hipFree(h->d_lane_order);
     if (h->h_ctrl) (void)hipHostFree(h->h_ctrl);
     if (h->h_sums) (void)hipHostFree(h->h_sums);
     for (auto e : h->ev) (void)hipEventDestroy(e);
@@ -870,6 +872,32 @@ extern "C" int exaadmm_download_branch_counters(exaadmm_handle* h, int32_t* a, i
         HIPCHK(hipMemcpy(tmp.data(), srcs[q], (size_t)h->L * sizeof(int), hipMemcpyDeviceToHost));
         for (int b = 0; b < h->L; b++) outs[q][b] = tmp[h->perm[b]];   // back to reference branch order
     }
+    return EXAADMM_OK;
+}
+
+// Lane assignment of the branch kernel: lane i solves reference branch order[i] (a permutation of
+// the active branches).  NULL restores the identity.  Results do not depend on it.
+extern "C" int exaadmm_set_branch_lane_order(exaadmm_handle* h, const int32_t* order, int64_t n)
+{
+    REQUIRE(h, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->dev_dirty = true;
+    if (!order) {
+        h->d.lane_order = nullptr;
+        return EXAADMM_OK;
+    }
+    REQUIRE(n == h->d.La, "order must list every active branch once");
+    std::vector<int> t(n);
+    std::vector<char> seen(h->L, 0);
+    for (int64_t i = 0; i < n; i++) {
+        REQUIRE(order[i] >= 0 && order[i] < h->d.La && !seen[order[i]], "order is not a permutation of the active branches");
+        seen[order[i]] = 1;
+        t[i] = h->perm[order[i]];
+    }
+    if (!h->d_lane_order) HIPCHK(hipMalloc((void**)&h->d_lane_order, (size_t)h->Lp * sizeof(int)));
+    HIPCHK(hipMemcpy(h->d_lane_order, t.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+    h->d.lane_order = h->d_lane_order;
     return EXAADMM_OK;
 }
 

@@ -39,6 +39,7 @@ struct Dev {
     const int *FrStart, *FrIdx, *ToStart, *ToIdx, *GenStart, *GenIdx;
     const int *EndStart, *EndCode;  // per bus: generators, from-branches, to-branches (kind << 28 | index)
     const unsigned char* owned;  // SoA order; nullptr = all owned
+    const int* lane_order;       // k_branch: lane i solves branch lane_order[i] (nullptr = identity)
     int *st_auglag, *st_minor, *st_ticks;
     unsigned long long* st_cyc;  // diagnostic build (EXA_PROFILE_PHASES): 5 x Lp phase cycle counters
     double* partials;  // [blocks][4]
@@ -99,8 +100,12 @@ __global__ void __launch_bounds__(BR_BLOCK) k_branch(const Dev* __restrict__ dp,
         generator_update(d, baseMVA, ((int)blockIdx.x - nbr_blocks) * BR_BLOCK + threadIdx.x);
         return;
     }
-    const int b = blockIdx.x * BR_BLOCK + threadIdx.x;
-    if (b >= d.La) return;
+    const int slot = blockIdx.x * BR_BLOCK + threadIdx.x;
+    if (slot >= d.La) return;
+    // lanes of a wavefront execute the union of their control paths: grouping branches that took
+    // similar paths in the previous ADMM iteration (lane_order, refreshed by the host side) cuts
+    // that divergence; which lane solves a branch does not change any result.
+    const int b = d.lane_order ? d.lane_order[slot] : slot;
     const int Lp = d.Lp;
     const int base = 2 * d.Gp + b;
     double* my = lds + threadIdx.x;

@@ -142,6 +142,10 @@ int exaadmm_branch_stats(exaadmm_handle *h, double *avg_auglag_it, double *avg_m
 /* per-branch work counters of the last x-update: augmented-Lagrangian iterations, TRON minor
  * iterations (summed), solver-loop trips of the lane (divergence diagnostics) */
 int exaadmm_download_branch_counters(exaadmm_handle *h, int32_t *auglag_it, int32_t *minor_it, int32_t *ticks, int64_t nline);
+/* lane assignment of the branch kernel: lane i solves branch order[i] (zero-based reference branch
+ * ids, a permutation of the active branches; NULL = identity).  Grouping branches with similar
+ * solver work into the same wavefront reduces divergence; results do not depend on it. */
+int exaadmm_set_branch_lane_order(exaadmm_handle *h, const int32_t *order, int64_t n);
 
 /* ---- fused: control stays on the device side ---- */
 /* Inner while-loop of admm_two_level (admm_two_level.jl:34-63) for outer iteration `outer`:

@@ -396,3 +396,22 @@ def test_rolling_horizon_matches_oracle(pkg, oracle, case9_grid, tmp_path):
         ref.pgmax_curr[:] = np.minimum(g["pgmax"], pg + ramp)
     assert np.abs(mod.solution.u_curr - ref.sol["u_curr"]).max() <= 1e-6
     assert np.allclose(mod.pgmin_curr, ref.pgmin_curr, atol=1e-8) and np.allclose(mod.pgmax_curr, ref.pgmax_curr, atol=1e-8)
+
+
+def test_results_do_not_depend_on_lane_assignment(pkg, syn):
+    """k_branch may solve branches in any lane order (exaadmm_set_branch_lane_order): bitwise
+    identical u, multipliers and norms for identity, reversed and random assignments."""
+    g = syn.sized_like("case1354pegase", seed=4)
+    outs = []
+    rng = np.random.default_rng(1)
+    for order in (None, np.arange(g["nline"])[::-1].copy(), rng.permutation(g["nline"])):
+        env = pkg.AdmmEnv("syn", 1e1, 1e3, verbose=0, grid=g)
+        mod = pkg.ModelAcopf(env)
+        mod.set_branch_lane_order(order)
+        norms, _, _ = mod.run_fixed(12, first_major_iter=1, beta=1e3)
+        outs.append((mod.solution.u_curr, mod.membuf, norms, mod.branch_counters()[0]))
+    for o in outs[1:]:
+        assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1])
+        assert np.array_equal(o[2], outs[0][2]) and np.array_equal(o[3], outs[0][3])
+    with pytest.raises(pkg.ExaAdmmError):
+        mod.set_branch_lane_order(np.zeros(g["nline"], dtype=np.int32))   # not a permutation

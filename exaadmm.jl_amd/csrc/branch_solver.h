@@ -280,10 +280,13 @@ EXA_HD void branch_solve(D& d, const BranchOptions& o, const MuPowTable& pw, dou
         int fin = TRON_RUN;
         unsigned long long t0 = EXA_TICK();
         if (need_gh) {
+            // ONE evaluation site for both cases (a second inlined copy would be executed one after
+            // the other whenever a wavefront holds lanes of both kinds)
+            const double fx = branch_fgh(d, x, g, A, phi);
             if (restart) {
                 // task START: f, g, H at x; delta0 = ||g||  (tron_linelimit_kernel.jl:66-106)
                 it++;
-                st.f = branch_fgh(d, x, g, A, phi);
+                st.f = fx;
                 st.delta = nrm2<6>(g);
                 st.iter = 1;
                 st.alphac = 1.0;
@@ -292,7 +295,6 @@ EXA_HD void branch_solve(D& d, const BranchOptions& o, const MuPowTable& pw, dou
                 restart = false;
             } else {
                 // task GH then NEWX  (tron_linelimit_kernel.jl:86-135)
-                (void)branch_fgh(d, x, g, A, phi);
                 st.minor_iter++;
                 if (gpnorm<6>(x, xl, xu, g) <= o.gtol) fin = TRON_CONV;
                 if (st.minor_iter >= o.max_minor) fin = TRON_MAXMINOR;

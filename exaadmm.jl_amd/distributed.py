@@ -312,13 +312,33 @@ class DistributedAcopf:
         self.buf_recv_v = backend.new_buffer(sum(p.plan_recv_v[2]))
         self.info = {"outer": 0, "inner": 0, "cumul": 0, "status": "IterationLimit"}
 
+    def _staged(self, t):
+        """gloo cannot move device tensors: stage through the host (debug / no-RCCL fallback)"""
+        return self.dist.get_backend() == "gloo" and getattr(t, "is_cuda", False)
+
     def _exchange(self, send, recv, send_counts, recv_counts):
         ns, nr = sum(send_counts), sum(recv_counts)
         if self.dist.get_world_size() == 1:
             return
         # every rank must enter the collective, also with empty lists
-        self.dist.all_to_all_single(recv[:nr] if nr else recv[:0], send[:ns] if ns else send[:0],
-                                    output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts))
+        s, r = send[:ns], recv[:nr]
+        if self._staged(send):
+            s_h = s.cpu()
+            r_h = r.cpu()
+            self.dist.all_to_all_single(r_h, s_h, output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts))
+            r.copy_(r_h)
+        else:
+            self.dist.all_to_all_single(r, s, output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts))
+
+    def _all_reduce(self, t):
+        if self.dist.get_world_size() == 1:
+            return
+        if self._staged(t):
+            t_h = t.cpu()
+            self.dist.all_reduce(t_h)
+            t.copy_(t_h)
+        else:
+            self.dist.all_reduce(t)
 
     def inner_iteration(self, major_iter, beta):
         be, p = self.be, self.part
@@ -331,8 +351,7 @@ class DistributedAcopf:
         self._exchange(self.buf_send_v, self.buf_recv_v, p.plan_send_v[2], p.plan_recv_v[2])
         be.unpack(3, self.buf_recv_v)
         sums = be.update_zl_partial(beta)
-        if self.dist.get_world_size() > 1:
-            self.dist.all_reduce(sums)
+        self._all_reduce(sums)
         be.ctrl_step()
 
     def run_inner(self, outer, max_inner, beta, batch=8):
@@ -353,8 +372,7 @@ class DistributedAcopf:
 
     def norm_z(self):
         sums = self.be.sumsq_z_partial()
-        if self.dist.get_world_size() > 1:
-            self.dist.all_reduce(sums)
+        self._all_reduce(sums)
         return math.sqrt(float(sums.cpu()[2]))
 
     def solve(self):

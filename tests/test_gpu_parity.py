@@ -415,3 +415,19 @@ def test_results_do_not_depend_on_lane_assignment(pkg, syn):
         assert np.array_equal(o[2], outs[0][2]) and np.array_equal(o[3], outs[0][3])
     with pytest.raises(pkg.ExaAdmmError):
         mod.set_branch_lane_order(np.zeros(g["nline"], dtype=np.int32))   # not a permutation
+
+
+def test_two_processes_sharing_the_gpu_reproduce_single_handle():
+    """The N>1 code path with real processes: two ranks (torch.distributed.run, gloo with host-staged
+    collectives, because RCCL refuses two ranks on one device) each drive their partition through
+    HipBackend + DistributedAcopf.solve(); rank 0 compares with the single-handle solve."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "scripts", "dist_two_ranks_one_gpu.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-2000:]
+    line = [l for l in out.splitlines() if l.startswith("two ranks on one GPU")]
+    assert line and line[0].endswith("-> OK"), out[-2000:]

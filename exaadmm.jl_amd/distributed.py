@@ -247,7 +247,8 @@ class HipBackend:
         self.torch.cuda.synchronize(self.dev)
         return self.mod.download(name)
 
-    def set_params_from(self, par):
+    def set_check_every(self, k):
+        self.env.params.check_every = int(k)
         self.mod.sync_params()
 
     def ctrl_begin(self, outer, max_inner, beta):
@@ -300,8 +301,13 @@ class DistributedAcopf:
     """admm_two_level over P partitions.  `dist` is torch.distributed (initialised by the caller);
     `backend` implements the HipBackend interface."""
 
-    def __init__(self, part, backend, dist, global_state, params):
+    def __init__(self, part, backend, dist, global_state, params, check_every=1):
         self.part, self.be, self.dist = part, backend, dist
+        # check_every = 1: the reference's per-iteration break test (default).  k > 1 is an explicit
+        # opt-in relaxation: the residual all-reduce (and the test) only happen every k-th inner
+        # iteration, the loop may run up to k-1 iterations longer than the reference's.
+        self.check_every = max(1, int(check_every))
+        backend.set_check_every(self.check_every)
         self.par = params            # dict: initial_beta, inc_c, theta, outer_eps, outer_iterlim, inner_iterlim, MAX_MULTIPLIER
         for name in ("v_curr", "rho"):
             backend.upload(name, part.slice_global(global_state[name]))
@@ -340,7 +346,7 @@ class DistributedAcopf:
         else:
             self.dist.all_reduce(t)
 
-    def inner_iteration(self, major_iter, beta):
+    def inner_iteration(self, major_iter, beta, max_inner=None):
         be, p = self.be, self.part
         be.update_x(major_iter)
         be.pack(0, self.buf_send_uzl)
@@ -351,7 +357,8 @@ class DistributedAcopf:
         self._exchange(self.buf_send_v, self.buf_recv_v, p.plan_send_v[2], p.plan_recv_v[2])
         be.unpack(3, self.buf_recv_v)
         sums = be.update_zl_partial(beta)
-        self._all_reduce(sums)
+        if self.check_every == 1 or major_iter % self.check_every == 0 or major_iter == max_inner:
+            self._all_reduce(sums)      # otherwise the (untested) local sums are only stored
         be.ctrl_step()
 
     def run_inner(self, outer, max_inner, beta, batch=8):
@@ -364,7 +371,7 @@ class DistributedAcopf:
         while enq < max_inner and not done:
             nb = min(batch, max_inner - enq)
             for i in range(nb):
-                self.inner_iteration(enq + i + 1, beta)   # major_iter is re-derived on the device when armed
+                self.inner_iteration(enq + i + 1, beta, max_inner)   # major_iter is re-derived on the device when armed
             enq += nb
             done, inner, res = be.ctrl_read()
         be.ctrl_end()

@@ -24,9 +24,13 @@ class OracleBackend:
         self.cg_native.nline = part.n_native
         self.sums = torch.zeros(4, dtype=torch.float64)
         self.ctrl = None
+        self.check_every = 1
         self.plans = (part.plan_send_uzl, part.plan_recv_uzl, part.plan_send_v, part.plan_recv_v)
 
     # -- plumbing
+    def set_check_every(self, k):
+        self.check_every = int(k)
+
     def new_buffer(self, n):
         return torch.zeros(max(int(n), 1), dtype=torch.float64)
 
@@ -50,7 +54,8 @@ class OracleBackend:
             return
         c["res"] = np.sqrt(self.sums.numpy().copy())
         c["inner"] += 1
-        if c["res"][0] <= c["eps_pri"] or c["inner"] >= c["max_inner"]:
+        test = self.check_every <= 1 or c["inner"] % self.check_every == 0
+        if (test and c["res"][0] <= c["eps_pri"]) or c["inner"] >= c["max_inner"]:
             c["done"] = True
 
     def ctrl_read(self):

@@ -26,7 +26,7 @@ RHO = (4e2, 4e4)
 PAR = dict(outer_iterlim=2, inner_iterlim=25)
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, check_every=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -40,7 +40,7 @@ def _worker(rank, world, port, outdir):
         be = OracleBackend(part, *RHO)
         par = dict(dm.DEFAULT_PAR)
         par.update(PAR)
-        model = dm.DistributedAcopf(part, be, dist, st, par)
+        model = dm.DistributedAcopf(part, be, dist, st, par, check_every=check_every)
         info = model.solve()
         u = model.gather_owned("u_curr")
         v = model.gather_owned("v_curr")
@@ -104,3 +104,15 @@ def test_bfs_order_is_a_permutation():
     grid = syn.synthetic_grid(5, 80, 50, seed=2, locality=6)
     order = dm.bfs_bus_order(grid)
     assert sorted(order.tolist()) == list(range(50))
+
+
+def test_relaxed_check_every_runs_at_most_k_minus_1_iterations_longer(tmp_path, oracle):
+    """opt-in relaxation: residual all-reduce + break test every 4th inner iteration"""
+    syn = exaadmm_loader.load_submodule("synthetic")
+    grid = syn.synthetic_grid(GRID["ngen"], GRID["nline"], GRID["nbus"], seed=GRID["seed"], locality=GRID["locality"])
+    ref = oracle.solve_acopf("x", grid=grid, rho_pq=RHO[0], rho_va=RHO[1], **PAR)
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), 4), nprocs=2, join=True)
+    out = np.load(os.path.join(str(tmp_path), "out.npz"))
+    assert int(out["outer"]) == ref.info.outer
+    assert ref.info.cumul <= int(out["cumul"]) <= ref.info.cumul + 3 * ref.info.outer
+    assert np.isfinite(out["u"]).all() and np.abs(out["u"] - ref.sol["u_curr"]).max() < 0.5

@@ -50,9 +50,18 @@ def synthetic_grid(ngen, nline, nbus, seed=0, tight_factor=0.99, locality=64, fe
     r = rng.uniform(1e-3, 3e-2, nline)
     x = rng.uniform(1e-2, 2e-1, nline)
     bc = rng.uniform(0.0, 0.3 if not feasible else 0.06, nline)
+    # ~12 % of the branches are transformers (off-nominal tap, no line charging), a few of them
+    # phase shifters -- as in the pegase / ACTIVSg cases; admittances as utils/opfdata.jl:428-447
+    is_tr = rng.random(nline) < 0.12
+    ratio = np.where(is_tr, rng.uniform(0.94, 1.06, nline), 1.0)
+    shift = np.where(is_tr & (rng.random(nline) < 0.1), rng.uniform(-5.0, 5.0, nline), 0.0)
+    bc = np.where(is_tr, 0.0, bc)
+    tap = ratio * np.exp(1j * shift * np.pi / 180.0)
     Ys = 1.0 / (r + 1j * x)
     Ytt = Ys + 1j * bc / 2
-    Yff, Yft, Ytf = Ytt, -Ys, -Ys
+    Yff = Ytt / (tap * np.conj(tap))
+    Yft = -Ys / np.conj(tap)
+    Ytf = -Ys / tap
     unlimited = rng.random(nline) < 0.3
     rate = np.where(unlimited, 0.0, rng.uniform(100.0, 900.0, nline))
 
@@ -106,7 +115,10 @@ def synthetic_grid(ngen, nline, nbus, seed=0, tight_factor=0.99, locality=64, fe
     g["rateA"] = np.where(rate == 0.0, 1e3, tight_factor * (rate / M) ** 2)
     g["brBusIdx"] = np.stack([fr, to], 1).ravel()
     g["Pd"], g["Qd"], g["Vmin"], g["Vmax"] = Pd, Qd, Vmin, Vmax
-    g["YshR"], g["YshI"] = np.zeros(nbus), np.zeros(nbus)
+    # bus shunts on ~8 % of the buses (MW / MVAr at 1 p.u., divided by baseMVA: opfdata.jl:453-456)
+    has_sh = rng.random(nbus) < 0.08
+    g["YshR"] = np.where(has_sh, rng.uniform(0.0, 5.0, nbus), 0.0) / M
+    g["YshI"] = np.where(has_sh, rng.uniform(-20.0, 20.0, nbus), 0.0) / M
 
     def csr(owner, n):
         order = np.argsort(owner, kind="stable").astype(np.int64)

@@ -121,3 +121,37 @@ def test_dead_reference_options_are_rejected(pkg):
         pkg.AdmmEnv(CASE9, 4e2, 4e4, use_linelimit=False)
     with pytest.raises(pkg.ExaAdmmError, match="use_projection"):
         pkg.AdmmEnv(CASE9, 4e2, 4e4, use_projection=True)
+
+
+def test_loader_taps_phase_shifters_shunts_inf_limits(pkg, oracle, tmp_path):
+    """admittances with off-nominal taps and phase shifts, bus shunts, Inf generator limits
+    (parse_matpower.jl:137-142, opfdata.jl:199-206,428-456): native loader == numpy restatement"""
+    src = open(CASE9).read()
+    src = src.replace("4\t5\t0.017\t0.092\t0.158\t250\t250\t250\t0\t0\t1", "4\t5\t0.017\t0.092\t0.158\t250\t250\t250\t0.97\t0\t1")
+    src = src.replace("6\t7\t0.0119\t0.1008\t0.209\t150\t150\t150\t0\t0\t1", "6\t7\t0.0119\t0.1008\t0.209\t150\t150\t150\t1.03\t-3.5\t1")
+    src = src.replace("5\t1\t90\t30\t0\t0\t1", "5\t1\t90\t30\t2.5\t-19\t1")
+    src = src.replace("2\t163\t6.54\t300\t-300\t1.025\t100\t1\t300\t10", "2\t163\t6.54\tInf\t-Inf\t1.025\t100\t1\tInf\t10")
+    p = tmp_path / "c.m"
+    p.write_text(src)
+    a = pkg.opf_loaddata(str(p))
+    b = oracle.grid_from_matpower(str(p))
+    for k in pkg.Grid._F64 + pkg.Grid._BUS:
+        assert np.allclose(a[k], b[k], rtol=1e-14, atol=0), k
+    assert a["YffR"][1] != a["YttR"][1] and a["YftI"][4] != a["YtfI"][4]       # tap / phase shift took effect
+    assert a["YshR"][4] == 0.025 and a["YshI"][4] == -0.19
+    assert a["qgmax"][1] == 999.99 and a["qgmin"][1] == -999.99 and a["pgmax"][1] == 999.99
+
+
+def test_loader_pglib_format_has_ten_generator_columns(pkg, oracle, tmp_path):
+    src = open(CASE9).read()
+    lines = []
+    for ln in src.splitlines():
+        t = ln.split("\t")
+        if len(t) >= 22 and t[0] == "" and t[8] in ("1",) and t[7] == "100":   # a generator row: keep 10 columns
+            ln = "\t".join(t[:11]) + ";"
+        lines.append(ln)
+    p = tmp_path / "pglib.m"
+    p.write_text("\n".join(lines))
+    a = pkg.opf_loaddata(str(p), case_format="pglib")
+    b = oracle.grid_from_matpower(CASE9)
+    assert a["ngen"] == 3 and np.allclose(a["pgmax"], b["pgmax"]) and np.allclose(a["c2"], b["c2"])

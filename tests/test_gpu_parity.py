@@ -431,3 +431,18 @@ def test_two_processes_sharing_the_gpu_reproduce_single_handle():
     assert r.returncode == 0, out[-2000:]
     line = [l for l in out.splitlines() if l.startswith("two ranks on one GPU")]
     assert line and line[0].endswith("-> OK"), out[-2000:]
+
+
+def _find_case(name):
+    for d in (os.environ.get("MATPOWER_DATA", ""), GOLDEN):
+        if d and os.path.exists(os.path.join(d, name)):
+            return os.path.join(d, name)
+    return None
+
+
+@pytest.mark.skipif(_find_case("case118.m") is None, reason="case118.m not available offline (ExaData artifact)")
+def test_case118_full_solve_anchor_gpu(pkg):
+    a = G["solve_case118"]
+    env, mod = pkg.solve_acopf(_find_case("case118.m"), outer_iterlim=25, rho_pq=4e2, rho_va=4e4, outer_eps=2e-5, verbose=0)
+    assert mod.info.status == "Solved" and mod.info.outer == a["outer"] and mod.info.cumul == a["cumul"]
+    assert abs(mod.info.objval - a["objval"]) <= 1e-6 * a["objval"]

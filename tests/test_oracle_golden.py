@@ -123,3 +123,19 @@ def test_openmp_oracle_matches_serial(oracle):
     b = oracle.solve_acopf(CASE9, outer_iterlim=3, inner_iterlim=30, nthreads=4)
     assert a.info.cumul == b.info.cumul
     assert np.array_equal(a.sol["u_curr"], b.sol["u_curr"])
+
+
+def _find_case(name):
+    for d in (os.environ.get("MATPOWER_DATA", ""), GOLDEN, os.path.join(os.path.dirname(GOLDEN), "..", "data")):
+        if d and os.path.exists(os.path.join(d, name)):
+            return os.path.join(d, name)
+    return None
+
+
+@pytest.mark.skipif(_find_case("case118.m") is None, reason="case118.m not available offline (ExaData artifact)")
+def test_case118_full_solve_anchor(oracle):
+    """second anchor of the reference test (acopf_update_cpu.jl:174-179); runs when the file is supplied"""
+    a = G["solve_case118"]
+    m = oracle.solve_acopf(_find_case("case118.m"), outer_iterlim=25, rho_pq=4e2, rho_va=4e4, outer_eps=2e-5)
+    assert m.info.status == 1 and m.info.outer == a["outer"] and m.info.cumul == a["cumul"]
+    assert abs(m.info.objval - a["objval"]) <= 1e-6 * a["objval"]

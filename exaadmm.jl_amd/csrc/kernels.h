@@ -73,14 +73,20 @@ __global__ void k_generator(Dev d, double baseMVA, const Ctrl* ctrl)
 
 // ---------------------------------------------------------------- branch
 // auglag_linelimit_two_level_alternative (acopf_auglag_linelimit_kernel_gpu.jl:1-151):
-// one lane per branch, 64 branches per wavefront.  Per lane, the 32 read-only problem
-// constants (l, rho, v-z, Y), the packed 6x6 Hessian and its Cholesky factor (21 doubles
-// each) are staged in LDS as [entry][lane] planes (74 x 64 doubles = 37 KB per wavefront,
-// every access conflict-free and with a compile-time offset); vectors and scalars of the
-// solver stay in registers.  (The reference keeps 1728 B of shared memory per BRANCH and one
-// 32-thread block per branch.)
+// one lane per branch, 64 branches per wavefront.  Per lane, the 32 read-only problem constants
+// (l, rho, v-z, Y) are staged in LDS as [entry][lane] planes (16 KB per wavefront, every access
+// conflict-free and with a compile-time offset); the packed 6x6 Hessian, its Cholesky factor and
+// all vectors / scalars of the solver are registers.  (The reference keeps 1728 B of shared memory
+// per BRANCH and one 32-thread block per branch.)  -DEXA_A_IN_LDS / -DEXA_L_IN_LDS move the
+// matrices to LDS planes as well (6 % slower; kept for bisecting compiler trouble).
 constexpr int BR_LDS_CONST = 32, BR_LDS_MAT = 21;
+#if defined(EXA_A_IN_LDS) && defined(EXA_L_IN_LDS)
 constexpr int BR_LDS_DOUBLES = BR_LDS_CONST + 2 * BR_LDS_MAT;
+#elif defined(EXA_A_IN_LDS) || defined(EXA_L_IN_LDS)
+constexpr int BR_LDS_DOUBLES = BR_LDS_CONST + BR_LDS_MAT;
+#else
+constexpr int BR_LDS_DOUBLES = BR_LDS_CONST;
+#endif
 
 // The Dev block is read through a pointer (not by-value kernel arguments): its ~40 pointers would
 // otherwise sit in SGPRs across the whole solver and spill.
@@ -127,15 +133,15 @@ __global__ void __launch_bounds__(BR_BLOCK) k_branch(const Dev* __restrict__ dp,
     bd.ls2 = d.ls2[b];
     bd.mu = (major_iter == 1) ? 10.0 : d.mu[b];
     bd.scale = scale;
-#if defined(EXA_A_IN_REGS)
-    SymMat<6> A;
-#else
+#if defined(EXA_A_IN_LDS)
     SymRef<6, BR_BLOCK> A{my + BR_LDS_CONST * BR_BLOCK};
-#endif
-#if defined(EXA_L_IN_REGS)
-    SymMat<6> L;
 #else
-    SymRef<6, BR_BLOCK> L{my + (BR_LDS_CONST + BR_LDS_MAT) * BR_BLOCK};
+    SymMat<6> A;
+#endif
+#if defined(EXA_L_IN_LDS)
+    SymRef<6, BR_BLOCK> L{my + (BR_LDS_DOUBLES - BR_LDS_MAT) * BR_BLOCK};
+#else
+    SymMat<6> L;
 #endif
 
     double x[6], xl[6], xu[6], phi[4];

@@ -117,6 +117,20 @@ __global__ void __launch_bounds__(BR_BLOCK) k_branch(const Dev* __restrict__ dp,
     double* my = lds + threadIdx.x;
 
     double ub[8], bnd[8];
+#if defined(EXA_CONST_IN_REGS)
+    BranchData bd;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int e = base + k * Lp;
+        ub[k] = d.u[e];
+        bd.lam_[k] = d.l[e];
+        bd.rho_[k] = d.rho[e];
+        bd.xt_[k] = d.v[e] - d.z[e];
+        bd.Y_[k] = d.Y[b + k * Lp];
+        bnd[k] = d.bnd[b + k * Lp];
+    }
+    (void)my;
+#else
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         const int e = base + k * Lp;
@@ -129,6 +143,7 @@ __global__ void __launch_bounds__(BR_BLOCK) k_branch(const Dev* __restrict__ dp,
     }
     BranchDataRef<BR_BLOCK> bd;
     bd.p = my;
+#endif
     bd.ls1 = d.ls1[b];
     bd.ls2 = d.ls2[b];
     bd.mu = (major_iter == 1) ? 10.0 : d.mu[b];

@@ -86,6 +86,10 @@ struct exaadmm_handle {
     std::vector<int> perm;
     unsigned char* d_owned = nullptr;
     int* d_lane_order = nullptr;
+    // hipGraph of one batch of fused inner iterations (exaadmm_run_inner); rebuilt when anything
+    // baked into its kernel arguments changes (parameters, active counts, masks, lane order)
+    hipGraphExec_t batch_graph = nullptr;
+    bool use_graph = true;
     HaloSlot halo[8];
     bool residual_vectors_valid = false;
     bool async_mode = false;
@@ -183,8 +187,17 @@ extern "C" void exaadmm_default_params(exaadmm_params* p)
     p->check_every = 1;
 }
 
+static void invalidate_graph(exaadmm_handle* h)
+{
+    if (h->batch_graph) {
+        (void)hipGraphExecDestroy(h->batch_graph);
+        h->batch_graph = nullptr;
+    }
+}
+
 static void fill_branch_options(exaadmm_handle* h)
 {
+    invalidate_graph(h);
     BranchOptions& o = h->bo;
     o.max_auglag = h->par.max_auglag;
     o.mu_max = h->par.mu_max;
@@ -327,6 +340,7 @@ extern "C" int exaadmm_create(const exaadmm_grid* g, const exaadmm_params* p, in
     {
         const char* e = getenv("EXAADMM_BUS_KERNEL");
         h->bus_lane_kernel = (e != nullptr && strcmp(e, "lane") == 0);
+        h->use_graph = (getenv("EXAADMM_NO_GRAPH") == nullptr);
     }
     TRY(upload_mupow_table());
 
@@ -458,6 +472,7 @@ extern "C" int exaadmm_destroy(exaadmm_handle* h)
     }
     if (h->d_owned) (void)hipFree(h->d_owned);
     if (h->d_lane_order) (void)hipFree(h->d_lane_order);
+    if (h->batch_graph) (void)hipGraphExecDestroy(h->batch_graph);
     if (h->h_ctrl) (void)hipHostFree(h->h_ctrl);
     if (h->h_sums) (void)hipHostFree(h->h_sums);
     for (auto e : h->ev) (void)hipEventDestroy(e);
@@ -669,7 +684,7 @@ static void launch_gen(exaadmm_handle* h, const Ctrl* c)
 }
 static void launch_branch(exaadmm_handle* h, int major_iter, const Ctrl* c, bool with_generators = false)
 {
-    if (h->dev_dirty) {  // rare: after create / set_active / set_owned_mask
+    if (h->dev_dirty) {  // rare: after create / set_active / set_owned_mask / lane order
         (void)hipMemcpyAsync(h->d_dev, &h->d, sizeof(Dev), hipMemcpyHostToDevice, h->stream);
         h->dev_dirty = false;
     }
@@ -883,6 +898,7 @@ extern "C" int exaadmm_set_branch_lane_order(exaadmm_handle* h, const int32_t* o
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->dev_dirty = true;
+    invalidate_graph(h);
     if (!order) {
         h->d.lane_order = nullptr;
         return EXAADMM_OK;
@@ -944,25 +960,49 @@ extern "C" int exaadmm_run_inner(exaadmm_handle* h, int outer, int max_inner, do
     int enq = 0;
     for (auto& e : h->tev)
         if (!e) HIPCHK(hipEventCreate(&e));
-    int inner_before = 0;
+    // Full batches after the first are replayed from a hipGraph (32 kernel nodes); the first batch
+    // of every call is launched directly with HIP events around its first iteration, which feed
+    // the sampled step times (mod.info.time_*_update of the reference).  Capturing needs a real
+    // stream: with the caller's null stream (exaadmm_set_stream(NULL)) launches stay direct.
+    const bool graph_ok = h->use_graph && h->stream == h->own_stream;
+    if (h->dev_dirty) {   // flush the Dev copy outside any capture; it is baked into the graph
+        invalidate_graph(h);
+        HIPCHK(hipMemcpyAsync(h->d_dev, &h->d, sizeof(Dev), hipMemcpyHostToDevice, h->stream));
+        h->dev_dirty = false;
+    }
+    float ms_sample[3] = {0.f, 0.f, 0.f};
+    bool first = true;
     while (enq < max_inner) {
         const int nb = std::min(batch, max_inner - enq);
-        // the first iteration of every batch is timed with events; its step times stand for the
-        // iterations the batch executed (mod.info.time_*_update of the reference, sampled)
-        for (int i = 0; i < nb; i++) enqueue_iteration(h, h->d_ctrl, i == 0);
+        if (!first && graph_ok && nb == batch) {
+            if (!h->batch_graph) {
+                hipGraph_t g = nullptr;
+                HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+                for (int i = 0; i < batch; i++) enqueue_iteration(h, h->d_ctrl, false);
+                HIPCHK(hipStreamEndCapture(h->stream, &g));
+                hipError_t e = hipGraphInstantiate(&h->batch_graph, g, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(g);
+                if (e != hipSuccess) {
+                    set_err("hipGraphInstantiate failed: %s", hipGetErrorString(e));
+                    return EXAADMM_ERR_HIP;
+                }
+            }
+            HIPCHK(hipGraphLaunch(h->batch_graph, h->stream));
+        } else {
+            for (int i = 0; i < nb; i++) enqueue_iteration(h, h->d_ctrl, first && i == 0);
+        }
         enq += nb;
         HIPCHK(hipMemcpyAsync(hc, h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
         int rc = sync_check(h, true);
         if (rc) return rc;
-        const int executed = hc->inner - inner_before;
-        inner_before = hc->inner;
-        if (executed > 0) {
-            float ms;
+        if (first) {
             for (int q = 0; q < 3; q++)
-                if (hipEventElapsedTime(&ms, h->tev[q], h->tev[q + 1]) == hipSuccess) h->acc_ms[q] += (double)ms * executed;
+                if (hipEventElapsedTime(&ms_sample[q], h->tev[q], h->tev[q + 1]) != hipSuccess) ms_sample[q] = 0.f;
+            first = false;
         }
         if (hc->done) break;
     }
+    for (int q = 0; q < 3; q++) h->acc_ms[q] += (double)ms_sample[q] * hc->inner;
     if (inner_done) *inner_done = hc->inner;
     if (out)
         for (int j = 0; j < 4; j++) out[j] = hc->res[j];
@@ -1127,6 +1167,7 @@ extern "C" int exaadmm_set_active(exaadmm_handle* h, int64_t nbranch, int64_t nb
     h->d.La = (int)nbranch;
     h->d.Ba = (int)nbus;
     h->dev_dirty = true;
+    invalidate_graph(h);
     return EXAADMM_OK;
 }
 
@@ -1189,6 +1230,7 @@ extern "C" int exaadmm_set_owned_mask(exaadmm_handle* h, const uint8_t* mask, in
     REQUIRE(h, "null handle");
     HIPCHK(hipSetDevice(h->device));
     h->dev_dirty = true;
+    invalidate_graph(h);
     if (!mask) {
         h->d.owned = nullptr;
         return EXAADMM_OK;

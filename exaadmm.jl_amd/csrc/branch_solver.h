@@ -79,11 +79,17 @@ struct FlowTrig {
     double vi2, vj2, vv, E0, F0, E2, F2;
 };
 
-template <class D>
-EXA_HD void flow_trig(const D& d, const double (&x)[6], FlowTrig& t)
+// sin / cos of the angle difference: the only transcendental of the branch model.  Evaluated once
+// per point (together with the flows) and carried with the point: g and H at an accepted trial
+// point reuse the values its objective evaluation produced.
+EXA_HD void angle_sincos(const double (&x)[6], double& sn, double& cs)
 {
-    double sn, cs;
     sincos(x[2] - x[3], &sn, &cs);
+}
+
+template <class D>
+EXA_HD void flow_trig(const D& d, const double (&x)[6], double sn, double cs, FlowTrig& t)
+{
     t.vi2 = x[0] * x[0];
     t.vj2 = x[1] * x[1];
     t.vv = x[0] * x[1];
@@ -103,11 +109,13 @@ EXA_HD void flows_from_trig(const D& d, const FlowTrig& t, double (&phi)[4])
     phi[3] = -d.Y(5) * t.vj2 + t.vv * t.F2;
 }
 
+// flows at x; sc[0] = sin, sc[1] = cos of the angle difference are returned for later g/H evaluations at x
 template <class D>
-EXA_HD void branch_flows(const D& d, const double (&x)[6], double (&phi)[4])
+EXA_HD void branch_flows(const D& d, const double (&x)[6], double (&phi)[4], double (&sc)[2])
 {
     FlowTrig t;
-    flow_trig(d, x, t);
+    angle_sincos(x, sc[0], sc[1]);
+    flow_trig(d, x, sc[0], sc[1], t);
     flows_from_trig(d, t, phi);
 }
 
@@ -132,73 +140,97 @@ EXA_HD double objective_from_flows(const D& d, const double (&x)[6], const FlowT
     return f * d.scale;
 }
 
+// objective at x; also returns the flows and sin/cos at x
 template <class D>
-EXA_BIG double branch_f(const D& d, const double (&x)[6], double (&phi)[4])
+EXA_BIG double branch_f(const D& d, const double (&x)[6], double (&phi)[4], double (&sc)[2])
 {
     FlowTrig t;
-    flow_trig(d, x, t);
+    angle_sincos(x, sc[0], sc[1]);
+    flow_trig(d, x, sc[0], sc[1], t);
     flows_from_trig(d, t, phi);
     return objective_from_flows(d, x, t, phi);
 }
 
-// objective, gradient and packed Hessian at x
-template <class D, class MA>
-EXA_BIG double branch_fgh(const D& d, const double (&x)[6], double (&g)[6], MA& A, double (&phi)[4])
+// objective at x from flows and sin/cos already known at x (same operations as branch_f after the
+// transcendental, hence the same bits): used when only the multipliers / penalty changed
+template <class D>
+EXA_HD double branch_f_known(const D& d, const double (&x)[6], const double (&phi)[4], const double (&sc)[2])
 {
     FlowTrig t;
-    flow_trig(d, x, t);
-    flows_from_trig(d, t, phi);
-    const double f = objective_from_flows(d, x, t, phi);
+    flow_trig(d, x, sc[0], sc[1], t);
+    return objective_from_flows(d, x, t, phi);
+}
 
+// Intermediates of the gradient that the Hessian reuses (all SSA values after inlining).
+struct GradParts {
+    FlowTrig t;
+    double E[4], F[4], J[4][3], w[4], r[4], d1[3], d2[3], wvi, wvj;
+};
+
+// gradient at x from flows and sin/cos known at x
+template <class D>
+EXA_BIG void branch_g(const D& d, const double (&x)[6], const double (&phi)[4], const double (&scs)[2],
+                      double (&g)[6], GradParts& q)
+{
+    flow_trig(d, x, scs[0], scs[1], q.t);
+    const FlowTrig& t = q.t;
     const double vi = x[0], vj = x[1], vv = t.vv, sc = d.scale, mu = d.mu;
-    const double E[4] = {t.E0, -t.F0, t.E2, t.F2};
-    const double F[4] = {t.F0, t.E0, t.F2, -t.E2};
+    q.E[0] = t.E0; q.E[1] = -t.F0; q.E[2] = t.E2; q.E[3] = t.F2;
+    q.F[0] = t.F0; q.F[1] = t.E0; q.F[2] = t.F2; q.F[3] = -t.E2;
     const double a2[4] = {2 * d.Y(0), -2 * d.Y(1), 0.0, 0.0};  // d2phi/dvi2
     const double b2[4] = {0.0, 0.0, 2 * d.Y(4), -2 * d.Y(5)};  // d2phi/dvj2
 
     // Jacobian of the flows in (vi, vj, th)
-    double J[4][3];
     EXA_UNROLL
     for (int k = 0; k < 4; k++) {
-        J[k][0] = a2[k] * vi + vj * E[k];
-        J[k][1] = b2[k] * vj + vi * E[k];
-        J[k][2] = vv * F[k];
+        q.J[k][0] = a2[k] * vi + vj * q.E[k];
+        q.J[k][1] = b2[k] * vj + vi * q.E[k];
+        q.J[k][2] = vv * q.F[k];
     }
     const double c1 = phi[0] * phi[0] + phi[1] * phi[1] + x[4];
     const double c2 = phi[2] * phi[2] + phi[3] * phi[3] + x[5];
     const double m1 = d.ls1 + mu * c1;
     const double m2 = d.ls2 + mu * c2;
 
-    double w[4], r[4];
     EXA_UNROLL
     for (int k = 0; k < 4; k++) {
         const double mk = (k < 2) ? m1 : m2;
-        w[k] = d.lam(k) + d.rho(k) * (phi[k] - d.xt(k)) + 2 * phi[k] * mk;
-        r[k] = d.rho(k) + 2 * mk;
+        q.w[k] = d.lam(k) + d.rho(k) * (phi[k] - d.xt(k)) + 2 * phi[k] * mk;
+        q.r[k] = d.rho(k) + 2 * mk;
     }
-    double d1[3], d2[3], gr[3];
+    double gr[3];
     EXA_UNROLL
     for (int i = 0; i < 3; i++) {
-        d1[i] = 2 * (phi[0] * J[0][i] + phi[1] * J[1][i]);
-        d2[i] = 2 * (phi[2] * J[2][i] + phi[3] * J[3][i]);
-        gr[i] = w[0] * J[0][i] + w[1] * J[1][i] + w[2] * J[2][i] + w[3] * J[3][i];
+        q.d1[i] = 2 * (phi[0] * q.J[0][i] + phi[1] * q.J[1][i]);
+        q.d2[i] = 2 * (phi[2] * q.J[2][i] + phi[3] * q.J[3][i]);
+        gr[i] = q.w[0] * q.J[0][i] + q.w[1] * q.J[1][i] + q.w[2] * q.J[2][i] + q.w[3] * q.J[3][i];
     }
-    const double wvi = d.lam(4) + d.rho(4) * (t.vi2 - d.xt(4));
-    const double wvj = d.lam(5) + d.rho(5) * (t.vj2 - d.xt(5));
+    q.wvi = d.lam(4) + d.rho(4) * (t.vi2 - d.xt(4));
+    q.wvj = d.lam(5) + d.rho(5) * (t.vj2 - d.xt(5));
 
-    g[0] = sc * (gr[0] + wvi * (2 * vi));
-    g[1] = sc * (gr[1] + wvj * (2 * vj));
+    g[0] = sc * (gr[0] + q.wvi * (2 * vi));
+    g[1] = sc * (gr[1] + q.wvj * (2 * vj));
     g[2] = sc * (gr[2] + (d.lam(6) + d.rho(6) * (x[2] - d.xt(6))));
     g[3] = sc * (-gr[2] + (d.lam(7) + d.rho(7) * (x[3] - d.xt(7))));
     g[4] = sc * m1;
     g[5] = sc * m2;
+}
 
+// packed Hessian at x from the gradient's intermediates
+template <class D, class MA>
+EXA_BIG void branch_h(const D& d, const double (&x)[6], const GradParts& q, MA& A)
+{
+    const FlowTrig& t = q.t;
+    const double vi = x[0], vj = x[1], vv = t.vv, sc = d.scale, mu = d.mu;
+    const double* w = q.w;
+    const double a2[4] = {2 * d.Y(0), -2 * d.Y(1), 0.0, 0.0};
+    const double b2[4] = {0.0, 0.0, 2 * d.Y(4), -2 * d.Y(5)};
     // reduced 3x3 Hessian in (vi, vj, th): sum_k w_k Hess(phi_k) + sum_k r_k J_k J_k' + mu (d1 d1' + d2 d2')
-    const double WE = w[0] * E[0] + w[1] * E[1] + w[2] * E[2] + w[3] * E[3];
-    const double WF = w[0] * F[0] + w[1] * F[1] + w[2] * F[2] + w[3] * F[3];
+    const double WE = w[0] * q.E[0] + w[1] * q.E[1] + w[2] * q.E[2] + w[3] * q.E[3];
+    const double WF = w[0] * q.F[0] + w[1] * q.F[1] + w[2] * q.F[2] + w[3] * q.F[3];
     double Hr[3][3];
-    Hr[0][0] = (w[0] * a2[0] + w[1] * a2[1]) + (2 * wvi + 4 * d.rho(4) * t.vi2);
-    Hr[1][1] = (w[2] * b2[2] + w[3] * b2[3]) + (2 * wvj + 4 * d.rho(5) * t.vj2);
+    Hr[0][0] = (w[0] * a2[0] + w[1] * a2[1]) + (2 * q.wvi + 4 * d.rho(4) * t.vi2);
+    Hr[1][1] = (w[2] * b2[2] + w[3] * b2[3]) + (2 * q.wvj + 4 * d.rho(5) * t.vj2);
     Hr[1][0] = WE;
     Hr[2][0] = vj * WF;
     Hr[2][1] = vi * WF;
@@ -209,8 +241,8 @@ EXA_BIG double branch_fgh(const D& d, const double (&x)[6], double (&g)[6], MA& 
         for (int j = 0; j <= i; j++) {
             double s = Hr[i][j];
             EXA_UNROLL
-            for (int k = 0; k < 4; k++) s += (r[k] * J[k][i]) * J[k][j];
-            s += mu * (d1[i] * d1[j] + d2[i] * d2[j]);
+            for (int k = 0; k < 4; k++) s += (q.r[k] * q.J[k][i]) * q.J[k][j];
+            s += mu * (q.d1[i] * q.d1[j] + q.d2[i] * q.d2[j]);
             Hr[i][j] = s;
         }
     }
@@ -225,17 +257,28 @@ EXA_BIG double branch_fgh(const D& d, const double (&x)[6], double (&g)[6], MA& 
     A.lo(3, 2) = -(sc * Hr[2][2]);
     A.lo(3, 3) = sc * (Hr[2][2] + d.rho(7));
     const double smu = sc * mu;
-    A.lo(4, 0) = smu * d1[0];
-    A.lo(4, 1) = smu * d1[1];
-    A.lo(4, 2) = smu * d1[2];
-    A.lo(4, 3) = -(smu * d1[2]);
+    A.lo(4, 0) = smu * q.d1[0];
+    A.lo(4, 1) = smu * q.d1[1];
+    A.lo(4, 2) = smu * q.d1[2];
+    A.lo(4, 3) = -(smu * q.d1[2]);
     A.lo(4, 4) = smu;
-    A.lo(5, 0) = smu * d2[0];
-    A.lo(5, 1) = smu * d2[1];
-    A.lo(5, 2) = smu * d2[2];
-    A.lo(5, 3) = -(smu * d2[2]);
+    A.lo(5, 0) = smu * q.d2[0];
+    A.lo(5, 1) = smu * q.d2[1];
+    A.lo(5, 2) = smu * q.d2[2];
+    A.lo(5, 3) = -(smu * q.d2[2]);
     A.lo(5, 4) = 0.0;
     A.lo(5, 5) = smu;
+}
+
+// objective, gradient and packed Hessian at x in one call (tests; the solver loop uses the pieces)
+template <class D, class MA>
+EXA_BIG double branch_fgh(const D& d, const double (&x)[6], double (&g)[6], MA& A, double (&phi)[4])
+{
+    double sc[2];
+    const double f = branch_f(d, x, phi, sc);
+    GradParts q;
+    branch_g(d, x, phi, sc, g, q);
+    branch_h(d, x, q, A);
     return f;
 }
 
@@ -246,7 +289,8 @@ EXA_BIG double branch_fgh(const D& d, const double (&x)[6], double (&g)[6], MA& 
 #endif
 
 struct BranchStats {
-    unsigned long long cyc[5];  // diagnostic build only: fgh, model step, f(trial), ratio test, auglag step
+    unsigned long long cyc[13];  // diagnostic build only: fgh, model step, f(trial), ratio test, auglag step, then TronState::pc[0..7]
+    unsigned long long* tl;     // diagnostic build only: per-wavefront timeline, (active lanes << 56 | clock) per tick
     int auglag_it;
     int minor_it;  // TRON minor iterations summed over the augmented-Lagrangian iterations
     int ticks;     // trips of the lane's solver loop
@@ -256,16 +300,23 @@ struct BranchStats {
 // d.mu must be initialised; d.ls1, d.ls2, d.mu are updated.  phi receives the flows at
 // the final x.  The two nested reference loops (auglag iterations, each a full TRON
 // reverse-communication loop) are flattened into one loop of "ticks": a tick refreshes
-// g, H when the previous tick moved x (or a new subproblem starts), then makes one
-// model step + ratio test.  Lanes of a wavefront therefore stay phase-aligned
+// g (and H, if the solve goes on) when the previous tick moved x or a new subproblem starts,
+// then makes one model step + ratio test.  Lanes of a wavefront therefore stay phase-aligned
 // whatever auglag/TRON iteration each of them is in.
+//
+// Work that the reference repeats and this loop does not (same operations on the same inputs, so
+// the same bits): sin/cos and the flows are evaluated once per point, by the objective evaluation
+// of the trial point, and carried with it (phi/scs accepted, phit/scst trial); f is recomputed only
+// when the multipliers changed (new subproblem), and the Hessian only when the projected-gradient
+// test did not end the TRON solve.
 template <class D, class MA, class ML>
 EXA_HD void branch_solve(D& d, const BranchOptions& o, const MuPowTable& pw, double (&x)[6], const double (&xl)[6],
                          const double (&xu)[6], MA& A, ML& L, double (&phi)[4], BranchStats& stats)
 {
     TronState<6> st;
     double g[6];
-    double phit[4];  // flows at the trial point; phi always holds the flows at the accepted x
+    double scs[2];             // sin, cos of the angle difference at the accepted x
+    double phit[4], scst[2];   // flows, sin/cos at the trial point
 
     double mu = d.mu;
     double eta = 1.0 / mu_pow(pw, mu, false);
@@ -274,19 +325,36 @@ EXA_HD void branch_solve(D& d, const BranchOptions& o, const MuPowTable& pw, dou
     const int hard_cap = o.max_auglag * (o.max_feval + o.max_minor + 2) + 8;
 
     EXA_UNROLL
-    for (int k = 0; k < 5; k++) stats.cyc[k] = 0;
+    for (int k = 0; k < 13; k++) stats.cyc[k] = 0;
+#if defined(EXA_PROFILE_PHASES)
+    EXA_UNROLL
+    for (int k = 0; k < 8; k++) st.pc[k] = 0;
+#endif
+    branch_flows(d, x, phi, scs);
     while (!done && ticks < hard_cap) {
         ticks++;
         int fin = TRON_RUN;
         unsigned long long t0 = EXA_TICK();
-        if (need_gh) {
+#if defined(EXA_PROFILE_PHASES) && defined(__HIP_DEVICE_COMPILE__)
+        const int n_active = (int)__popcll(__ballot(1));
+        if (stats.tl && ticks <= 127) stats.tl[ticks - 1] = (t0 & 0x00ffffffffffffffull) | ((unsigned long long)n_active << 56);
+        // phase counters only keep ticks in which this lane ran alone (true single-lane latency)
+        unsigned long long keep_c[5], keep_p[8];
+        EXA_UNROLL
+        for (int k = 0; k < 5; k++) keep_c[k] = stats.cyc[k];
+        EXA_UNROLL
+        for (int k = 0; k < 8; k++) keep_p[k] = st.pc[k];
+#endif
+        const bool refresh = need_gh;
+        GradParts gp;
+        if (refresh) {
             // ONE evaluation site for both cases (a second inlined copy would be executed one after
             // the other whenever a wavefront holds lanes of both kinds)
-            const double fx = branch_fgh(d, x, g, A, phi);
+            branch_g(d, x, phi, scs, g, gp);
             if (restart) {
                 // task START: f, g, H at x; delta0 = ||g||  (tron_linelimit_kernel.jl:66-106)
                 it++;
-                st.f = fx;
+                st.f = branch_f_known(d, x, phi, scs);
                 st.delta = nrm2<6>(g);
                 st.iter = 1;
                 st.alphac = 1.0;
@@ -304,29 +372,32 @@ EXA_HD void branch_solve(D& d, const BranchOptions& o, const MuPowTable& pw, dou
         unsigned long long t1 = EXA_TICK();
         stats.cyc[0] += t1 - t0;
         if (fin == TRON_RUN) {
+            if (refresh) branch_h(d, x, gp, A);
             tron_compute<6>(st, x, xl, xu, A, L, g, o.cgtol, 6);
             unsigned long long t2 = EXA_TICK();
             stats.cyc[1] += t2 - t1;
-            const double ftrial = branch_f(d, x, phit);
+            const double ftrial = branch_f(d, x, phit, scst);
             unsigned long long t3 = EXA_TICK();
             stats.cyc[2] += t3 - t2;
             t1 = t3;
             st.nfev++;
+            bool moved;
             if (st.nfev >= o.max_feval) {
                 fin = TRON_MAXFEVAL;  // search stops before the ratio test (tron_linelimit_kernel.jl:76-78)
-                EXA_UNROLL
-                for (int k = 0; k < 4; k++) phi[k] = phit[k];
+                moved = true;
             } else {
                 int task;
-                const bool success = tron_evaluate<6>(st, ftrial, x, g, o.frtol, o.fatol, o.fmin, task);
-                if (success) {
-                    EXA_UNROLL
-                    for (int k = 0; k < 4; k++) phi[k] = phit[k];
-                }
+                moved = tron_evaluate<6>(st, ftrial, x, g, o.frtol, o.fatol, o.fmin, task);
                 if (task != TRON_RUN)
                     fin = task;
                 else
-                    need_gh = success;
+                    need_gh = moved;
+            }
+            if (moved) {
+                EXA_UNROLL
+                for (int k = 0; k < 4; k++) phi[k] = phit[k];
+                scs[0] = scst[0];
+                scs[1] = scst[1];
             }
         }
         unsigned long long t4 = EXA_TICK();
@@ -362,7 +433,22 @@ EXA_HD void branch_solve(D& d, const BranchOptions& o, const MuPowTable& pw, dou
             }
         }
         stats.cyc[4] += EXA_TICK() - t4;
+#if defined(EXA_PROFILE_PHASES) && defined(__HIP_DEVICE_COMPILE__)
+        if (stats.tl && ticks <= 127) stats.tl[ticks] = EXA_TICK() & 0x00ffffffffffffffull;  // end mark, overwritten by the next tick
+        if (n_active != 1) {
+            EXA_UNROLL
+            for (int k = 0; k < 5; k++) stats.cyc[k] = keep_c[k];
+            EXA_UNROLL
+            for (int k = 0; k < 8; k++) st.pc[k] = keep_p[k];
+        } else {
+            st.pc[7] += 1;
+        }
+#endif
     }
+#if defined(EXA_PROFILE_PHASES)
+    EXA_UNROLL
+    for (int k = 0; k < 8; k++) stats.cyc[5 + k] = st.pc[k];
+#endif
     d.mu = mu;
     stats.auglag_it = it;
     stats.minor_it = minor_total;

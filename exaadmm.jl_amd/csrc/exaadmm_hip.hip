@@ -383,7 +383,9 @@ extern "C" int exaadmm_create(const exaadmm_grid* g, const exaadmm_params* p, in
         TRY(dev_alloc(h, &d.st_auglag, (size_t)h->Lp));
         TRY(dev_alloc(h, &d.st_minor, (size_t)h->Lp));
         TRY(dev_alloc(h, &d.st_ticks, (size_t)h->Lp));
-        TRY(dev_alloc(h, &d.st_cyc, (size_t)5 * h->Lp));
+        TRY(dev_alloc(h, &d.st_cyc, (size_t)13 * h->Lp));
+        TRY(dev_alloc(h, &d.st_tl, (size_t)2 * h->Lp));
+        (void)hipMemset(d.st_tl, 0, (size_t)2 * h->Lp * sizeof(unsigned long long));
         (void)hipMemset(d.st_auglag, 0, h->Lp * sizeof(int));
         (void)hipMemset(d.st_minor, 0, h->Lp * sizeof(int));
         (void)hipMemset(d.st_ticks, 0, h->Lp * sizeof(int));
@@ -920,10 +922,20 @@ extern "C" int exaadmm_set_branch_lane_order(exaadmm_handle* h, const int32_t* o
 // diagnostic builds only (-DEXA_PROFILE_PHASES): per-branch cycle counters of the solver phases
 extern "C" int exaadmm_debug_phase_cycles(exaadmm_handle* h, unsigned long long* out, int64_t n)
 {
-    REQUIRE(h && out && n == 5 * (int64_t)h->Lp, "buffer must hold 5 x Lp counters");
+    REQUIRE(h && out && n == 13 * (int64_t)h->Lp, "buffer must hold 13 x Lp counters");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(out, h->d.st_cyc, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return EXAADMM_OK;
+}
+
+extern "C" int exaadmm_debug_wave_timeline(exaadmm_handle* h, unsigned long long* out, int64_t n)
+{
+    REQUIRE(h && out && n == 2 * (int64_t)h->Lp, "buffer must hold 128 entries per wavefront (2 x Lp)");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(out, h->d.st_tl, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(h->d.st_tl, 0, (size_t)n * sizeof(unsigned long long)));
     return EXAADMM_OK;
 }
 

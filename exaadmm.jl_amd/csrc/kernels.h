@@ -41,7 +41,8 @@ struct Dev {
     const unsigned char* owned;  // SoA order; nullptr = all owned
     const int* lane_order;       // k_branch: lane i solves branch lane_order[i] (nullptr = identity)
     int *st_auglag, *st_minor, *st_ticks;
-    unsigned long long* st_cyc;  // diagnostic build (EXA_PROFILE_PHASES): 5 x Lp phase cycle counters
+    unsigned long long* st_cyc;  // diagnostic build (EXA_PROFILE_PHASES): 13 x Lp phase cycle counters
+    unsigned long long* st_tl;   // diagnostic build: 128 timeline entries per wavefront (2 x Lp)
     double* partials;  // [blocks][4]
 };
 
@@ -162,6 +163,9 @@ __global__ void __launch_bounds__(BR_BLOCK) k_branch(const Dev* __restrict__ dp,
     double x[6], xl[6], xu[6], phi[4];
     branch_start(ub, bnd, d.rateA[b], x, xl, xu);
     BranchStats st;
+#if defined(EXA_PROFILE_PHASES)
+    st.tl = d.st_tl ? d.st_tl + (size_t)(slot / 64) * 128 : nullptr;
+#endif
     branch_solve(bd, o, c_mupow, x, xl, xu, A, L, phi, st);
 
     d.u[base] = phi[0];
@@ -179,7 +183,7 @@ __global__ void __launch_bounds__(BR_BLOCK) k_branch(const Dev* __restrict__ dp,
     d.st_minor[b] = st.minor_it;
     d.st_ticks[b] = st.ticks;
 #if defined(EXA_PROFILE_PHASES)
-    for (int q = 0; q < 5; q++) d.st_cyc[q * d.Lp + b] = st.cyc[q];
+    for (int q = 0; q < 13; q++) d.st_cyc[q * d.Lp + b] = st.cyc[q];
 #endif
 }
 

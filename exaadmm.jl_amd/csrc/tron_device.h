@@ -47,6 +47,12 @@
 #define EXA_UNROLL
 #endif
 
+#if defined(EXA_PROFILE_PHASES) && defined(__HIP_DEVICE_COMPILE__)
+#define EXA_CLK() __builtin_amdgcn_s_memtime()
+#else
+#define EXA_CLK() 0ull
+#endif
+
 namespace exa {
 
 // task / termination codes (numbering of acopf_tron_linelimit_kernel.jl)
@@ -241,25 +247,80 @@ EXA_HD void trsol_t(const ML& L, const double (&id)[N], double (&r)[N])
     }
 }
 
+// In-place left-looking Cholesky of the packed lower triangle (TRON dicf, dense), columns in order.
+// rd[j] receives 1 / L(j,j).  Returns false when a pivot is not positive (the factor is then garbage).
+template <int N, class ML>
+EXA_HD bool chol_inplace(ML& L, double (&rd)[N])
+{
+    bool ok = true;
+    EXA_UNROLL
+    for (int j = 0; j < N; j++) {
+        EXA_UNROLL
+        for (int k = 0; k < j; k++) {
+            double ljk = L.lo(j, k);
+            EXA_UNROLL
+            for (int i = j; i < N; i++) L.lo(i, j) = fma(-L.lo(i, k), ljk, L.lo(i, j));
+        }
+        double d = L.lo(j, j);
+        ok = ok && (d > 0.0);
+        d = sqrt(d);
+        L.lo(j, j) = d;
+        const double r = 1.0 / d;
+        rd[j] = r;
+        EXA_UNROLL
+        for (int i = j + 1; i < N; i++) L.lo(i, j) *= r;
+    }
+    return ok;
+}
+
 // Scaled / shifted Cholesky of the free block of A (TRON dicfs + dicf, dense).
-// fr: bit i set = variable i free.  Bound rows/cols of L are the identity.
+// fr: bit i set = variable i free.  Bound rows/cols of L are the identity.  id[i] = 1 / L(i,i).
+//
+// dicfs factorises D A D + alpha I with D = diag(||A e_j||^-1/2) and returns D^-1 L.  The scaling only
+// matters for the size of the shift alpha; when no shift is needed (all free diagonals positive and
+// the matrix positive definite -- >99.9 % of the calls on the ACOPF path) D^-1 chol(D A D) = chol(A)
+// up to rounding, so the lane code first tries the plain factorisation of the masked matrix and only
+// falls back to the scaled / shifted loop when a pivot fails.  This skips 12 square roots, 6 divisions
+// and ~140 multiplications per call; the factor differs from the scaled one in the last bits only
+// (it preconditions CG; parity suite unchanged).
 template <int N, class MA, class ML>
 EXA_BIG void icfs_masked(unsigned fr, const MA& A, ML& L, double (&id)[N])
 {
     const int nbmax = 3;
     const double alpham = 1.0e-3, nbfactor = 512.0;
-    double wa2[N];
 
+    double m[N];  // 1.0 on free variables, 0.0 on bound ones
+    bool pos = true;
+    EXA_UNROLL
+    for (int i = 0; i < N; i++) {
+        const bool f = (fr >> i) & 1u;
+        m[i] = f ? 1.0 : 0.0;
+        pos = pos && (!f || A.lo(i, i) > 0.0);
+    }
+    if (pos) {
+        EXA_UNROLL
+        for (int i = 0; i < N; i++) {
+            EXA_UNROLL
+            for (int j = 0; j < i; j++) L.lo(i, j) = (A.lo(i, j) * m[i]) * m[j];
+            L.lo(i, i) = ((fr >> i) & 1u) ? A.lo(i, i) : 1.0;
+        }
+        if (chol_inplace<N>(L, id)) return;
+    }
+
+    double wa2[N], wi2[N], rdv[N];
     EXA_UNROLL
     for (int j = 0; j < N; j++) {
         double s = 0.0;
         EXA_UNROLL
         for (int i = 0; i < N; i++) {
-            double aij = ((fr >> i) & 1u) ? A.get(i, j) : 0.0;
+            double aij = A.get(i, j) * m[i];
             s = fma(aij, aij, s);
         }
         double nrm = sqrt(s);
-        wa2[j] = (((fr >> j) & 1u) && nrm > 0.0) ? 1.0 / sqrt(nrm) : 1.0;
+        const bool sc = ((fr >> j) & 1u) && nrm > 0.0;
+        const double rt = sqrt(nrm);
+        wa2[j] = sc ? 1.0 / rt : 1.0;
+        wi2[j] = sc ? rt : 1.0;  // 1 / wa2[j] up to rounding: the final un-scaling multiplies instead of dividing
     }
 
     double alphas = alpham;
@@ -288,35 +349,19 @@ EXA_BIG void icfs_masked(unsigned fr, const MA& A, ML& L, double (&id)[N])
                 L.lo(i, j) = v;
             }
         }
-        // left-looking Cholesky, columns in order
-        bool ok = true;
-        EXA_UNROLL
-        for (int j = 0; j < N; j++) {
-            EXA_UNROLL
-            for (int k = 0; k < j; k++) {
-                double ljk = L.lo(j, k);
-                EXA_UNROLL
-                for (int i = j; i < N; i++) L.lo(i, j) = fma(-L.lo(i, k), ljk, L.lo(i, j));
-            }
-            double d = L.lo(j, j);
-            ok = ok && (d > 0.0);
-            d = sqrt(d);
-            L.lo(j, j) = d;
-            const double rd = 1.0 / d;
-            EXA_UNROLL
-            for (int i = j + 1; i < N; i++) L.lo(i, j) *= rd;
-        }
+        const bool ok = chol_inplace<N>(L, rdv);
         if (ok) {
             if (alpha == alphas && nb < nbmax) {
                 alphas = alphas / nbfactor;
                 alpha = alphas;
                 nb++;
             } else {
+                // L <- D^-1 L with D = diag(wa2); 1/L(i,i) = wa2[i] / d_i
                 EXA_UNROLL
                 for (int i = 0; i < N; i++) {
                     EXA_UNROLL
-                    for (int j = 0; j <= i; j++) L.lo(i, j) = L.lo(i, j) / wa2[i];
-                    id[i] = 1.0 / L.lo(i, i);
+                    for (int j = 0; j <= i; j++) L.lo(i, j) = L.lo(i, j) * wi2[i];
+                    id[i] = rdv[i] * wa2[i];
                 }
                 return;
             }
@@ -455,7 +500,8 @@ EXA_BIG void prsrch_masked(unsigned fr, double (&x)[N], const double (&xl)[N], c
 // on exit x is the trial point and s = x - x0.
 template <int N, class MA, class ML>
 EXA_BIG void spcg(double (&x)[N], const double (&xl)[N], const double (&xu)[N], const MA& A, ML& L,
-                 const double (&g)[N], double delta, double rtol, double (&s)[N], int itermax)
+                 const double (&g)[N], double delta, double rtol, double (&s)[N], int itermax,
+                 unsigned long long* pc = nullptr)  // pc: diagnostic cycle counters (icfs, trpcg, prsrch, faces, cg its)
 {
     double w[N], gf[N], id[N];
     symv<N>(A, s, w);
@@ -473,7 +519,10 @@ EXA_BIG void spcg(double (&x)[N], const double (&xl)[N], const double (&xu)[N], 
             if (xl[i] < x[i] && x[i] < xu[i]) fr |= (1u << i);
         if (fr == 0u) return;
 
+        unsigned long long c0 = EXA_CLK();
         icfs_masked<N>(fr, A, L, id);
+        unsigned long long c1 = EXA_CLK();
+        if (pc) pc[0] += c1 - c0;
 
         double gfn2 = 0.0;
         EXA_UNROLL
@@ -486,11 +535,20 @@ EXA_BIG void spcg(double (&x)[N], const double (&xl)[N], const double (&xu)[N], 
         double gfnorm = sqrt(gfn2);
 
         int itertr;
+        c0 = EXA_CLK();
         int infotr = trpcg_masked<N>(fr, A, gf, delta, L, id, rtol * gfnorm, 0.0, itermax, w, itertr);
         iters += itertr;
         trsol_t<N>(L, id, w);
+        c1 = EXA_CLK();
+        if (pc) pc[1] += c1 - c0;
 
         prsrch_masked<N>(fr, x, xl, xu, A, gf, w);
+        c0 = EXA_CLK();
+        if (pc) {
+            pc[2] += c0 - c1;
+            pc[3] += 1;
+            pc[4] += (unsigned long long)itertr;
+        }
 
         EXA_UNROLL
         for (int i = 0; i < N; i++) s[i] += w[i];
@@ -516,6 +574,9 @@ struct TronState {
     double f, fc, delta, alphac, prered;
     double xc[N], s[N];
     int iter, minor_iter, nfev;
+#if defined(EXA_PROFILE_PHASES)
+    unsigned long long pc[8];  // diagnostic: icfs, trpcg, prsrch cycles, faces, cg its, cauchy cycles, spcg cycles
+#endif
 };
 
 // dtron, work = COMPUTE: model step from x (f, g, A valid at x).  x becomes the trial point.
@@ -526,8 +587,17 @@ EXA_HD void tron_compute(TronState<N>& st, double (&x)[N], const double (&xl)[N]
     st.fc = st.f;
     EXA_UNROLL
     for (int i = 0; i < N; i++) st.xc[i] = x[i];
+#if defined(EXA_PROFILE_PHASES)
+    unsigned long long c0 = EXA_CLK();
+    cauchy<N>(x, xl, xu, A, g, st.delta, st.alphac, st.s);
+    unsigned long long c1 = EXA_CLK();
+    spcg<N>(x, xl, xu, A, L, g, st.delta, cgtol, st.s, cg_itermax, st.pc);
+    st.pc[5] += c1 - c0;
+    st.pc[6] += EXA_CLK() - c1;
+#else
     cauchy<N>(x, xl, xu, A, g, st.delta, st.alphac, st.s);
     spcg<N>(x, xl, xu, A, L, g, st.delta, cgtol, st.s, cg_itermax);
+#endif
     double wa[N];
     symv<N>(A, st.s, wa);
     st.prered = -(dot<N>(st.s, g) + 0.5 * dot<N>(st.s, wa));

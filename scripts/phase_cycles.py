@@ -18,14 +18,14 @@ for rep in range(2):
     norms, ms, msb = mod.run_fixed(1, first_major_iter=40 + rep, beta=1e3, time_branch=True)
     a, m, t = mod.branch_counters()
     Lp = ((g["nline"] + 63) // 64) * 64
-    buf = np.zeros(5 * Lp, dtype=np.uint64)
+    buf = np.zeros(13 * Lp, dtype=np.uint64)
     pkg._check(L.exaadmm_debug_phase_cycles(mod.handle, buf.ctypes.data_as(C.POINTER(C.c_uint64)), buf.size), "phase cycles")
-    cyc = buf.reshape(5, Lp)[:, :g["nline"]].astype(np.float64)
-    names = ["fgh+newx", "model step", "f(trial)", "ratio test", "auglag step"]
+    cyc = buf.reshape(13, Lp)[:, :g["nline"]].astype(np.float64)
+    names = ["fgh+newx", "model step", "f(trial)", "ratio test", "auglag step", "icfs", "trpcg", "prsrch", "#faces", "#cg", "cauchy", "spcg", "#lone ticks"]
     print("k_branch %.3f ms; ticks: median %d max %d; auglag max %d" % (msb, np.median(t), t.max(), a.max()))
-    light = t == np.median(t)
-    heavy = t >= np.quantile(t, 0.999)
-    for nm, sel in (("median-tick branches", light), ("heaviest 0.1%", heavy)):
-        tot = cyc[:, sel].sum(axis=0).mean()
+    light = cyc[12] == 2
+    heavy = cyc[12] >= 4
+    for nm, sel in (("2 lone ticks", light), (">=4 lone ticks", heavy)):
+        tot = cyc[:5, sel].sum(axis=0).mean()
         print("  %-22s n=%5d ticks %.1f total cyc %.0f (%.1f us @2.4GHz)  per tick %.0f | " % (nm, sel.sum(), t[sel].mean(), tot, tot / 2400.0, tot / t[sel].mean())
-              + ", ".join("%s %.0f" % (names[q], cyc[q, sel].mean()) for q in range(5)))
+              + ", ".join("%s %.0f" % (names[q], cyc[q, sel].mean()) for q in range(13)))

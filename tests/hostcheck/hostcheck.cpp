@@ -46,8 +46,8 @@ extern "C" double hostcheck_f(const double* x_, const double* param, const doubl
     fill(d, param, Y, scale);
     double x[6];
     for (int i = 0; i < 6; i++) x[i] = x_[i];
-    double phi[4];
-    return branch_f(d, x, phi);
+    double phi[4], sc[2];
+    return branch_f(d, x, phi, sc);
 }
 
 // same contract as oracle_branch_solve

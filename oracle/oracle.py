@@ -30,7 +30,8 @@ c_int_p = C.POINTER(C.c_int32)
 def build(force=False):
     so = os.path.join(_HERE, "libexaadmm_oracle.so")
     srcs = [os.path.join(_HERE, f) for f in
-            ("tron_dense.c", "tron_dense.h", "acopf_oracle.c", "acopf_oracle.h", "Makefile")]
+            ("tron_dense.c", "tron_dense.h", "acopf_oracle.c", "acopf_oracle.h",
+             "mpacopf_oracle.c", "mpacopf_oracle.h", "Makefile")]
     if force or not os.path.exists(so) or any(
             os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-s", "-C", _HERE, "libexaadmm_oracle.so"])
@@ -328,5 +329,129 @@ def solve_acopf(case, outer_iterlim=20, inner_iterlim=1000, rho_pq=400.0, rho_va
         grid = grid_from_matpower(case, tight_factor=tight_factor)
     m = OracleModel(grid, rho_pq, rho_va, scale=scale, outer_eps=outer_eps,
                     outer_iterlim=outer_iterlim, inner_iterlim=inner_iterlim, nthreads=nthreads)
+    m.admm_two_level()
+    return m
+
+
+# --------------------------------------------------------------------------- #
+# Multi-period ACOPF (ModelMpacopf), oracle backend -- mpacopf_oracle.c
+# --------------------------------------------------------------------------- #
+_RAMP = ("u_curr", "l_curr", "rho", "rd", "rp", "z_curr", "z_prev", "lz", "Ax_plus_By", "s_curr")
+
+
+class Ramp(C.Structure):
+    _fields_ = [(n, c_double_p) for n in _RAMP + ("gen_membuf",)]
+
+
+class MP(C.Structure):
+    _fields_ = [("T", C.c_int32), ("grids", C.POINTER(Grid)), ("states", C.POINTER(State)),
+                ("ramps", C.POINTER(Ramp)), ("ramp_rate", c_double_p), ("sub_info", C.POINTER(Info))]
+
+
+def _mp_lib():
+    L = lib()
+    if not getattr(L, "_mp_ready", False):
+        mp, pp, ip = C.POINTER(MP), C.POINTER(Params), C.POINTER(Info)
+        L.oracle_mp_nvar.argtypes = [mp]
+        L.oracle_mp_init_solution.argtypes = [mp, C.c_double, C.c_double]
+        L.oracle_mp_inner_prestep.argtypes = [mp]
+        L.oracle_mp_update_x.argtypes = [mp, pp, C.c_int]
+        L.oracle_mp_update_xbar.argtypes = [mp]
+        L.oracle_mp_update_z.argtypes = [mp, C.c_double]
+        L.oracle_mp_update_l.argtypes = [mp, C.c_double]
+        L.oracle_mp_update_lz.argtypes = [mp, C.c_double, C.c_double]
+        L.oracle_mp_update_residual.argtypes = [mp, ip]
+        L.oracle_mp_norm_z_prev.argtypes = [mp]
+        L.oracle_mp_norm_z_prev.restype = C.c_double
+        L.oracle_mp_objective.argtypes = [mp]
+        L.oracle_mp_objective.restype = C.c_double
+        L.oracle_mp_admm_two_level.argtypes = [mp, pp, ip]
+        L.oracle_genramp_eval_f.restype = C.c_double
+        L.oracle_genramp_eval_f.argtypes = [c_double_p, c_double_p] + [C.c_double] * 5
+        L.oracle_genramp_eval_gh.argtypes = [c_double_p, c_double_p] + [C.c_double] * 5 + [c_double_p, c_double_p]
+        L.oracle_genramp_solve.restype = C.c_int
+        L.oracle_genramp_solve.argtypes = ([c_double_p] * 4 + [C.c_double] * 5 + [C.c_int, C.c_double, c_int_p, c_int_p])
+        L._mp_ready = True
+    return L
+
+
+class OracleMpModel:
+    """env + ModelMpacopf of the reference (mpacopf_model.jl:40-112), CPU oracle backend.
+    `pd`, `qd`: (nbus, T) load profiles in MW / MVAr (columns = periods), as get_load returns them."""
+
+    def __init__(self, grid, pd, qd, rho_pq=400.0, rho_va=40000.0, ramp_ratio=0.02, **params):
+        self.L = _mp_lib()
+        pd = np.asarray(pd, dtype=np.float64)
+        qd = np.asarray(qd, dtype=np.float64)
+        self.T = T = pd.shape[1]
+        self.periods = []
+        for t in range(T):
+            gt = dict(grid)
+            gt["Pd"] = np.ascontiguousarray(pd[:, t])
+            gt["Qd"] = np.ascontiguousarray(qd[:, t])
+            self.periods.append(OracleModel(gt, rho_pq, rho_va, **params))
+        m0 = self.periods[0]
+        self.ngen, self.nline, self.nbus = m0.ngen, m0.nline, m0.nbus
+        self.par = m0.par
+        G = self.ngen
+        self.ramp = [{k: np.zeros(G) for k in _RAMP} for _ in range(T)]
+        self.gen_membuf = [np.zeros((G, 8)) for _ in range(T)]
+        self.ramp_rate = np.ascontiguousarray(ramp_ratio * m0.g["pgmax"])
+        self._grids = (Grid * T)(*[p.cg for p in self.periods])
+        self._states = (State * T)(*[p.cs for p in self.periods])
+        self._ramps = (Ramp * T)()
+        for t in range(T):
+            for k in _RAMP:
+                setattr(self._ramps[t], k, _dp(self.ramp[t][k]))
+            self._ramps[t].gen_membuf = _dp(self.gen_membuf[t])
+        self._sub = (Info * T)()
+        self.mp = MP(T, self._grids, self._states, self._ramps, _dp(self.ramp_rate), self._sub)
+        self.info = Info()
+        self.nvar = self.L.oracle_mp_nvar(C.byref(self.mp))
+        self.L.oracle_mp_init_solution(C.byref(self.mp), rho_pq, rho_va)
+
+    def inner_prestep(self):
+        self.L.oracle_mp_inner_prestep(C.byref(self.mp))
+
+    def update_x(self, major_iter):
+        self.L.oracle_mp_update_x(C.byref(self.mp), C.byref(self.par), int(major_iter))
+
+    def update_xbar(self):
+        self.L.oracle_mp_update_xbar(C.byref(self.mp))
+
+    def update_z(self):
+        self.L.oracle_mp_update_z(C.byref(self.mp), self.par.beta)
+
+    def update_l(self):
+        self.L.oracle_mp_update_l(C.byref(self.mp), self.par.beta)
+
+    def update_lz(self):
+        self.L.oracle_mp_update_lz(C.byref(self.mp), self.par.beta, self.par.MAX_MULTIPLIER)
+
+    def update_residual(self):
+        self.L.oracle_mp_update_residual(C.byref(self.mp), C.byref(self.info))
+        return (self.info.primres, self.info.dualres, self.info.norm_z_curr, self.info.mismatch)
+
+    def norm_z_prev(self):
+        return self.L.oracle_mp_norm_z_prev(C.byref(self.mp))
+
+    def objective(self):
+        return self.L.oracle_mp_objective(C.byref(self.mp))
+
+    def admm_two_level(self):
+        self.L.oracle_mp_admm_two_level(C.byref(self.mp), C.byref(self.par), C.byref(self.info))
+        return self.info
+
+
+def solve_mpacopf(grid, pd, qd, outer_iterlim=20, inner_iterlim=1000, rho_pq=400.0, rho_va=40000.0,
+                  scale=1e-4, outer_eps=2e-4, ramp_ratio=0.02, warm_start=True):
+    """interface/solve_mpacopf.jl:1-37 on the oracle backend."""
+    m = OracleMpModel(grid, pd, qd, rho_pq, rho_va, ramp_ratio=ramp_ratio, scale=scale, outer_eps=outer_eps,
+                      outer_iterlim=outer_iterlim, inner_iterlim=inner_iterlim)
+    if warm_start:
+        for p in m.periods:          # each period alone, then re-initialise the ramp blocks (:26-31)
+            p.par = m.par
+            p.admm_two_level()
+        m.L.oracle_mp_init_solution(C.byref(m.mp), rho_pq, rho_va)
     m.admm_two_level()
     return m

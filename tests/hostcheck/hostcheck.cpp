@@ -6,6 +6,7 @@
 #define _GNU_SOURCE 1
 #include <math.h>
 #include "branch_solver.h"
+#include "genramp_solver.h"
 
 using namespace exa;
 
@@ -91,5 +92,45 @@ extern "C" int hostcheck_branch_solve(double* x_, const double* xl_, const doubl
     *auglag_it = st.auglag_it;
     *minor_it = st.minor_it;
     *ticks = st.ticks;
+    return 0;
+}
+
+// same contract as oracle_genramp_solve (scale = 1)
+extern "C" int hostcheck_genramp_solve(double* x_, const double* xl_, const double* xu_, double* param, double c2,
+                                       double c1, double c0, double baseMVA, int max_auglag, double xi_max,
+                                       int* auglag_it, int* minor_it)
+{
+    GenRampData d;
+    d.lam_p = param[0]; d.lam_h = param[1]; d.rho_p = param[2]; d.rho_h = param[3];
+    d.xt_p = param[4]; d.xt_h = param[5]; d.mu = param[6]; d.xi = param[7];
+    d.c2 = c2; d.c1 = c1; d.c0 = c0; d.M = baseMVA;
+    BranchOptions o;
+    o.max_auglag = max_auglag;
+    o.mu_max = xi_max;
+    o.max_feval = 500;
+    o.max_minor = 200;
+    o.gtol = 1e-6;
+    o.frtol = 1e-12;
+    o.fatol = 0.0;
+    o.fmin = -1e32;
+    o.cgtol = 0.1;
+    MuPowTable pw;
+    double p = 1.0;
+    for (int k = 0; k < 8; k++) {
+        p *= 10.0;
+        pw.pow10[k] = p;
+        pw.pow01[k] = pow(p, 0.1);
+        pw.pow09[k] = pow(p, 0.9);
+    }
+    double x[3], xl[3], xu[3];
+    for (int i = 0; i < 3; i++) {
+        x[i] = x_[i];
+        xl[i] = xl_[i];
+        xu[i] = xu_[i];
+    }
+    genramp_solve(d, o, pw, x, xl, xu, *auglag_it, *minor_it);
+    for (int i = 0; i < 3; i++) x_[i] = x[i];
+    param[6] = d.mu;
+    param[7] = d.xi;
     return 0;
 }

@@ -25,7 +25,7 @@ def _p(a):
 def hc():
     so = os.path.join(HC_DIR, "libhostcheck.so")
     srcs = [os.path.join(HC_DIR, "hostcheck.cpp"), os.path.join(CSRC, "tron_device.h"),
-            os.path.join(CSRC, "branch_solver.h")]
+            os.path.join(CSRC, "branch_solver.h"), os.path.join(CSRC, "genramp_solver.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mfma",
                                "-I", CSRC, srcs[0], "-o", so, "-lm"])
@@ -35,6 +35,7 @@ def hc():
     L.hostcheck_f.restype = C.c_double
     L.hostcheck_f.argtypes = [dp, dp, dp, C.c_double]
     L.hostcheck_branch_solve.argtypes = [dp, dp, dp, dp, dp, C.c_double, C.c_int, C.c_double, ip, ip, ip]
+    L.hostcheck_genramp_solve.argtypes = [dp, dp, dp, dp] + [C.c_double] * 4 + [C.c_int, C.c_double, ip, ip]
     return L
 
 
@@ -120,3 +121,35 @@ def test_lane_branch_solve_matches_oracle(hc, oracle, cold):
         n_same_counts += (ith.value == ito.value and mih.value == mio.value)
         assert tk.value >= mih.value - ith.value
     assert n_same_counts >= 0.97 * ncase
+
+
+def test_lane_generator_ramp_solve_matches_oracle(hc, oracle):
+    """3-variable generator ramp subproblem of the multi-period model: lane code
+    (TRON with N = 3) against the oracle's restatement of mpacopf_auglag_generator_kernel_cpu.jl."""
+    rng = np.random.default_rng(23)
+    oracle._mp_lib()
+    OL = oracle.lib()
+    same = 0
+    ncase = 400
+    for _ in range(ncase):
+        pmax = rng.uniform(0.5, 5.0)
+        pmin = rng.choice([0.0, 0.1 * pmax])
+        ramp = 0.02 * pmax
+        xl = np.array([pmin, pmin, -ramp])
+        xu = np.array([pmax, pmax, ramp])
+        x = np.array([rng.uniform(pmin, pmax), rng.uniform(pmin, pmax), rng.uniform(-ramp, ramp)])
+        rho = float(rng.choice([10.0, 50.0, 400.0]))
+        param = np.array([rng.normal(0, 5), rng.normal(0, 5), rho, rho, rng.uniform(pmin, pmax),
+                          rng.uniform(pmin, pmax), rng.choice([0.0, rng.normal(0, 20)]), 10.0 ** rng.integers(1, 5)])
+        c2, c1, c0, M = rng.uniform(0.0, 0.2), rng.uniform(1, 40), rng.uniform(0, 500), 100.0
+        xo, po = x.copy(), param.copy()
+        ito, mio = C.c_int(), C.c_int()
+        OL.oracle_genramp_solve(_p(xo), _p(xl), _p(xu), _p(po), 1.0, c2, c1, c0, M, 50, 1e8,
+                                C.cast(C.byref(ito), oracle.c_int_p), C.cast(C.byref(mio), oracle.c_int_p))
+        xh, ph = x.copy(), param.copy()
+        ith, mih = C.c_int(), C.c_int()
+        hc.hostcheck_genramp_solve(_p(xh), _p(xl), _p(xu), _p(ph), c2, c1, c0, M, 50, 1e8, C.byref(ith), C.byref(mih))
+        assert np.abs(xh - xo).max() <= 1e-9 * max(1.0, pmax), (xh, xo)
+        assert np.abs(ph[6:8] - po[6:8]).max() <= 1e-7 * max(1.0, np.abs(po[6:8]).max())
+        same += (ith.value == ito.value and mih.value == mio.value)
+    assert same >= 0.97 * ncase

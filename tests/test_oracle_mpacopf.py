@@ -1,0 +1,100 @@
+"""Pin the multi-period oracle (oracle/mpacopf_oracle.c) against the
+reference's own known answers (/root/reference/test/algorithms/mpacopf_update_cpu.jl, extracted
+into tests/golden/mpacopf_case9.json by tests/golden/gen_mpacopf_case9.py).
+
+The reference's load profile files are unavailable offline; the fixture carries the inferred
+profile (period 1 = case9 loads, periods 2-3 = uniform scalings, fitted on the golden v/z/l
+vectors).  With 2 fitted scalars the oracle reproduces all 4 x 3 x 78 golden numbers AND the
+full-solve anchor Solved / outer 20 / cumul 729 / objval 15901.48."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+G = json.load(open(os.path.join(GOLDEN, "mpacopf_case9.json")))
+ATOL = G["atol"] + 1e-9
+
+
+def mp_loads(grid):
+    sc = G["load_scaling"]
+    pd = np.stack([grid["Pd"] * a for a in sc["P"]], 1)
+    qd = np.stack([grid["Qd"] * a for a in sc["Q"]], 1)
+    return pd, qd
+
+
+def _check(vecs, key, slack=0.0):
+    for t in range(3):
+        full = np.concatenate([G[key + "_GEN"][t], G[key + "_BR"][t]])
+        assert np.abs(vecs[t] - full).max() <= ATOL + slack, (key, t)
+
+
+def test_load_profile_is_a_uniform_scaling():
+    sc = G["load_scaling"]
+    assert sc["P"][0] == 1.0 and sc["Q"][0] == 1.0
+    for t in (1, 2):   # P and Q factors fitted independently agree: one scalar per period
+        assert abs(sc["P"][t] - sc["Q"][t]) < 5e-8
+    assert sc["worst_abs_residual_vs_golden"] <= 1.0e-6 + 1e-9
+
+
+def test_one_iteration_known_answers(oracle, case9_grid):
+    s = G["settings"]
+    pd, qd = mp_loads(case9_grid)
+    m = oracle.OracleMpModel(case9_grid, pd, qd, s["rho_pq"], s["rho_va"], ramp_ratio=s["ramp_ratio"], scale=s["scale"])
+    m.par.beta = s["initial_beta"]
+    assert m.nvar == 78 + 3
+    m.inner_prestep()
+    m.update_x(1)
+    _check([p.sol["u_curr"] for p in m.periods], "U")
+    m.update_xbar()
+    _check([p.sol["v_curr"] for p in m.periods], "V")
+    m.update_z()
+    _check([p.sol["z_curr"] for p in m.periods], "Z")
+    m.update_l()
+    _check([p.sol["l_curr"] for p in m.periods], "L", slack=1e-6)   # literals truncated at 6 decimals
+    m.update_residual()
+    for t, p in enumerate(m.periods):      # mpacopf_update_cpu.jl:393-407
+        sol = p.sol
+        assert np.abs(sol["rp"] - (sol["u_curr"] - sol["v_curr"] + sol["z_curr"])).max() <= ATOL
+        assert np.abs(sol["rd"] - (sol["z_curr"] - sol["z_prev"])).max() <= ATOL
+        assert np.abs(sol["Ax_plus_By"] - (sol["u_curr"] - sol["v_curr"])).max() <= ATOL
+        if t > 0:
+            r = m.ramp[t]
+            vprev = m.periods[t - 1].sol["v_curr"][0:2 * m.ngen:2]
+            assert np.abs(r["rp"] - (r["u_curr"] - vprev + r["z_curr"])).max() <= ATOL
+            assert np.abs(r["rd"] - (r["z_curr"] - r["z_prev"])).max() <= ATOL
+            assert np.abs(r["Ax_plus_By"] - (r["u_curr"] - vprev)).max() <= ATOL
+    lz0 = [p.sol["lz"].copy() for p in m.periods]
+    rlz0 = [r["lz"].copy() for r in m.ramp]
+    m.update_lz()
+    for t, p in enumerate(m.periods):      # :409-427
+        assert np.abs(p.sol["lz"] - (lz0[t] + m.par.beta * p.sol["z_curr"])).max() <= ATOL
+        if t > 0:
+            assert np.abs(m.ramp[t]["lz"] - (rlz0[t] + m.par.beta * m.ramp[t]["z_curr"])).max() <= ATOL
+
+
+def test_full_solve_anchor(oracle, case9_grid):
+    a = G["solve"]
+    pd, qd = mp_loads(case9_grid)
+    m = oracle.solve_mpacopf(case9_grid, pd, qd, outer_iterlim=a["outer_iterlim"], rho_pq=4e2, rho_va=4e4,
+                             outer_eps=a["outer_eps"], warm_start=a["warm_start"])
+    assert m.info.status == 1
+    assert m.info.outer == a["outer"]
+    assert m.info.cumul == a["cumul"]
+    assert abs(m.info.objval - a["objval"]) <= a["objval_atol"]
+
+
+def test_anchor_is_insensitive_to_the_inferred_digits(oracle, case9_grid):
+    """The fitted scale factors carry ~1e-8 uncertainty; the anchor must not hinge on them."""
+    a = G["solve"]
+    pd, qd = mp_loads(case9_grid)
+    for eps in (-2e-7, 2e-7):
+        pd2, qd2 = pd.copy(), qd.copy()
+        pd2[:, 1:] *= 1 + eps
+        qd2[:, 1:] *= 1 + eps
+        m = oracle.solve_mpacopf(case9_grid, pd2, qd2, outer_iterlim=a["outer_iterlim"], rho_pq=4e2, rho_va=4e4,
+                                 outer_eps=a["outer_eps"], warm_start=False)
+        assert (m.info.status, m.info.outer, m.info.cumul) == (1, a["outer"], a["cumul"])
+        assert abs(m.info.objval - a["objval"]) <= a["objval_atol"]

@@ -137,6 +137,14 @@ def library():
     L.exaadmm_ctrl_step.argtypes = [H, C.c_void_p]
     L.exaadmm_ctrl_read.argtypes = [H, C.POINTER(C.c_int), C.POINTER(C.c_int), c_double_p]
     L.exaadmm_ctrl_end.argtypes = [H]
+    L.exaadmm_mp_create.argtypes = [C.POINTER(Grid), C.POINTER(Parameters), C.c_int, c_double_p, c_double_p,
+                                    C.c_double, C.c_int, C.POINTER(H)]
+    L.exaadmm_mp_periods.argtypes = [H]
+    L.exaadmm_mp_nvar.argtypes = [H]
+    L.exaadmm_mp_nvar.restype = C.c_int64
+    L.exaadmm_mp_update_x_gen.argtypes = [H, C.c_int]
+    L.exaadmm_mp_download_ramp.argtypes = [H, C.c_int, c_double_p, C.c_int64]
+    L.exaadmm_mp_upload_ramp.argtypes = [H, C.c_int, c_double_p, C.c_int64]
     L.exaadmm_load_matpower.argtypes = [C.c_char_p, C.c_double, C.c_char_p, C.POINTER(C.c_void_p)]
     L.exaadmm_case_grid.argtypes = [C.c_void_p, C.POINTER(Grid)]
     L.exaadmm_case_free.argtypes = [C.c_void_p]
@@ -559,3 +567,195 @@ def solve_acopf_rolling(case, load_prefix=None, load=None, case_format="matpower
         load = get_load(load_prefix)
     results = admm_restart_rolling(env, mod, load, start_period=start_period, end_period=end_period, fused=fused)
     return env, mod, results
+
+
+# --------------------------------------------------------------------------- multi-period ACOPF
+RAMP_VECTORS = dict(VECTORS, s_curr=20, mu=21, xi=22)
+RAMP_VECTORS.pop("v_curr", None)   # SolutionRamping.v_curr is never read on this path
+
+
+class _PeriodSolution:
+    """mod.models[i].solution of the reference: the period's slice of the time-expanded vectors,
+    in the single-period reference layout [2 ngen | 8 nline]."""
+
+    def __init__(self, mp, t):
+        object.__setattr__(self, "_mp", mp)
+        object.__setattr__(self, "_t", t)
+
+    def __getattr__(self, name):
+        if name in VECTORS:
+            return self._mp.period_vector(name, self._t)
+        raise AttributeError(name)
+
+
+class _RampSolution:
+    """mod.solution[i] of the reference (SolutionRamping, mpacopf_model.jl:1-38), ngen entries."""
+
+    def __init__(self, mp, t):
+        object.__setattr__(self, "_mp", mp)
+        object.__setattr__(self, "_t", t)
+
+    def __getattr__(self, name):
+        if name in RAMP_VECTORS:
+            G = self._mp.ngen
+            return self._mp.download_ramp(name)[self._t * G:(self._t + 1) * G]
+        raise AttributeError(name)
+
+
+class _Period:
+    def __init__(self, mp, t):
+        self.solution = _PeriodSolution(mp, t)
+        self.grid_data = mp.grid_data
+        self.ngen, self.nline, self.nbus = mp.ngen, mp.nline, mp.nbus
+        self.gen_start, self.line_start = 1, 2 * mp.ngen + 1
+
+
+class ModelMpacopf:
+    """ModelMpacopf (models/mpacopf/mpacopf_model.jl:40-112) on one MI355X: one time-expanded device
+    model (include/exaadmm_hip.h, exaadmm_mp_create).  `load` = (pd, qd), nbus x T matrices as
+    returned by get_load; periods start_period..end_period (1-based, inclusive) are used.
+    All admm_* plugin steps and admm_two_level take this object unchanged."""
+
+    def __init__(self, env, load, start_period=1, end_period=1, ramp_ratio=0.02):
+        L = library()
+        pd, qd = (np.asarray(a, dtype=np.float64) for a in load)
+        if not (1 <= start_period <= end_period <= pd.shape[1]):
+            raise ExaAdmmError("start_period / end_period out of range of the load profile")
+        self.env = env
+        g = env.data
+        self.grid_data = g
+        self.ngen, self.nline, self.nbus = g["ngen"], g["nline"], g["nbus"]
+        self.len_horizon = T = end_period - start_period + 1
+        self.ramp_ratio = float(ramp_ratio)
+        self.n = 6
+        cg = Grid()
+        cg.ngen, cg.nline, cg.nbus, cg.index_base, cg.baseMVA = self.ngen, self.nline, self.nbus, 0, g["baseMVA"]
+        for k in Grid._F64 + Grid._BUS:
+            setattr(cg, k, _dp(g[k]))
+        for k in Grid._IDX + ("brBusIdx",):
+            setattr(cg, k, g[k].ctypes.data_as(c_i64_p))
+        self._pd = np.ascontiguousarray(pd[:, start_period - 1:end_period].T)   # T x nbus, period-major
+        self._qd = np.ascontiguousarray(qd[:, start_period - 1:end_period].T)
+        self._h = C.c_void_p()
+        _check(L.exaadmm_mp_create(C.byref(cg), C.byref(env.params), T, _dp(self._pd), _dp(self._qd), self.ramp_ratio,
+                                   env.gpu_no, C.byref(self._h)), "exaadmm_mp_create")
+        _check(L.exaadmm_init_solution(self._h, env.initial_rho_pq, env.initial_rho_va), "exaadmm_init_solution")
+        self.nvar = int(L.exaadmm_mp_nvar(self._h))              # mod.nvar of the reference
+        self.nvar_expanded = int(L.exaadmm_nvar(self._h))        # length of the device vectors
+        self.info = Info()
+        self.models = [_Period(self, t) for t in range(T)]
+        self.solution = [_RampSolution(self, t) for t in range(T)]
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if self._h:
+            library().exaadmm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync_params(self):
+        _check(library().exaadmm_set_params(self._h, C.byref(self.env.params)), "exaadmm_set_params")
+
+    def init_solution(self):
+        _check(library().exaadmm_init_solution(self._h, self.env.initial_rho_pq, self.env.initial_rho_va), "exaadmm_init_solution")
+
+    def download(self, name):
+        out = np.empty(self.nvar_expanded)
+        _check(library().exaadmm_download_solution(self._h, VECTORS[name], _dp(out), out.size), "download " + name)
+        return out
+
+    def upload(self, name, value):
+        a = np.ascontiguousarray(value, dtype=np.float64)
+        _check(library().exaadmm_upload_solution(self._h, VECTORS[name], _dp(a), a.size), "upload " + name)
+
+    def period_vector(self, name, t):
+        """Period t (0-based) of a solution vector in the single-period reference layout."""
+        x = self.download(name)
+        G, Ln, T = self.ngen, self.nline, self.len_horizon
+        return np.concatenate([x[2 * G * t:2 * G * (t + 1)], x[2 * G * T + 8 * Ln * t:2 * G * T + 8 * Ln * (t + 1)]])
+
+    def download_ramp(self, name):
+        out = np.empty(self.len_horizon * self.ngen)
+        _check(library().exaadmm_mp_download_ramp(self._h, RAMP_VECTORS[name], _dp(out), out.size), "download ramp " + name)
+        return out
+
+    def upload_ramp(self, name, value):
+        a = np.ascontiguousarray(value, dtype=np.float64)
+        _check(library().exaadmm_mp_upload_ramp(self._h, RAMP_VECTORS[name], _dp(a), a.size), "upload ramp " + name)
+
+    @property
+    def membuf(self):
+        n = self.len_horizon * self.nline
+        out = np.zeros((n, 31))
+        _check(library().exaadmm_download_membuf(self._h, _dp(out), 31, n), "download membuf")
+        return out.T.copy()
+
+    @membuf.setter
+    def membuf(self, value):
+        n = self.len_horizon * self.nline
+        a = np.ascontiguousarray(np.asarray(value, dtype=np.float64).T)
+        _check(library().exaadmm_upload_membuf(self._h, _dp(a), 31, n), "upload membuf")
+
+    def run_inner(self, outer, max_inner, beta):
+        self.sync_params()
+        done = C.c_int()
+        out = np.zeros(4)
+        _check(library().exaadmm_run_inner(self._h, outer, max_inner, beta, C.byref(done), _dp(out)), "exaadmm_run_inner")
+        return done.value, out
+
+    def run_fixed(self, iters, first_major_iter=2, beta=None, time_branch=False):
+        self.sync_params()
+        out = np.zeros(4)
+        ms, msb = C.c_double(), C.c_double()
+        beta = self.env.params.beta if beta is None else beta
+        _check(library().exaadmm_run_fixed(self._h, iters, first_major_iter, beta, _dp(out), C.byref(ms),
+                                           C.byref(msb) if time_branch else None), "exaadmm_run_fixed")
+        return out, ms.value, msb.value
+
+
+def solve_mpacopf(case, load_prefix=None, load=None, case_format="matpower", start_period=1, end_period=1,
+                  outer_iterlim=20, inner_iterlim=1000, rho_pq=400.0, rho_va=40000.0, obj_scale=1.0, scale=1e-4,
+                  use_linelimit=True, tight_factor=1.0, outer_eps=2e-4, gpu_no=0, verbose=0, ramp_ratio=0.02,
+                  warm_start=True, grid=None, fused=True):
+    """solve_mpacopf (interface/solve_mpacopf.jl:1-37).  `load` = (pd, qd) may be given instead of
+    `load_prefix`.  warm_start: every period is first solved alone; as in the reference the
+    following init_solution! resets all vectors, so what survives is membuf (the line-limit
+    multipliers, rows 25-26) -- reproduced here by solving each period on a single-period handle
+    and copying those rows into the multi-period model."""
+    if load is None:
+        if load_prefix is None:
+            raise ExaAdmmError("solve_mpacopf needs load_prefix or load")
+        load = get_load(load_prefix)
+    env = AdmmEnv(case, rho_pq, rho_va, case_format=case_format, use_linelimit=use_linelimit,
+                  tight_factor=tight_factor, gpu_no=gpu_no, verbose=verbose, grid=grid)
+    mod = ModelMpacopf(env, load, start_period=start_period, end_period=end_period, ramp_ratio=ramp_ratio)
+    env.params.scale = scale
+    env.params.outer_eps = outer_eps
+    env.params.outer_iterlim = outer_iterlim
+    env.params.inner_iterlim = inner_iterlim
+    if warm_start:
+        mb = mod.membuf
+        Ln = mod.nline
+        single = ModelAcopf(env)
+        for t in range(mod.len_horizon):
+            _check(library().exaadmm_init_solution(single.handle, env.initial_rho_pq, env.initial_rho_va), "exaadmm_init_solution")
+            if t > 0:   # copy(models[1]) in the reference: membuf of period 1 as constructed (zeros)
+                pass
+            single.set_load(mod._pd[t], mod._qd[t])
+            admm_two_level(env, single, fused=fused)
+            mb[:, t * Ln:(t + 1) * Ln] = single.membuf
+        single.close()
+        mod.init_solution()
+        mod.membuf = mb
+    admm_two_level(env, mod, fused=fused)
+    if verbose > 0:
+        print_statistics(env, mod)
+    return env, mod

@@ -64,6 +64,11 @@ struct exaadmm_handle {
     int device = 0;
     int G = 0, L = 0, B = 0, Gp = 0, Lp = 0, N = 0;
     int64_t nvar = 0;
+    // multi-period model (exaadmm_mp_create): T periods stored period-major in one time-expanded
+    // handle; nvar_ctrl is mod.nvar of the reference (one period + ngen, mpacopf_model.jl:99-104),
+    // which sets eps_pri and the outer tolerance
+    int T = 1, g1 = 0, l1 = 0, b1 = 0, mp_nbx = 1;
+    int64_t nvar_ctrl = 0;
     double baseMVA = 100.0;
     exaadmm_params par;
     Dev d;
@@ -103,6 +108,10 @@ struct exaadmm_handle {
 };
 
 static int attach_init_data(exaadmm_handle* h, const exaadmm_grid* g);
+static void launch_gen(exaadmm_handle* h, const Ctrl* c, int major_iter = 0);
+static int sync_check(exaadmm_handle* h, bool force = false);
+template <int MODE>
+static void launch_mp_elem(exaadmm_handle* h, double beta, const Ctrl* c);
 
 template <class T>
 static int dev_alloc(exaadmm_handle* h, T** p, size_t n)
@@ -296,6 +305,8 @@ extern "C" int exaadmm_create(const exaadmm_grid* g, const exaadmm_params* p, in
     h->Lp = round_up(h->L, 64);
     h->N = 2 * h->Gp + 8 * h->Lp;
     h->nvar = 2 * (int64_t)h->G + 8 * (int64_t)h->L;
+    h->nvar_ctrl = h->nvar;
+    h->g1 = h->G; h->l1 = h->L; h->b1 = h->B;
     h->baseMVA = g->baseMVA;
     if (p)
         h->par = *p;
@@ -328,6 +339,7 @@ extern "C" int exaadmm_create(const exaadmm_grid* g, const exaadmm_params* p, in
     d.G = h->G; d.L = h->L; d.B = h->B; d.Gp = h->Gp; d.Lp = h->Lp; d.N = h->N;
     d.La = g->nline_active > 0 ? (int)g->nline_active : h->L;
     d.Ba = g->nbus_active > 0 ? (int)g->nbus_active : h->B;
+    d.T = 1; d.g1 = h->G; d.l1 = h->L; d.b1 = h->B;
     const int base = g->index_base;
     int rc = 0;
 #define TRY(x) do { if ((rc = (x))) { exaadmm_destroy(h); return rc; } } while (0)
@@ -527,7 +539,10 @@ extern "C" int exaadmm_upload_solution(exaadmm_handle* h, int which, const doubl
 static int materialize_if_needed(exaadmm_handle* h)
 {
     if (!h->residual_vectors_valid) {
-        hipLaunchKernelGGL(k_materialize, dim3(h->ew_blocks), dim3(EW_BLOCK), 0, h->stream, h->d);
+        if (h->T > 1)
+            launch_mp_elem<MP_RESIDUAL>(h, 0.0, nullptr);   // also fills the ramp block's rp, rd, Ax_plus_By
+        else
+            hipLaunchKernelGGL(k_materialize, dim3(h->ew_blocks), dim3(EW_BLOCK), 0, h->stream, h->d);
         HIPCHK(hipGetLastError());
         h->residual_vectors_valid = true;
     }
@@ -673,16 +688,215 @@ extern "C" int exaadmm_init_solution(exaadmm_handle* h, double rho_pq, double rh
     for (int l = 0; l < h->L; l++) mb[28 + 31 * (size_t)l] = h->rateA_h[l];
     if ((rc = exaadmm_upload_membuf(h, mb.data(), 31, h->L))) return rc;
     if (h->G > 0 && (rc = exaadmm_set_pg_bounds(h, id->pgmin.data(), id->pgmax.data(), h->G))) return rc;
+    if (h->T > 1) {
+        // init_solution! of the multi-period model (mpacopf_init_solution_cpu.jl:1-20): ramp blocks zero,
+        // rho = rho_pq, phat_{t-1} = pbar_{t-1} (= v of the previous period), s = p_t - phat = -phat
+        // (u is zero here).  gen_membuf (multiplier, penalty) is NOT touched, as in the reference.
+        const size_t n = (size_t)h->T * h->g1;
+        std::vector<double> z0(n, 0.0), ru(n, 0.0), rs(n, 0.0), rr(n, rho_pq);
+        for (int t = 1; t < h->T; t++)
+            for (int g = 0; g < h->g1; g++) {
+                const size_t i = (size_t)t * h->g1 + g;
+                ru[i] = v[2 * ((size_t)(t - 1) * h->g1 + g)];
+                rs[i] = 0.0 - ru[i];
+            }
+        double* zs[] = {h->d.r_z, h->d.r_zp, h->d.r_l, h->d.r_lz, h->d.r_rp, h->d.r_rd, h->d.r_ax};
+        for (double* q : zs) HIPCHK(hipMemcpy(q, z0.data(), n * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d.r_u, ru.data(), n * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d.r_s, rs.data(), n * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d.r_rho, rr.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    }
     h->residual_vectors_valid = true;
+    return EXAADMM_OK;
+}
+
+// ------------------------------------------------------------------ multi-period model (ModelMpacopf)
+// One TIME-EXPANDED handle: the T periods are block-diagonal copies of the network (generator
+// t*ngen+i, branch t*nline+j, bus t*nbus+k) with their own loads, so every kernel of the
+// single-period path covers all periods in one launch; the ramp coupling adds the 3-variable
+// generator subproblem (k_gen_ramp), the ramp terms of the bus update and the ramp block of the
+// elementwise steps.  Reference: models/mpacopf/mpacopf_model.jl:40-112.
+extern "C" int exaadmm_mp_create(const exaadmm_grid* g, const exaadmm_params* p, int T, const double* Pd, const double* Qd,
+                                 double ramp_ratio, int device_id, exaadmm_handle** out)
+{
+    REQUIRE(g && out && Pd && Qd, "null argument");
+    REQUIRE(T >= 1, "need at least one period");
+    REQUIRE(g->nline_active == 0 && g->nbus_active == 0, "a multi-period model cannot be a partition");
+    const int64_t G = g->ngen, L = g->nline, B = g->nbus;
+    REQUIRE((2 * G + 8 * L) * (int64_t)T < (int64_t)2000000000, "time-expanded grid too large for 32-bit device indices");
+    const int base = (int)g->index_base;
+    auto rep = [&](const double* src, int64_t n) {
+        std::vector<double> o((size_t)(n * T));
+        for (int t = 0; t < T; t++) std::copy(src, src + n, o.begin() + (size_t)t * n);
+        return o;
+    };
+    std::vector<double> pgmin = rep(g->pgmin, G), pgmax = rep(g->pgmax, G), qgmin = rep(g->qgmin, G), qgmax = rep(g->qgmax, G);
+    std::vector<double> c2 = rep(g->c2, G), c1 = rep(g->c1, G), c0 = rep(g->c0, G);
+    std::vector<double> Y[8];
+    const double* Ysrc[8] = {g->YffR, g->YffI, g->YftR, g->YftI, g->YttR, g->YttI, g->YtfR, g->YtfI};
+    for (int k = 0; k < 8; k++) Y[k] = rep(Ysrc[k], L);
+    std::vector<double> frvm = rep(g->FrVmBound, 2 * L), tovm = rep(g->ToVmBound, 2 * L), frva = rep(g->FrVaBound, 2 * L),
+                        tova = rep(g->ToVaBound, 2 * L), rate = rep(g->rateA, L);
+    std::vector<double> vmin = rep(g->Vmin, B), vmax = rep(g->Vmax, B), yshr = rep(g->YshR, B), yshi = rep(g->YshI, B);
+    std::vector<double> pd(Pd, Pd + (size_t)B * T), qd(Qd, Qd + (size_t)B * T);
+    std::vector<int64_t> brbus((size_t)(2 * L * T));
+    for (int t = 0; t < T; t++)
+        for (int64_t k = 0; k < 2 * L; k++) brbus[(size_t)(t * 2 * L + k)] = g->brBusIdx[k] + (int64_t)t * B;
+    auto csr = [&](const int64_t* st, const int64_t* ix, int64_t nnz, std::vector<int64_t>& S, std::vector<int64_t>& I) {
+        S.assign((size_t)(B * T + 1), 0);
+        I.assign((size_t)(nnz * T), 0);
+        for (int t = 0; t < T; t++) {
+            for (int64_t k = 0; k < B; k++) S[(size_t)(t * B + k)] = st[k] + (int64_t)t * nnz;
+            for (int64_t k = 0; k < nnz; k++) I[(size_t)(t * nnz + k)] = ix[k] + (int64_t)t * nnz;
+        }
+        S[(size_t)(B * T)] = base + (int64_t)T * nnz;
+    };
+    REQUIRE(g->FrStart[B] - base == L && g->ToStart[B] - base == L && g->GenStart[B] - base == G, "CSR arrays must cover every component");
+    std::vector<int64_t> frs, fri, tos, toi, gs, gi;
+    csr(g->FrStart, g->FrIdx, L, frs, fri);
+    csr(g->ToStart, g->ToIdx, L, tos, toi);
+    csr(g->GenStart, g->GenIdx, G, gs, gi);
+
+    exaadmm_grid e;
+    memset(&e, 0, sizeof(e));
+    e.ngen = G * T; e.nline = L * T; e.nbus = B * T;
+    e.index_base = g->index_base;
+    e.baseMVA = g->baseMVA;
+    e.pgmin = pgmin.data(); e.pgmax = pgmax.data(); e.qgmin = qgmin.data(); e.qgmax = qgmax.data();
+    e.c2 = c2.data(); e.c1 = c1.data(); e.c0 = c0.data();
+    e.YffR = Y[0].data(); e.YffI = Y[1].data(); e.YftR = Y[2].data(); e.YftI = Y[3].data();
+    e.YttR = Y[4].data(); e.YttI = Y[5].data(); e.YtfR = Y[6].data(); e.YtfI = Y[7].data();
+    e.FrVmBound = frvm.data(); e.ToVmBound = tovm.data(); e.FrVaBound = frva.data(); e.ToVaBound = tova.data();
+    e.rateA = rate.data();
+    e.brBusIdx = brbus.data();
+    e.Pd = pd.data(); e.Qd = qd.data(); e.Vmin = vmin.data(); e.Vmax = vmax.data(); e.YshR = yshr.data(); e.YshI = yshi.data();
+    e.FrStart = frs.data(); e.FrIdx = fri.data(); e.ToStart = tos.data(); e.ToIdx = toi.data();
+    e.GenStart = gs.data(); e.GenIdx = gi.data();
+
+    exaadmm_handle* h = nullptr;
+    int rc = exaadmm_create(&e, p, device_id, &h);
+    if (rc) return rc;
+    // the bus-sorted branch order keeps every period contiguous (bus ids are period-major)
+    for (int t = 0; t < T; t++)
+        for (int64_t b = 0; b < L; b++) {
+            const int q = h->perm[(size_t)(t * L + b)];
+            if (q < t * L || q >= (t + 1) * L) {
+                set_err("internal: branch permutation crosses a period boundary");
+                exaadmm_destroy(h);
+                return EXAADMM_ERR_INVALID;
+            }
+        }
+    h->T = T; h->g1 = (int)G; h->l1 = (int)L; h->b1 = (int)B;
+    h->nvar_ctrl = (T == 1) ? (2 * G + 8 * L) : (2 * G + 8 * L + G);   // mpacopf_model.jl:99-104
+    Dev& d = h->d;
+    d.T = T; d.g1 = (int)G; d.l1 = (int)L; d.b1 = (int)B;
+#define TRYM(x) do { if ((rc = (x))) { exaadmm_destroy(h); return rc; } } while (0)
+    const size_t n = (size_t)std::max<int64_t>(G * T, 1);
+    double** rv[] = {&d.r_u, &d.r_s, &d.r_z, &d.r_zp, &d.r_l, &d.r_lz, &d.r_rho, &d.r_rp, &d.r_rd, &d.r_ax, &d.r_mu, &d.r_xi};
+    for (auto pp : rv) {
+        TRYM(dev_alloc(h, pp, n));
+        if (hipMemset(*pp, 0, n * sizeof(double)) != hipSuccess) { set_err("hipMemset failed"); exaadmm_destroy(h); return EXAADMM_ERR_HIP; }
+    }
+    {
+        std::vector<double> rr(n, 0.0), cc(n, 0.0);
+        for (size_t i = 0; i < (size_t)(G * T); i++) {
+            rr[i] = ramp_ratio * pgmax[i];   // acopf_model.jl:66-67
+            cc[i] = c0[i];
+        }
+        double *drr, *dcc;
+        TRYM(dev_alloc(h, &drr, n));
+        TRYM(dev_alloc(h, &dcc, n));
+        TRYM(upload_vec(h, drr, rr));
+        TRYM(upload_vec(h, dcc, cc));
+        d.ramp_rate = drr;
+        d.c0 = dcc;
+    }
+    // (chunk, period, plane) launch shape of the elementwise steps; partial sums per block
+    h->mp_nbx = std::min(256, std::max(1, (int)((std::max(G, L) + EW_BLOCK - 1) / EW_BLOCK)));
+    TRYM(dev_alloc(h, &d.partials, (size_t)T * MP_PLANES * h->mp_nbx * 4));
+#undef TRYM
+    h->dev_dirty = true;
+    *out = h;
+    return EXAADMM_OK;
+}
+
+extern "C" int exaadmm_mp_periods(exaadmm_handle* h) { return h ? h->T : -1; }
+extern "C" int64_t exaadmm_mp_nvar(exaadmm_handle* h) { return h ? h->nvar_ctrl : -1; }
+
+extern "C" int exaadmm_mp_update_x_gen(exaadmm_handle* h, int major_iter)
+{
+    REQUIRE(h && major_iter >= 1, "bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    launch_gen(h, nullptr, major_iter);
+    h->residual_vectors_valid = false;
+    return sync_check(h);
+}
+
+static double* ramp_ptr(exaadmm_handle* h, int which)
+{
+    switch (which) {
+        case EXAADMM_U_CURR: return h->d.r_u;
+        case EXAADMM_L_CURR: return h->d.r_l;
+        case EXAADMM_RHO: return h->d.r_rho;
+        case EXAADMM_RD: return h->d.r_rd;
+        case EXAADMM_RP: return h->d.r_rp;
+        case EXAADMM_Z_CURR: return h->d.r_z;
+        case EXAADMM_Z_PREV: return h->d.r_zp;
+        case EXAADMM_LZ: return h->d.r_lz;
+        case EXAADMM_AX_PLUS_BY: return h->d.r_ax;
+        case EXAADMM_RAMP_S: return h->d.r_s;
+        case EXAADMM_RAMP_MU: return h->d.r_mu;
+        case EXAADMM_RAMP_XI: return h->d.r_xi;
+        default: return nullptr;
+    }
+}
+
+extern "C" int exaadmm_mp_download_ramp(exaadmm_handle* h, int which, double* host, int64_t n)
+{
+    REQUIRE(h && host, "null argument");
+    REQUIRE(h->T > 1, "not a multi-period handle");
+    REQUIRE(n == (int64_t)h->T * h->g1, "ramp vectors have T x ngen entries (period-major, block 0 unused)");
+    double* src = ramp_ptr(h, which);
+    REQUIRE(src, "unknown ramp vector id");
+    HIPCHK(hipSetDevice(h->device));
+    if (which == EXAADMM_RP || which == EXAADMM_RD || which == EXAADMM_AX_PLUS_BY) {
+        int rc = materialize_if_needed(h);
+        if (rc) return rc;
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(host, src, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    return EXAADMM_OK;
+}
+
+extern "C" int exaadmm_mp_upload_ramp(exaadmm_handle* h, int which, const double* host, int64_t n)
+{
+    REQUIRE(h && host, "null argument");
+    REQUIRE(h->T > 1, "not a multi-period handle");
+    REQUIRE(n == (int64_t)h->T * h->g1, "ramp vectors have T x ngen entries (period-major, block 0 unused)");
+    double* dst = ramp_ptr(h, which);
+    REQUIRE(dst, "unknown ramp vector id");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(dst, host, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
     return EXAADMM_OK;
 }
 
 // ------------------------------------------------------------------ launches
 static inline dim3 grid_for(int n, int block) { return dim3((unsigned)std::max(1, (n + block - 1) / block)); }
 
-static void launch_gen(exaadmm_handle* h, const Ctrl* c)
+static void launch_gen(exaadmm_handle* h, const Ctrl* c, int major_iter)
 {
-    if (h->G > 0) hipLaunchKernelGGL(k_generator, grid_for(h->G, 64), dim3(64), 0, h->stream, h->d, h->baseMVA, c);
+    if (h->G <= 0) return;
+    if (h->T > 1)
+        hipLaunchKernelGGL(k_gen_ramp, grid_for(h->G, 64), dim3(64), 0, h->stream, h->d, h->bo, h->baseMVA, major_iter, c);
+    else
+        hipLaunchKernelGGL(k_generator, grid_for(h->G, 64), dim3(64), 0, h->stream, h->d, h->baseMVA, c);
+}
+template <int MODE>
+static void launch_mp_elem(exaadmm_handle* h, double beta, const Ctrl* c)
+{
+    hipLaunchKernelGGL((k_mp_elem<MODE>), dim3(h->mp_nbx, h->T, MP_PLANES), dim3(EW_BLOCK), 0, h->stream, h->d, beta,
+                       h->par.MAX_MULTIPLIER, c);
 }
 static void launch_branch(exaadmm_handle* h, int major_iter, const Ctrl* c, bool with_generators = false)
 {
@@ -703,15 +917,23 @@ static void launch_bus(exaadmm_handle* h, const Ctrl* c)
 }
 static void launch_fused_zl(exaadmm_handle* h, double beta, const Ctrl* c)
 {
-    hipLaunchKernelGGL(k_fused_zl, dim3(h->ew_blocks), dim3(EW_BLOCK), 0, h->stream, h->d, beta, c);
+    if (h->T > 1)
+        launch_mp_elem<MP_FUSED_ZL>(h, beta, c);
+    else
+        hipLaunchKernelGGL(k_fused_zl, dim3(h->ew_blocks), dim3(EW_BLOCK), 0, h->stream, h->d, beta, c);
 }
+// single-period: d_sums receives the four SUMS OF SQUARES; multi-period: the four NORMS (max over periods)
 static void launch_final(exaadmm_handle* h, Ctrl* c, double* out = nullptr)
 {
-    hipLaunchKernelGGL(k_final_reduce, dim3(1), dim3(EW_BLOCK), 0, h->stream, h->d.partials, h->ew_blocks,
-                       out ? out : h->d_sums, c);
+    if (h->T > 1)
+        hipLaunchKernelGGL(k_final_reduce_mp, dim3(1), dim3(EW_BLOCK), 0, h->stream, h->d.partials, MP_PLANES * h->mp_nbx,
+                           h->T, out ? out : h->d_sums, c);
+    else
+        hipLaunchKernelGGL(k_final_reduce, dim3(1), dim3(EW_BLOCK), 0, h->stream, h->d.partials, h->ew_blocks,
+                           out ? out : h->d_sums, c);
 }
 
-static int sync_check(exaadmm_handle* h, bool force = false)
+static int sync_check(exaadmm_handle* h, bool force)
 {
     HIPCHK(hipGetLastError());
     if (force || !h->async_mode) HIPCHK(hipStreamSynchronize(h->stream));
@@ -723,6 +945,7 @@ static int fetch_sums(exaadmm_handle* h, double out[4], bool take_sqrt)
     HIPCHK(hipMemcpyAsync(h->h_sums, h->d_sums, 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     int rc = sync_check(h, true);
     if (rc) return rc;
+    if (h->T > 1) take_sqrt = false;  // the multi-period reduction delivers norms
     for (int j = 0; j < 4; j++) out[j] = take_sqrt ? sqrt(h->h_sums[j]) : h->h_sums[j];
     return 0;
 }
@@ -732,7 +955,10 @@ extern "C" int exaadmm_inner_prestep(exaadmm_handle* h)
 {
     REQUIRE(h, "null handle");
     HIPCHK(hipSetDevice(h->device));
-    hipLaunchKernelGGL(k_copy_z, dim3(h->ew_blocks), dim3(EW_BLOCK), 0, h->stream, h->d);
+    if (h->T > 1)
+        launch_mp_elem<MP_COPY_Z>(h, 0.0, nullptr);
+    else
+        hipLaunchKernelGGL(k_copy_z, dim3(h->ew_blocks), dim3(EW_BLOCK), 0, h->stream, h->d);
     h->residual_vectors_valid = false;
     return sync_check(h);
 }
@@ -740,6 +966,7 @@ extern "C" int exaadmm_inner_prestep(exaadmm_handle* h)
 extern "C" int exaadmm_update_x_gen(exaadmm_handle* h)
 {
     REQUIRE(h, "null handle");
+    REQUIRE(h->T == 1, "multi-period handle: use exaadmm_mp_update_x_gen(h, major_iter)");
     HIPCHK(hipSetDevice(h->device));
     launch_gen(h, h->ctrl_mode ? h->d_ctrl : nullptr);
     h->residual_vectors_valid = false;
@@ -759,7 +986,7 @@ extern "C" int exaadmm_update_x(exaadmm_handle* h, int major_iter)
 {
     REQUIRE(h, "null handle");
     HIPCHK(hipSetDevice(h->device));
-    launch_gen(h, nullptr);
+    launch_gen(h, nullptr, major_iter);
     launch_branch(h, major_iter, h->ctrl_mode ? h->d_ctrl : nullptr);
     h->residual_vectors_valid = false;
     return sync_check(h);
@@ -778,7 +1005,10 @@ extern "C" int exaadmm_update_z(exaadmm_handle* h, double beta)
 {
     REQUIRE(h, "null handle");
     HIPCHK(hipSetDevice(h->device));
-    hipLaunchKernelGGL(k_update_z, dim3(h->ew_blocks), dim3(EW_BLOCK), 0, h->stream, h->d, beta);
+    if (h->T > 1)
+        launch_mp_elem<MP_UPDATE_Z>(h, beta, nullptr);
+    else
+        hipLaunchKernelGGL(k_update_z, dim3(h->ew_blocks), dim3(EW_BLOCK), 0, h->stream, h->d, beta);
     h->residual_vectors_valid = false;
     return sync_check(h);
 }
@@ -787,7 +1017,10 @@ extern "C" int exaadmm_update_l(exaadmm_handle* h, double beta)
 {
     REQUIRE(h, "null handle");
     HIPCHK(hipSetDevice(h->device));
-    hipLaunchKernelGGL(k_update_l, dim3(h->ew_blocks), dim3(EW_BLOCK), 0, h->stream, h->d, beta);
+    if (h->T > 1)
+        launch_mp_elem<MP_UPDATE_L>(h, beta, nullptr);
+    else
+        hipLaunchKernelGGL(k_update_l, dim3(h->ew_blocks), dim3(EW_BLOCK), 0, h->stream, h->d, beta);
     return sync_check(h);
 }
 
@@ -795,7 +1028,10 @@ extern "C" int exaadmm_update_lz(exaadmm_handle* h, double beta)
 {
     REQUIRE(h, "null handle");
     HIPCHK(hipSetDevice(h->device));
-    hipLaunchKernelGGL(k_update_lz, dim3(h->ew_blocks), dim3(EW_BLOCK), 0, h->stream, h->d, beta, h->par.MAX_MULTIPLIER);
+    if (h->T > 1)
+        launch_mp_elem<MP_UPDATE_LZ>(h, beta, nullptr);
+    else
+        hipLaunchKernelGGL(k_update_lz, dim3(h->ew_blocks), dim3(EW_BLOCK), 0, h->stream, h->d, beta, h->par.MAX_MULTIPLIER);
     return sync_check(h);
 }
 
@@ -803,7 +1039,10 @@ extern "C" int exaadmm_update_residual(exaadmm_handle* h, double out[4])
 {
     REQUIRE(h && out, "null argument");
     HIPCHK(hipSetDevice(h->device));
-    hipLaunchKernelGGL(k_residual, dim3(h->ew_blocks), dim3(EW_BLOCK), 0, h->stream, h->d);
+    if (h->T > 1)
+        launch_mp_elem<MP_RESIDUAL>(h, 0.0, nullptr);
+    else
+        hipLaunchKernelGGL(k_residual, dim3(h->ew_blocks), dim3(EW_BLOCK), 0, h->stream, h->d);
     launch_final(h, nullptr);
     h->residual_vectors_valid = true;
     return fetch_sums(h, out, true);
@@ -812,6 +1051,7 @@ extern "C" int exaadmm_update_residual(exaadmm_handle* h, double out[4])
 extern "C" int exaadmm_update_zl_partial(exaadmm_handle* h, double beta, double* dev_out4)
 {
     REQUIRE(h && dev_out4, "null argument");
+    REQUIRE(h->T == 1, "partition helpers are not available on a multi-period handle");
     HIPCHK(hipSetDevice(h->device));
     launch_fused_zl(h, beta, h->ctrl_mode ? h->d_ctrl : nullptr);
     launch_final(h, nullptr, dev_out4);
@@ -822,6 +1062,7 @@ extern "C" int exaadmm_update_zl_partial(exaadmm_handle* h, double beta, double*
 extern "C" int exaadmm_sumsq_z_partial(exaadmm_handle* h, double* dev_out4)
 {
     REQUIRE(h && dev_out4, "null argument");
+    REQUIRE(h->T == 1, "partition helpers are not available on a multi-period handle");
     HIPCHK(hipSetDevice(h->device));
     hipLaunchKernelGGL(k_sumsq_z, dim3(h->ew_blocks), dim3(EW_BLOCK), 0, h->stream, h->d);
     launch_final(h, nullptr, dev_out4);
@@ -832,7 +1073,10 @@ extern "C" int exaadmm_norm_z(exaadmm_handle* h, double* out)
 {
     REQUIRE(h && out, "null argument");
     HIPCHK(hipSetDevice(h->device));
-    hipLaunchKernelGGL(k_sumsq_z, dim3(h->ew_blocks), dim3(EW_BLOCK), 0, h->stream, h->d);
+    if (h->T > 1)
+        launch_mp_elem<MP_SUMSQ_Z>(h, 0.0, nullptr);
+    else
+        hipLaunchKernelGGL(k_sumsq_z, dim3(h->ew_blocks), dim3(EW_BLOCK), 0, h->stream, h->d);
     launch_final(h, nullptr);
     double s[4];
     int rc = fetch_sums(h, s, true);
@@ -943,7 +1187,8 @@ extern "C" int exaadmm_debug_wave_timeline(exaadmm_handle* h, unsigned long long
 static void enqueue_iteration(exaadmm_handle* h, Ctrl* c, bool sample = false)
 {
     if (sample) (void)hipEventRecord(h->tev[0], h->stream);
-    launch_branch(h, 0, c, true);   // generators ride in the same launch
+    if (h->T > 1) launch_gen(h, c);           // multi-period: ramp subproblems need their own kernel
+    launch_branch(h, 0, c, h->T == 1);        // single-period: generators ride in the same launch
     if (sample) (void)hipEventRecord(h->tev[1], h->stream);
     launch_bus(h, c);
     if (sample) (void)hipEventRecord(h->tev[2], h->stream);
@@ -960,7 +1205,7 @@ extern "C" int exaadmm_run_inner(exaadmm_handle* h, int outer, int max_inner, do
     memset(hc, 0, sizeof(Ctrl));
     hc->max_inner = max_inner;
     hc->check_every = std::max(1, (int)h->par.check_every);
-    hc->eps_pri = sqrt((double)h->nvar) / (2500.0 * outer);  // admm_two_level.jl:45
+    hc->eps_pri = sqrt((double)h->nvar_ctrl) / (2500.0 * outer);  // admm_two_level.jl:45
     hc->beta = beta;
     HIPCHK(hipMemcpyAsync(h->d_ctrl, hc, sizeof(Ctrl), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));  // hc is reused as the download target below
@@ -1028,7 +1273,7 @@ extern "C" int exaadmm_solve_two_level(exaadmm_handle* h, exaadmm_info* out)
     HIPCHK(hipSetDevice(h->device));
     exaadmm_params& par = h->par;
     exaadmm_info& info = h->info;
-    const double sqrt_d = sqrt((double)h->nvar);
+    const double sqrt_d = sqrt((double)h->nvar_ctrl);
     const double OUTER_TOL = sqrt_d * par.outer_eps;
     memset(&info, 0, sizeof(info));
     info.mismatch = INFINITY;
@@ -1090,8 +1335,9 @@ extern "C" int exaadmm_run_fixed(exaadmm_handle* h, int iters, int first_major_i
     h->residual_vectors_valid = false;
     HIPCHK(hipEventRecord(h->ev[0], h->stream));
     for (int i = 0; i < iters; i++) {
+        if (h->T > 1) launch_gen(h, nullptr, first_major_iter + i);
         if (time_branch) HIPCHK(hipEventRecord(h->ev[2 + 2 * i], h->stream));
-        launch_branch(h, first_major_iter + i, nullptr, true);
+        launch_branch(h, first_major_iter + i, nullptr, h->T == 1);
         if (time_branch) HIPCHK(hipEventRecord(h->ev[3 + 2 * i], h->stream));
         launch_bus(h, nullptr);
         launch_fused_zl(h, beta, nullptr);

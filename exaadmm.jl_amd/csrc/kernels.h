@@ -10,6 +10,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "branch_solver.h"
+#include "genramp_solver.h"
 
 namespace exa {
 
@@ -35,6 +36,7 @@ struct Dev {
     const double* rateA;
     double *ls1, *ls2, *mu;
     const double *pgmin, *pgmax, *qgmin, *qgmax, *c2, *c1;
+    const double* c0;  // multi-period model only (the ramp subproblem's objective carries the constant)
     const double *Pd, *Qd, *YshR, *YshI;
     const int *FrStart, *FrIdx, *ToStart, *ToIdx, *GenStart, *GenIdx;
     const int *EndStart, *EndCode;  // per bus: generators, from-branches, to-branches (kind << 28 | index)
@@ -44,6 +46,13 @@ struct Dev {
     unsigned long long* st_cyc;  // diagnostic build (EXA_PROFILE_PHASES): 13 x Lp phase cycle counters
     unsigned long long* st_tl;   // diagnostic build: 128 timeline entries per wavefront (2 x Lp)
     double* partials;  // [blocks][4]
+    // multi-period model (ModelMpacopf): T periods stored period-major inside every
+    // plane (generator t*g1+i, branch t*l1+j, bus t*b1+k); T = 1 for the single-period model.
+    // Ramp block (SolutionRamping of period t >= 1) at [t*g1 + i]; block 0 is unused.
+    int T, g1, l1, b1;
+    double *r_u, *r_s, *r_z, *r_zp, *r_l, *r_lz, *r_rho, *r_rp, *r_rd, *r_ax;
+    double *r_mu, *r_xi;      // gen_membuf rows 7, 8: multiplier and penalty of the ramp constraint (persistent)
+    const double* ramp_rate;  // per expanded generator: ramp_ratio * pgmax
 };
 
 __constant__ MuPowTable c_mupow;
@@ -70,6 +79,54 @@ __global__ void k_generator(Dev d, double baseMVA, const Ctrl* ctrl)
 {
     if (loop_done(ctrl)) return;
     generator_update(d, baseMVA, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// Multi-period generator update (mpacopf_admm_update_x_cpu.jl:5-31): period 0 keeps the closed
+// form; a generator of period t >= 1 solves the 3-variable ramp subproblem (p_t, phat_{t-1}, s_t)
+// by augmented Lagrangian x TRON (auglag_generator_kernel, mpacopf_auglag_generator_kernel_cpu.jl),
+// one lane per generator and period.
+__global__ void __launch_bounds__(64) k_gen_ramp(Dev d, BranchOptions o, double baseMVA, int major_iter, const Ctrl* ctrl)
+{
+    if (ctrl != nullptr) {
+        if (ctrl->done) return;
+        major_iter = ctrl->inner + 1;
+    }
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.G) return;
+    if (i < d.g1) {
+        generator_update(d, baseMVA, i);
+        return;
+    }
+    const int pg = i, qg = d.Gp + i;
+    d.u[qg] = fmax(d.qgmin[i], fmin(d.qgmax[i], (-(d.l[qg] + d.rho[qg] * (-d.v[qg] + d.z[qg]))) / d.rho[qg]));
+    double x[3], xl[3], xu[3];
+    xl[0] = xl[1] = d.pgmin[i];
+    xu[0] = xu[1] = d.pgmax[i];
+    xl[2] = -d.ramp_rate[i];
+    xu[2] = d.ramp_rate[i];
+    x[0] = fmin(xu[0], fmax(xl[0], d.u[pg]));
+    x[1] = fmin(xu[1], fmax(xl[1], d.r_u[i]));
+    x[2] = fmin(xu[2], fmax(xl[2], d.r_s[i]));
+    GenRampData gd;
+    gd.lam_p = d.l[pg];
+    gd.lam_h = d.r_l[i];
+    gd.rho_p = d.rho[pg];
+    gd.rho_h = d.r_rho[i];
+    gd.xt_p = d.v[pg] - d.z[pg];
+    gd.xt_h = d.v[pg - d.g1] - d.r_z[i];   // pbar of the previous period (mpacopf_admm_update_x_cpu.jl:19)
+    gd.mu = d.r_mu[i];
+    gd.xi = (major_iter <= 1) ? 10.0 : d.r_xi[i];
+    gd.c2 = d.c2[i];
+    gd.c1 = d.c1[i];
+    gd.c0 = d.c0[i];
+    gd.M = baseMVA;
+    int it, minor;
+    genramp_solve(gd, o, c_mupow, x, xl, xu, it, minor);
+    d.u[pg] = x[0];
+    d.r_u[i] = x[1];
+    d.r_s[i] = x[2];
+    d.r_mu[i] = gd.mu;
+    d.r_xi[i] = gd.xi;
 }
 
 // ---------------------------------------------------------------- branch
@@ -187,6 +244,10 @@ __global__ void __launch_bounds__(BR_BLOCK) k_branch(const Dev* __restrict__ dp,
 #endif
 }
 
+// Multi-period model: the real power of a generator of period t < T-1 is also tied to the copy
+// phat kept by period t+1 (ramp block index pg + g1); the last period has no such partner.
+__device__ __forceinline__ bool bus_gen_has_ramp(const Dev& d, int pg) { return d.T > 1 && pg < (d.T - 1) * d.g1; }
+
 // ---------------------------------------------------------------- bus
 // bus_kernel_two_level_alternative (acopf_bus_kernel_gpu.jl:1-119), one lane per bus.
 // Gathers 4 planes per incident branch end, 2 per generator; scatters v to the same places.
@@ -230,9 +291,16 @@ __global__ void k_bus(Dev d, double baseMVA, const Ctrl* ctrl)
     double rhs1 = 0.0, rhs2 = 0.0, inv_rhosum_pg = 0.0, inv_rhosum_qg = 0.0;
     for (int k = g0; k < g1; k++) {
         const int pg = d.GenIdx[k], qg = Gp + pg;
-        rhs1 += (u[pg] + z[pg]) + (l[pg] / rho[pg]);
+        if (bus_gen_has_ramp(d, pg)) {  // bus_kernel_ramp (mpacopf_bus_kernel_cpu.jl:53-62)
+            const int ri = pg + d.g1;
+            const double den = rho[pg] + d.r_rho[ri];
+            rhs1 += ((l[pg] + rho[pg] * (u[pg] + z[pg])) + (d.r_l[ri] + d.r_rho[ri] * (d.r_u[ri] + d.r_z[ri]))) / den;
+            inv_rhosum_pg += 1.0 / den;
+        } else {
+            rhs1 += (u[pg] + z[pg]) + (l[pg] / rho[pg]);
+            inv_rhosum_pg += 1.0 / rho[pg];
+        }
         rhs2 += (u[qg] + z[qg]) + (l[qg] / rho[qg]);
-        inv_rhosum_pg += 1.0 / rho[pg];
         inv_rhosum_qg += 1.0 / rho[qg];
     }
     rhs1 -= (d.Pd[I] / baseMVA);
@@ -262,7 +330,13 @@ __global__ void k_bus(Dev d, double baseMVA, const Ctrl* ctrl)
 
     for (int k = g0; k < g1; k++) {
         const int pg = d.GenIdx[k], qg = Gp + pg;
-        v[pg] = (u[pg] + z[pg]) + (l[pg] - mu1) / rho[pg];
+        if (bus_gen_has_ramp(d, pg)) {  // mpacopf_bus_kernel_cpu.jl:98-101
+            const int ri = pg + d.g1;
+            v[pg] = ((l[pg] + rho[pg] * (u[pg] + z[pg])) + (d.r_l[ri] + d.r_rho[ri] * (d.r_u[ri] + d.r_z[ri])) - mu1) /
+                    (rho[pg] + d.r_rho[ri]);
+        } else {
+            v[pg] = (u[pg] + z[pg]) + (l[pg] - mu1) / rho[pg];
+        }
         v[qg] = (u[qg] + z[qg]) + (l[qg] - mu2) / rho[qg];
     }
     for (int k = f0; k < f1; k++) {
@@ -306,6 +380,7 @@ __device__ __forceinline__ void bus_load_end(const Dev& d, int code, double (&r)
         idx[0] = c;
         idx[1] = d.Gp + c;
         idx[2] = idx[3] = -1;
+        if (bus_gen_has_ramp(d, c)) idx[2] = -2 - (c + d.g1);  // ramp partner: record 2 = (r_u, r_z, r_l, r_rho)
     } else {
         const int e = 2 * d.Gp + c;
         const int off = (kind == END_FROM) ? 0 : 2;
@@ -322,6 +397,12 @@ __device__ __forceinline__ void bus_load_end(const Dev& d, int code, double (&r)
             r[4 * m + 1] = d.z[i];
             r[4 * m + 2] = d.l[i];
             r[4 * m + 3] = d.rho[i];
+        } else if (i <= -2) {
+            const int ri = -2 - i;
+            r[4 * m] = d.r_u[ri];
+            r[4 * m + 1] = d.r_z[ri];
+            r[4 * m + 2] = d.r_l[ri];
+            r[4 * m + 3] = d.r_rho[ri];
         } else {
             r[4 * m] = r[4 * m + 1] = r[4 * m + 2] = 0.0;
             r[4 * m + 3] = 1.0;
@@ -359,9 +440,15 @@ __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group(Dev d, double baseMVA, 
             kind = code >> 28;
             bus_load_end(d, code, r, idx);
             kinds[grp][lane] = kind;
-            term[grp][T_P][lane] = (r[0] + r[1]) + (r[2] / r[3]);
+            if (idx[2] <= -2) {  // generator with a ramp partner (mpacopf_bus_kernel_cpu.jl:53-62)
+                const double den = r[3] + r[11];
+                term[grp][T_P][lane] = ((r[2] + r[3] * (r[0] + r[1])) + (r[10] + r[11] * (r[8] + r[9]))) / den;
+                term[grp][T_IP][lane] = 1.0 / den;
+            } else {
+                term[grp][T_P][lane] = (r[0] + r[1]) + (r[2] / r[3]);
+                term[grp][T_IP][lane] = 1.0 / r[3];
+            }
             term[grp][T_Q][lane] = (r[4] + r[5]) + (r[6] / r[7]);
-            term[grp][T_IP][lane] = 1.0 / r[3];
             term[grp][T_IQ][lane] = 1.0 / r[7];
             term[grp][T_W][lane] = r[10] + r[11] * (r[8] + r[9]);
             term[grp][T_T][lane] = r[14] + r[15] * (r[12] + r[13]);
@@ -432,7 +519,10 @@ __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group(Dev d, double baseMVA, 
                 bus_load_end(d, code, r, idx);
             }
             if (kind == END_GEN) {
-                d.v[idx[0]] = (r[0] + r[1]) + (r[2] - mu1) / r[3];
+                if (idx[2] <= -2)
+                    d.v[idx[0]] = ((r[2] + r[3] * (r[0] + r[1])) + (r[10] + r[11] * (r[8] + r[9])) - mu1) / (r[3] + r[11]);
+                else
+                    d.v[idx[0]] = (r[0] + r[1]) + (r[2] - mu1) / r[3];
                 d.v[idx[1]] = (r[4] + r[5]) + (r[6] - mu2) / r[7];
             } else {
                 d.v[idx[0]] = (r[0] + r[1]) + (r[2] + mu1) / r[3];
@@ -593,6 +683,127 @@ __global__ void __launch_bounds__(EW_BLOCK) k_final_reduce(const double* partial
             for (int j = 0; j < 4; j++) {
                 ctrl->sums[j] = s[j];
                 ctrl->res[j] = sqrt(s[j]);
+            }
+            const int inner = ctrl->inner + 1;
+            ctrl->inner = inner;
+            const bool test = (ctrl->check_every <= 1) || (inner % ctrl->check_every == 0);
+            if ((test && ctrl->res[0] <= ctrl->eps_pri) || inner >= ctrl->max_inner) ctrl->done = 1;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- multi-period elementwise steps
+// ModelMpacopf.  The residual norms of the multi-period model are the MAXIMUM over
+// periods of the per-period norms, period t >= 1 including its ramp block
+// (mpacopf_admm_update_residual_cpu.jl:1-55), so the elementwise kernels are launched on a
+// (chunk, period, plane) grid: plane 0..9 = the SoA planes, plane 10 = the ramp block, whose consensus
+// partner is v[pg] of the PREVIOUS period (mpacopf_admm_update_z_cpu.jl:10-14).  Each block stays
+// inside one period, partial sums are kept per (period, plane, chunk) and reduced in a fixed order.
+constexpr int MP_PLANES = 11;
+enum { MP_COPY_Z = 0, MP_UPDATE_Z = 1, MP_UPDATE_L = 2, MP_UPDATE_LZ = 3, MP_RESIDUAL = 4, MP_SUMSQ_Z = 5, MP_FUSED_ZL = 6 };
+
+template <int MODE>
+__global__ void __launch_bounds__(EW_BLOCK) k_mp_elem(Dev d, double beta_arg, double maxmult, const Ctrl* ctrl)
+{
+    if (loop_done(ctrl)) return;
+    const double beta = ctrl ? ctrl->beta : beta_arg;
+    const int plane = blockIdx.z, t = blockIdx.y;
+    const bool ramp = (plane == MP_PLANES - 1);
+    const int n = (plane < 2 || ramp) ? d.g1 : d.l1;
+    const int off = ramp ? t * d.g1 : ((plane < 2 ? plane * d.Gp : 2 * d.Gp + (plane - 2) * d.Lp) + t * n);
+    const int voff = ramp ? (t - 1) * d.g1 : off;
+    double* const U = ramp ? d.r_u : d.u;
+    double* const Z = ramp ? d.r_z : d.z;
+    double* const ZP = ramp ? d.r_zp : d.zp;
+    double* const Lm = ramp ? d.r_l : d.l;
+    double* const LZ = ramp ? d.r_lz : d.lz;
+    const double* const RHO = ramp ? d.r_rho : d.rho;
+    double* const RP = ramp ? d.r_rp : d.rp;
+    double* const RD = ramp ? d.r_rd : d.rd;
+    double* const AX = ramp ? d.r_ax : d.ax;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    if (!(ramp && t == 0)) {
+        for (int i = blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += gridDim.x * EW_BLOCK) {
+            const int e = off + i, ev = voff + i;
+            if (MODE == MP_COPY_Z) {
+                ZP[e] = Z[e];
+            } else if (MODE == MP_UPDATE_Z) {
+                Z[e] = (-(LZ[e] + Lm[e] + RHO[e] * (U[e] - d.v[ev]))) / (beta + RHO[e]);
+            } else if (MODE == MP_UPDATE_L) {
+                Lm[e] = -(LZ[e] + beta * Z[e]);
+            } else if (MODE == MP_UPDATE_LZ) {
+                LZ[e] = fmax(-maxmult, fmin(maxmult, LZ[e] + (beta * Z[e])));
+            } else if (MODE == MP_RESIDUAL) {
+                const double z = Z[e];
+                const double rp = U[e] - d.v[ev] + z;
+                const double rd = z - ZP[e];
+                const double ax = rp - z;
+                RP[e] = rp;
+                RD[e] = rd;
+                AX[e] = ax;
+                s[0] += rp * rp;
+                s[1] += rd * rd;
+                s[2] += z * z;
+                s[3] += ax * ax;
+            } else if (MODE == MP_SUMSQ_Z) {
+                const double z = Z[e];
+                s[2] += z * z;
+            } else {  // MP_FUSED_ZL: z_prev <- z, z-update, l-update, residual sums in one pass
+                const double u = U[e], v = d.v[ev], rho = RHO[e], lz = LZ[e];
+                const double zold = Z[e];
+                const double z = (-(lz + Lm[e] + rho * (u - v))) / (beta + rho);
+                const double rp = u - v + z;
+                const double rd = z - zold;
+                const double ax = rp - z;
+                ZP[e] = zold;
+                Z[e] = z;
+                Lm[e] = -(lz + beta * z);
+                s[0] += rp * rp;
+                s[1] += rd * rd;
+                s[2] += z * z;
+                s[3] += ax * ax;
+            }
+        }
+    }
+    if (MODE == MP_RESIDUAL || MODE == MP_SUMSQ_Z || MODE == MP_FUSED_ZL) {
+        block_reduce4(s);
+        if (threadIdx.x == 0) {
+            const int slot = (t * MP_PLANES + plane) * gridDim.x + blockIdx.x;
+#pragma unroll
+            for (int j = 0; j < 4; j++) d.partials[slot * 4 + j] = s[j];
+        }
+    }
+}
+
+// Per-period sums in a fixed order, norm = sqrt, model norm = max over periods; optionally advance the
+// loop control exactly like k_final_reduce.  out[j] receives the NORMS (not their squares).
+__global__ void __launch_bounds__(EW_BLOCK) k_final_reduce_mp(const double* partials, int nblk_per_period, int T, double* out,
+                                                              Ctrl* ctrl)
+{
+    if (ctrl != nullptr && ctrl->done) return;
+    double best[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int t = 0; t < T; t++) {
+        double s[4] = {0.0, 0.0, 0.0, 0.0};
+        const double* p = partials + (size_t)t * nblk_per_period * 4;
+        for (int b = threadIdx.x; b < nblk_per_period; b += EW_BLOCK) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) s[j] += p[b * 4 + j];
+        }
+        block_reduce4(s);
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) best[j] = fmax(best[j], sqrt(s[j]));
+        }
+        __syncthreads();   // block_reduce4's scratch is reused by the next period
+    }
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) out[j] = best[j];
+        if (ctrl != nullptr) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                ctrl->sums[j] = best[j] * best[j];
+                ctrl->res[j] = best[j];
             }
             const int inner = ctrl->inner + 1;
             ctrl->inner = inner;

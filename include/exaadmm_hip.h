@@ -94,7 +94,9 @@ typedef struct {
 typedef enum {
     EXAADMM_U_CURR = 0, EXAADMM_V_CURR = 1, EXAADMM_L_CURR = 2, EXAADMM_RHO = 3,
     EXAADMM_RD = 4, EXAADMM_RP = 5, EXAADMM_Z_CURR = 6, EXAADMM_Z_PREV = 7,
-    EXAADMM_LZ = 8, EXAADMM_AX_PLUS_BY = 9
+    EXAADMM_LZ = 8, EXAADMM_AX_PLUS_BY = 9,
+    /* ramp block of the multi-period model only (SolutionRamping.s_curr, gen_membuf rows 7 and 8) */
+    EXAADMM_RAMP_S = 20, EXAADMM_RAMP_MU = 21, EXAADMM_RAMP_XI = 22
 } exaadmm_vector;
 
 const char *exaadmm_version(void);
@@ -197,6 +199,34 @@ int exaadmm_ctrl_begin(exaadmm_handle *h, int outer, int max_inner, double beta,
 int exaadmm_ctrl_step(exaadmm_handle *h, const double *dev_sums4);
 int exaadmm_ctrl_read(exaadmm_handle *h, int *done, int *inner, double res[4]);
 int exaadmm_ctrl_end(exaadmm_handle *h);
+
+/* ---- multi-period ACOPF: ModelMpacopf (src/models/mpacopf/mpacopf_model.jl:40-112) ----
+ * T periods of the same network with their own loads, coupled through generator ramp constraints
+ *   p_{t,g} - phat_{t-1,g} - s_{t,g} = 0,  |s| <= ramp_ratio * pgmax_g,  phat_{t-1,g} in consensus with pbar_{t-1,g}.
+ * The handle is ONE time-expanded model: every vector of the single-period API has T x (its
+ * single-period length) entries in the layout [gens of period 1 | ... | gens of period T | lines of
+ * period 1 | ... | lines of period T] (exaadmm_nvar = T * (2 ngen + 8 nline)), and every entry point
+ * above applies to all periods at once with the reference's multi-period semantics:
+ *   exaadmm_update_x      mpacopf_admm_update_x_cpu.jl:5-45 (closed form for period 1, 3-variable
+ *                         augmented-Lagrangian x TRON ramp subproblem per generator for t >= 2, then lines)
+ *   exaadmm_update_xbar   mpacopf_admm_update_xbar_cpu.jl / bus_kernel_ramp (mpacopf_bus_kernel_cpu.jl:1-121)
+ *   exaadmm_update_z/l/lz mpacopf_admm_update_{z,l,lz}_cpu.jl (ramp block included)
+ *   exaadmm_update_residual, exaadmm_norm_z   per-period norms incl. ramp block, MAX over periods
+ *                         (mpacopf_admm_update_residual_cpu.jl:1-55, mpacopf_admm_prepoststep_cpu.jl:1-22)
+ *   exaadmm_run_inner, exaadmm_solve_two_level  eps_pri / outer tolerance from mod.nvar = 2 ngen + 8 nline + ngen
+ *   exaadmm_objective     sum over periods (mpacopf_admm_prepoststep_cpu.jl:73)
+ * Pd, Qd: T x nbus, period-major (the columns of get_load, src/utils/opfdata.jl:121-130, one after another).
+ * exaadmm_update_x_gen is replaced by exaadmm_mp_update_x_gen (the ramp subproblem needs major_iter);
+ * the partition helpers (halo, masks, ctrl_*) are not available on a multi-period handle. */
+int exaadmm_mp_create(const exaadmm_grid *g, const exaadmm_params *p, int T, const double *Pd, const double *Qd,
+                      double ramp_ratio, int device_id, exaadmm_handle **out);
+int exaadmm_mp_periods(exaadmm_handle *h);
+int64_t exaadmm_mp_nvar(exaadmm_handle *h); /* mod.nvar of the reference */
+int exaadmm_mp_update_x_gen(exaadmm_handle *h, int major_iter); /* mpacopf_admm_update_x_cpu.jl:5-31 */
+/* SolutionRamping vectors (mpacopf_model.jl:1-38): T x ngen, period-major; block 0 (period 1) is unused.
+ * `which`: U_CURR (phat), L_CURR, RHO, RD, RP, Z_CURR, Z_PREV, LZ, AX_PLUS_BY, RAMP_S, RAMP_MU, RAMP_XI */
+int exaadmm_mp_download_ramp(exaadmm_handle *h, int which, double *host, int64_t n);
+int exaadmm_mp_upload_ramp(exaadmm_handle *h, int which, const double *host, int64_t n);
 
 /* ---- MATPOWER ingest (next row f1: utils/parse_matpower.jl, utils/opfdata.jl) ---- */
 int exaadmm_load_matpower(const char *path, double tight_factor, const char *case_format, exaadmm_case **out);

@@ -1,0 +1,202 @@
+"""GPU parity tests of the multi-period ACOPF model: the time-expanded HIP
+model, called through the C ABI, against the reference's own known answers
+(test/algorithms/mpacopf_update_cpu.jl via tests/golden/mpacopf_case9.json) and against the CPU
+oracle (oracle/mpacopf_oracle.c) on the same inputs.  Tolerances next to each assertion."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import CASE9, GOLDEN
+import exaadmm_loader
+
+pytestmark = pytest.mark.gpu
+
+G = json.load(open(os.path.join(GOLDEN, "mpacopf_case9.json")))
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    p = exaadmm_loader.load_package()
+    p.library()
+    return p
+
+
+@pytest.fixture(scope="module")
+def syn():
+    return exaadmm_loader.load_submodule("synthetic")
+
+
+def _case9_loads(grid):
+    sc = G["load_scaling"]
+    pd = np.stack([grid["Pd"] * a for a in sc["P"]], 1)
+    qd = np.stack([grid["Qd"] * a for a in sc["Q"]], 1)
+    return pd, qd
+
+
+def _check(mod, name, key, atol):
+    for t in range(3):
+        full = np.concatenate([G[key + "_GEN"][t], G[key + "_BR"][t]])
+        got = getattr(mod.models[t].solution, name)
+        assert np.abs(got - full).max() <= atol, (key, t, np.abs(got - full).max())
+
+
+def test_case9_three_periods_one_iteration_reference_known_answers(pkg):
+    """Same sequence and vectors as test/algorithms/mpacopf_update_cpu.jl:1-427, atol 1e-6."""
+    env = pkg.AdmmEnv(CASE9, 4e2, 4e4, verbose=0)
+    mod = pkg.ModelMpacopf(env, _case9_loads(env.data), end_period=3)
+    assert mod.nvar == 78 + 3 and mod.len_horizon == 3
+    env.params.scale, env.params.initial_beta, env.params.beta = 1e-4, 1e3, 1e3
+    pkg.admm_increment_outer(env, mod)
+    pkg.admm_outer_prestep(env, mod)
+    pkg.admm_increment_reset_inner(env, mod)
+    pkg.admm_increment_inner(env, mod)
+    pkg.admm_inner_prestep(env, mod)
+    atol = G["atol"] + 1e-9   # the reference test's tolerance; its literals are truncated at 6 decimals
+    pkg.admm_update_x(env, mod)
+    _check(mod, "u_curr", "U", atol)
+    pkg.admm_update_xbar(env, mod)
+    _check(mod, "v_curr", "V", atol)
+    pkg.admm_update_z(env, mod)
+    _check(mod, "z_curr", "Z", atol)
+    pkg.admm_update_l(env, mod)
+    _check(mod, "l_curr", "L", atol + 1e-6)
+    pkg.admm_update_residual(env, mod)
+    G3 = mod.ngen
+    for t in range(3):          # residual identities, mpacopf_update_cpu.jl:393-407
+        s = mod.models[t].solution
+        u, v, z, zp = s.u_curr, s.v_curr, s.z_curr, s.z_prev
+        assert np.abs(s.rp - (u - v + z)).max() <= atol
+        assert np.abs(s.rd - (z - zp)).max() <= atol
+        assert np.abs(s.Ax_plus_By - (u - v)).max() <= atol
+        if t > 0:
+            r = mod.solution[t]
+            vprev = mod.models[t - 1].solution.v_curr[0:2 * G3:2]
+            assert np.abs(r.rp - (r.u_curr - vprev + r.z_curr)).max() <= atol
+            assert np.abs(r.rd - (r.z_curr - r.z_prev)).max() <= atol
+            assert np.abs(r.Ax_plus_By - (r.u_curr - vprev)).max() <= atol
+    lz0 = [mod.models[t].solution.lz for t in range(3)]
+    rlz0 = [mod.solution[t].lz for t in range(3)]
+    pkg.admm_update_lz(env, mod)
+    for t in range(3):          # lz recurrence, :409-427
+        s = mod.models[t].solution
+        assert np.abs(s.lz - (lz0[t] + env.params.beta * s.z_curr)).max() <= atol
+        if t > 0:
+            r = mod.solution[t]
+            assert np.abs(r.lz - (rlz0[t] + env.params.beta * r.z_curr)).max() <= atol
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_case9_three_periods_full_solve_anchor(pkg, fused):
+    """mpacopf_update_cpu.jl:429-433: Solved, outer 20, cumul 729, objval 15901.48 (atol 1e-2)."""
+    a = G["solve"]
+    env = pkg.AdmmEnv(CASE9, 4e2, 4e4, verbose=0)
+    env2, mod = pkg.solve_mpacopf(CASE9, load=_case9_loads(env.data), end_period=3, warm_start=False,
+                                  outer_iterlim=a["outer_iterlim"], rho_pq=4e2, rho_va=4e4, outer_eps=a["outer_eps"],
+                                  fused=fused)
+    i = mod.info
+    assert i.status == "Solved"
+    assert i.outer == a["outer"]
+    assert i.cumul == a["cumul"]
+    assert abs(i.objval - a["objval"]) <= a["objval_atol"]
+
+
+def _oracle_mp(oracle, grid, pd, qd, rho_pq, rho_va, **kw):
+    og = {k: (np.asarray(v, dtype=np.int32) if isinstance(v, np.ndarray) and v.dtype == np.int64 else v) for k, v in grid.items()}
+    return oracle.OracleMpModel(og, pd, qd, rho_pq, rho_va, **kw)
+
+
+def test_multi_period_trajectory_matches_oracle(pkg, syn, oracle):
+    """Synthetic 118-bus-sized grid, T = 4 periods with different load levels: 12 step-wise inner
+    iterations, every vector (period blocks and ramp blocks) within 1e-8 of the CPU oracle."""
+    grid = syn.sized_like("case118", seed=3)
+    T = 4
+    rng = np.random.default_rng(5)
+    al = 1.0 + 0.02 * rng.standard_normal(T)
+    pd = np.stack([grid["Pd"] * a for a in al], 1)
+    qd = np.stack([grid["Qd"] * a for a in al], 1)
+    env = pkg.AdmmEnv("syn118", 1e1, 1e3, verbose=0, grid=grid)
+    mod = pkg.ModelMpacopf(env, (pd, qd), end_period=T, ramp_ratio=0.02)
+    env.params.scale, env.params.beta = 1e-4, 1e3
+    om = _oracle_mp(oracle, env.data, pd, qd, 1e1, 1e3, ramp_ratio=0.02, scale=1e-4)
+    om.par.beta = 1e3
+    Gn = mod.ngen
+    mod.info.inner = 0
+    for it in range(1, 13):
+        pkg.admm_increment_inner(env, mod)
+        pkg.admm_inner_prestep(env, mod); om.inner_prestep()
+        pkg.admm_update_x(env, mod); om.update_x(it)
+        pkg.admm_update_xbar(env, mod); om.update_xbar()
+        pkg.admm_update_z(env, mod); om.update_z()
+        pkg.admm_update_l(env, mod); om.update_l()
+        pkg.admm_update_residual(env, mod); ores = om.update_residual()
+        res = (mod.info.primres, mod.info.dualres, mod.info.norm_z_curr, mod.info.mismatch)
+        assert np.allclose(res, ores, rtol=1e-9, atol=1e-12), (it, res, ores)
+        if it in (1, 2, 6, 12):
+            for t in range(T):
+                for name in ("u_curr", "v_curr", "z_curr", "l_curr"):
+                    got = getattr(mod.models[t].solution, name)
+                    ref = om.periods[t].sol[name]
+                    scale_ = max(1.0, np.abs(ref).max())
+                    assert np.abs(got - ref).max() <= 1e-8 * scale_, (it, t, name, np.abs(got - ref).max())
+                if t > 0:
+                    for name in ("u_curr", "s_curr", "z_curr", "l_curr"):
+                        got = getattr(mod.solution[t], name)
+                        ref = om.ramp[t][name]
+                        assert np.abs(got - ref).max() <= 1e-8 * max(1.0, np.abs(ref).max()), (it, t, "ramp " + name)
+                    assert np.abs(mod.solution[t].mu - om.gen_membuf[t][:, 6]).max() <= 1e-6 * max(1.0, np.abs(om.gen_membuf[t][:, 6]).max())
+                    assert np.array_equal(mod.solution[t].xi, om.gen_membuf[t][:, 7])
+    # outer-loop pieces
+    pkg.admm_update_lz(env, mod); om.update_lz()
+    pkg.admm_outer_prestep(env, mod)
+    assert abs(mod.info.norm_z_prev - om.norm_z_prev()) <= 1e-9 * max(1.0, mod.info.norm_z_prev)
+    pkg.admm_poststep(env, mod)
+    assert abs(mod.info.objval - om.objective()) <= 1e-8 * abs(om.objective())
+
+
+def test_multi_period_fused_loop_matches_oracle(pkg, syn, oracle):
+    """Fused device-resident loop (hipGraph replay, device-side break test with the max-over-periods
+    norm): same inner-iteration counts as the oracle's admm_two_level over 3 outer iterations."""
+    grid = syn.sized_like("case118", seed=4)
+    T = 3
+    al = np.array([1.0, 1.01, 0.985])
+    pd = np.stack([grid["Pd"] * a for a in al], 1)
+    qd = np.stack([grid["Qd"] * a for a in al], 1)
+    env = pkg.AdmmEnv("syn118", 1e1, 1e3, verbose=0, grid=grid)
+    env2, mod = pkg.solve_mpacopf("syn118", load=(pd, qd), end_period=T, warm_start=False, outer_iterlim=3, inner_iterlim=400,
+                                  rho_pq=1e1, rho_va=1e3, grid=grid)
+    og = {k: (np.asarray(v, dtype=np.int32) if isinstance(v, np.ndarray) and v.dtype == np.int64 else v) for k, v in env.data.items()}
+    om = oracle.solve_mpacopf(og, pd, qd, outer_iterlim=3, inner_iterlim=400, rho_pq=1e1, rho_va=1e3, warm_start=False)
+    assert (mod.info.outer, mod.info.cumul) == (om.info.outer, om.info.cumul)
+    assert abs(mod.info.objval - om.info.objval) <= 1e-6 * abs(om.info.objval)     # north_star tolerance
+    assert abs(mod.info.mismatch - om.info.mismatch) <= 1e-6 * max(1.0, om.info.mismatch)
+    for t in range(T):
+        ref = om.periods[t].sol["u_curr"]
+        assert np.abs(mod.models[t].solution.u_curr - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max())
+
+
+def test_single_period_multi_period_handle_equals_plain_handle(pkg, syn):
+    """Edge: T = 1 has no ramp block and must reproduce the single-period model bit for bit."""
+    grid = syn.sized_like("case118", seed=1)
+    env = pkg.AdmmEnv("syn118", 1e1, 1e3, verbose=0, grid=grid)
+    pd, qd = env.data["Pd"][:, None], env.data["Qd"][:, None]
+    mp = pkg.ModelMpacopf(env, (pd, qd), end_period=1)
+    sp = pkg.ModelAcopf(env)
+    assert mp.nvar == sp.nvar
+    r1 = mp.run_fixed(15, first_major_iter=1, beta=1e3)[0]
+    r2 = sp.run_fixed(15, first_major_iter=1, beta=1e3)[0]
+    assert np.array_equal(r1, r2)
+    assert np.array_equal(mp.download("u_curr"), sp.download("u_curr"))
+
+
+def test_warm_start_path_runs_and_converges_like_cold(pkg):
+    """solve_mpacopf(warm_start=true): per-period solves first; only the line-limit multipliers
+    survive the re-initialisation (reference behaviour).  On case9 no line limit binds, so the
+    warm-started run must reproduce the cold anchor."""
+    a = G["solve"]
+    env = pkg.AdmmEnv(CASE9, 4e2, 4e4, verbose=0)
+    env2, mod = pkg.solve_mpacopf(CASE9, load=_case9_loads(env.data), end_period=3, warm_start=True,
+                                  outer_iterlim=a["outer_iterlim"], rho_pq=4e2, rho_va=4e4, outer_eps=a["outer_eps"])
+    assert mod.info.status == "Solved"
+    assert abs(mod.info.objval - a["objval"]) <= 1.0   # same optimum; iteration counts may differ by the carried multipliers

@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--full-solve", action="store_true",
                     help="also run a whole solve_acopf (outer 20 x inner 1000) and report cumul/time_overall; minutes on a non-converging instance")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU code path even with one rank")
+    ap.add_argument("--periods", type=int, default=1,
+                    help="T > 1: multi-period ACOPF (SURVEY.md §8 f4) over T load levels of the same grid, one time-expanded device model")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -110,7 +112,15 @@ def main():
     G, L, B = int(grid["ngen"]), int(grid["nline"]), int(grid["nbus"])
 
     env = pkg.AdmmEnv(args.case, params["rho_pq"], params["rho_va"], tight_factor=0.99, gpu_no=0, verbose=0, grid=grid)
-    mod = pkg.ModelAcopf(env)
+    T = max(1, args.periods)
+    if T > 1:
+        import numpy as np
+        lvl = 1.0 + 0.01 * np.sin(np.arange(T) * 2 * np.pi / max(T, 2))   # smooth load profile, +-1 %
+        mp_load = (np.stack([env.data["Pd"] * a for a in lvl], 1), np.stack([env.data["Qd"] * a for a in lvl], 1))
+        mod = pkg.ModelMpacopf(env, mp_load, end_period=T)
+        workload += "-x%d-periods" % T
+    else:
+        mod = pkg.ModelAcopf(env)
     env.params.scale = params["scale"]
     mod.sync_params()
     beta = env.params.initial_beta
@@ -125,7 +135,11 @@ def main():
     dt = time.perf_counter() - t0
 
     its = args.steps / dt
-    a_it, m_it = mod.branch_stats()
+    if T > 1:
+        a_it = m_it = float("nan")
+        G, L, B = G * T, L * T, B * T   # algorithmic bytes of the time-expanded model (ramp block: +88 B per generator and period)
+    else:
+        a_it, m_it = mod.branch_stats()
     # HBM traffic of the dominant kernel from the PMC passes committed under profiles/ (collected
     # with rocprofv3 on this same command; bench.py itself cannot collect counters)
     traffic = None
@@ -160,7 +174,25 @@ def main():
         i2 = mod2.info
         out["full_solve"] = {"status": i2.status, "outer": i2.outer, "cumul": i2.cumul, "time_overall_s": i2.time_overall,
                              "iterations_per_s": i2.cumul / i2.time_overall, "objval": i2.objval, "mismatch": i2.mismatch}
-    if not args.no_cpu_baseline:
+    if T > 1:
+        out["config"]["periods"] = T
+        out["config"]["mode"] = "multi-period ACOPF (ModelMpacopf), fixed-count inner iterations"
+    if not args.no_cpu_baseline and T > 1:
+        from oracle import oracle as O
+        om = O.OracleMpModel(grid, mp_load[0], mp_load[1], params["rho_pq"], params["rho_va"], scale=params["scale"])
+        om.par.beta = beta
+        n_done, t_used, it = 0, 0.0, 0
+        while t_used < 15.0 and n_done < 200:
+            it += 1
+            t1 = time.perf_counter()
+            om.inner_prestep(); om.update_x(it); om.update_xbar(); om.update_z(); om.update_l(); om.update_residual()
+            if it > 2:
+                t_used += time.perf_counter() - t1
+                n_done += 1
+        out["cpu_baseline"] = {"value": n_done / t_used, "unit": "ADMM inner iterations/s", "cores": 1, "kind": "port",
+                               "sample": "%d inner iterations (after 2 warm-up) of the same %d-period model, serial C oracle, %.1f s" % (n_done, T, t_used)}
+        out["speedup_vs_cpu_baseline"] = its / out["cpu_baseline"]["value"]
+    elif not args.no_cpu_baseline:
         cb = cpu_baseline(grid, params)
         out["cpu_baseline"] = cb
         out["speedup_vs_cpu_baseline"] = its / cb["value"]

@@ -158,3 +158,82 @@ function solve_acopf_hip(case::String; case_format="matpower", outer_iterlim=20,
     end
     return env, mod
 end
+
+# ---------------------------------------------------------------------------------------------------
+# Multi-period ACOPF (ModelMpacopf, models/mpacopf/mpacopf_model.jl:40-112): ONE time-expanded device
+# model (exaadmm_mp_create).  The reference's generic driver runs unchanged: every admm_* method above
+# is typed on AbstractOPFModel and therefore also serves ModelMpacopf with a HipNative device -- the
+# library applies the multi-period semantics (ramp subproblems, ramp terms of the bus update, ramp
+# blocks of z/l/lz, max-over-periods residual norms, eps_pri from mod.nvar) behind the same entry points.
+# Counters: mpacopf_admm_increment.jl types its methods `device::Nothing`, so with a HipNative device the
+# 3-argument calls of admm_two_level fall through to the generic AbstractOPFModel methods
+# (acopf_admm_increment.jl), which update mod.info -- all the library needs.
+"Device model of a CPU-typed ModelMpacopf; loads come from the periods' grid_data (mpacopf_model.jl:77-80)."
+function HipNative(env::AdmmEnv, mod::ModelMpacopf; gpu_no::Int=0)
+    d = mod.models[1].grid_data
+    T = mod.len_horizon
+    pd = reduce(vcat, [mod.models[i].grid_data.Pd for i in 1:T])   # T x nbus, period-major
+    qd = reduce(vcat, [mod.models[i].grid_data.Qd for i in 1:T])
+    g = ExaadmmGrid(d.ngen, d.nline, d.nbus, 1, d.baseMVA,
+        pointer(d.pgmin), pointer(d.pgmax), pointer(d.qgmin), pointer(d.qgmax), pointer(d.c2), pointer(d.c1), pointer(d.c0),
+        pointer(d.YffR), pointer(d.YffI), pointer(d.YftR), pointer(d.YftI), pointer(d.YttR), pointer(d.YttI),
+        pointer(d.YtfR), pointer(d.YtfI), pointer(d.FrVmBound), pointer(d.ToVmBound), pointer(d.FrVaBound),
+        pointer(d.ToVaBound), pointer(d.rateA), pointer(d.brBusIdx), pointer(d.Pd), pointer(d.Qd), pointer(d.Vmin),
+        pointer(d.Vmax), pointer(d.YshR), pointer(d.YshI), pointer(d.FrStart), pointer(d.FrIdx), pointer(d.ToStart),
+        pointer(d.ToIdx), pointer(d.GenStart), pointer(d.GenIdx), 0, 0)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    p = to_params(env.params)
+    GC.@preserve d pd qd begin
+        hipcheck(ccall((:exaadmm_mp_create, libexaadmm_hip), Cint,
+                       (Ref{ExaadmmGrid}, Ref{ExaadmmParams}, Cint, Ptr{Float64}, Ptr{Float64}, Cdouble, Cint, Ref{Ptr{Cvoid}}),
+                       g, p, T, pd, qd, mod.ramp_ratio, gpu_no, h), "exaadmm_mp_create")
+    end
+    dev = HipNative(h[])
+    finalizer(x -> ccall((:exaadmm_destroy, libexaadmm_hip), Cint, (Ptr{Cvoid},), x.handle), dev)
+    hipcheck(ccall((:exaadmm_init_solution, libexaadmm_hip), Cint, (Ptr{Cvoid}, Cdouble, Cdouble),
+                   dev.handle, env.initial_rho_pq, env.initial_rho_va), "exaadmm_init_solution")
+    return dev
+end
+
+"Copy the device state back into mod.models[i].solution / mod.solution[i] (reference layouts)."
+function download!(dev::HipNative, mod::ModelMpacopf)
+    T = mod.len_horizon; G = mod.models[1].grid_data.ngen; L = mod.models[1].grid_data.nline
+    n = T * (2G + 8L)
+    buf = zeros(n); rbuf = zeros(T * G)
+    for (id, f) in ((0, :u_curr), (1, :v_curr), (2, :l_curr), (3, :rho), (6, :z_curr), (7, :z_prev), (8, :lz))
+        hipcheck(ccall((:exaadmm_download_solution, libexaadmm_hip), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Int64),
+                       dev.handle, id, buf, n), "exaadmm_download_solution")
+        for t in 1:T   # expanded layout: [gens of all periods | lines of all periods]
+            v = getfield(mod.models[t].solution, f)
+            v[1:2G] .= buf[2G*(t-1)+1:2G*t]
+            v[2G+1:2G+8L] .= buf[2G*T+8L*(t-1)+1:2G*T+8L*t]
+        end
+        if f != :v_curr
+            hipcheck(ccall((:exaadmm_mp_download_ramp, libexaadmm_hip), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Int64),
+                           dev.handle, id, rbuf, T * G), "exaadmm_mp_download_ramp")
+            for t in 2:T
+                getfield(mod.solution[t], f) .= rbuf[G*(t-1)+1:G*t]
+            end
+        end
+    end
+    hipcheck(ccall((:exaadmm_mp_download_ramp, libexaadmm_hip), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Int64),
+                   dev.handle, 20, rbuf, T * G), "exaadmm_mp_download_ramp")   # s_curr
+    for t in 2:T
+        mod.solution[t].s_curr .= rbuf[G*(t-1)+1:G*t]
+    end
+end
+
+"solve_mpacopf with the MI355X backend; keyword surface of interface/solve_mpacopf.jl:1-6 (warm_start=false)."
+function solve_mpacopf_hip(case::String, load_prefix::String; case_format="matpower", start_period=1, end_period=1,
+        outer_iterlim=20, inner_iterlim=1000, rho_pq=400.0, rho_va=40000.0, obj_scale=1.0, scale=1e-4,
+        tight_factor=1.0, outer_eps=2e-4, gpu_no=0, verbose=1, ramp_ratio=0.02)
+    T = Float64; TD = Array{Float64,1}; TI = Array{Int,1}; TM = Array{Float64,2}
+    env = AdmmEnv{T,TD,TI,TM}(case, rho_pq, rho_va; case_format=case_format, use_gpu=false,
+                              load_prefix=load_prefix, tight_factor=tight_factor, verbose=verbose)
+    mod = ModelMpacopf{T,TD,TI,TM}(env; start_period=start_period, end_period=end_period, ramp_ratio=ramp_ratio)
+    env.params.scale = scale; env.params.obj_scale = obj_scale; env.params.outer_eps = outer_eps
+    env.params.outer_iterlim = outer_iterlim; env.params.inner_iterlim = inner_iterlim
+    dev = HipNative(env, mod; gpu_no=gpu_no)
+    admm_two_level(env, mod, dev)      # the reference's driver; admm_poststep downloads
+    return env, mod
+end

@@ -171,16 +171,14 @@ EXA_HD void quad_model(const MA& A, const double (&g)[N], const double (&s)[N], 
 }
 
 // Cauchy step (TRON dcauchy).  alpha persists across calls.
+// The break points are only needed by the extrapolation branch and are computed there.  (||s|| must be
+// compared with delta as a norm, not as squares: delta is often exactly the norm of the previous step,
+// so ties are structural and a squared comparison flips them.)
 template <int N, class MA>
 EXA_BIG void cauchy(const double (&x)[N], const double (&xl)[N], const double (&xu)[N], const MA& A,
                    const double (&g)[N], double delta, double& alpha, double (&s)[N])
 {
     const double mu0 = 0.01, interpf = 0.1, extrapf = 10.0;
-    double mg[N];
-    EXA_UNROLL
-    for (int i = 0; i < N; i++) mg[i] = -g[i];
-    double brptmin, brptmax;
-    breakpt<N>(x, xl, xu, mg, brptmin, brptmax);
 
     bool interp;
     gpstep<N>(x, xl, xu, -alpha, g, s);
@@ -205,6 +203,11 @@ EXA_BIG void cauchy(const double (&x)[N], const double (&xl)[N], const double (&
             }
         }
     } else {
+        double mg[N];
+        EXA_UNROLL
+        for (int i = 0; i < N; i++) mg[i] = -g[i];
+        double brptmin, brptmax;
+        breakpt<N>(x, xl, xu, mg, brptmin, brptmax);
         bool search = true;
         double alphas = alpha;
         for (int guard = 0; search && alpha <= brptmax && guard < 400; guard++) {
@@ -411,10 +414,11 @@ EXA_BIG int trpcg_masked(unsigned fr, const MA& A, const double (&gf)[N], double
     for (int i = 0; i < N; i++) p[i] = r[i];
 
     double rho = dot<N>(r, r);
-    if (sqrt(rho) == 0.0) {
+    if (rho == 0.0) {
         iters_out = 0;
         return 1;
     }
+    const double tol2 = tol * tol, stol2 = stol * stol;   // norms are only compared: use squares
 
     for (int iters = 1; iters <= itermax; iters++) {
         EXA_UNROLL
@@ -443,13 +447,11 @@ EXA_BIG int trpcg_masked(unsigned fr, const MA& A, const double (&gf)[N], double
             t[i] = fma(-alpha, z[i], t[i]);
         }
         double rtr = dot<N>(r, r);
-        double rnorm = sqrt(rtr);
-        double tnorm = nrm2<N>(t);
-        if (tnorm <= tol) {
+        if (dot<N>(t, t) <= tol2) {
             iters_out = iters;
             return 1;
         }
-        if (rnorm <= stol) {
+        if (rtr <= stol2) {
             iters_out = iters;
             return 2;
         }
@@ -560,9 +562,7 @@ EXA_BIG void spcg(double (&x)[N], const double (&xl)[N], const double (&xu)[N], 
             double gi = ((fr >> i) & 1u) ? (w[i] + g[i]) : 0.0;
             gn2 += gi * gi;
         }
-        double gfnormf = sqrt(gn2);
-
-        if (gfnormf <= rtol * gfnorm) return;
+        if (gn2 <= (rtol * rtol) * gfn2) return;   // ||g_free(new)|| <= rtol ||g_free||, compared as squares
         if (infotr == 3 || infotr == 4) return;
         if (iters > itermax) return;
     }

@@ -906,7 +906,10 @@ static void launch_branch(exaadmm_handle* h, int major_iter, const Ctrl* c, bool
     }
     const int nb = (int)grid_for(h->d.La, BR_BLOCK).x;
     const int ng = (with_generators && h->G > 0) ? (int)grid_for(h->G, BR_BLOCK).x : 0;
-    hipLaunchKernelGGL(k_branch, dim3(nb + ng), dim3(BR_BLOCK), 0, h->stream, h->d_dev, h->bo, h->par.scale, major_iter, c, ng, h->baseMVA);
+    if (h->T > 1)
+        hipLaunchKernelGGL((k_branch_t<true>), dim3(nb + ng), dim3(BR_BLOCK), 0, h->stream, h->d_dev, h->bo, h->par.scale, major_iter, c, ng, h->baseMVA);
+    else
+        hipLaunchKernelGGL((k_branch_t<false>), dim3(nb + ng), dim3(BR_BLOCK), 0, h->stream, h->d_dev, h->bo, h->par.scale, major_iter, c, ng, h->baseMVA);
 }
 static void launch_bus(exaadmm_handle* h, const Ctrl* c)
 {
@@ -1187,8 +1190,7 @@ extern "C" int exaadmm_debug_wave_timeline(exaadmm_handle* h, unsigned long long
 static void enqueue_iteration(exaadmm_handle* h, Ctrl* c, bool sample = false)
 {
     if (sample) (void)hipEventRecord(h->tev[0], h->stream);
-    if (h->T > 1) launch_gen(h, c);           // multi-period: ramp subproblems need their own kernel
-    launch_branch(h, 0, c, h->T == 1);        // single-period: generators ride in the same launch
+    launch_branch(h, 0, c, true);   // generators (multi-period: ramp subproblems) ride in the same launch
     if (sample) (void)hipEventRecord(h->tev[1], h->stream);
     launch_bus(h, c);
     if (sample) (void)hipEventRecord(h->tev[2], h->stream);
@@ -1335,9 +1337,8 @@ extern "C" int exaadmm_run_fixed(exaadmm_handle* h, int iters, int first_major_i
     h->residual_vectors_valid = false;
     HIPCHK(hipEventRecord(h->ev[0], h->stream));
     for (int i = 0; i < iters; i++) {
-        if (h->T > 1) launch_gen(h, nullptr, first_major_iter + i);
         if (time_branch) HIPCHK(hipEventRecord(h->ev[2 + 2 * i], h->stream));
-        launch_branch(h, first_major_iter + i, nullptr, h->T == 1);
+        launch_branch(h, first_major_iter + i, nullptr, true);
         if (time_branch) HIPCHK(hipEventRecord(h->ev[3 + 2 * i], h->stream));
         launch_bus(h, nullptr);
         launch_fused_zl(h, beta, nullptr);

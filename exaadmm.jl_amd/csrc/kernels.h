@@ -85,13 +85,8 @@ __global__ void k_generator(Dev d, double baseMVA, const Ctrl* ctrl)
 // form; a generator of period t >= 1 solves the 3-variable ramp subproblem (p_t, phat_{t-1}, s_t)
 // by augmented Lagrangian x TRON (auglag_generator_kernel, mpacopf_auglag_generator_kernel_cpu.jl),
 // one lane per generator and period.
-__global__ void __launch_bounds__(64) k_gen_ramp(Dev d, BranchOptions o, double baseMVA, int major_iter, const Ctrl* ctrl)
+__device__ __forceinline__ void gen_ramp_lane(const Dev& d, const BranchOptions& o, double baseMVA, int major_iter, int i)
 {
-    if (ctrl != nullptr) {
-        if (ctrl->done) return;
-        major_iter = ctrl->inner + 1;
-    }
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= d.G) return;
     if (i < d.g1) {
         generator_update(d, baseMVA, i);
@@ -129,6 +124,15 @@ __global__ void __launch_bounds__(64) k_gen_ramp(Dev d, BranchOptions o, double 
     d.r_xi[i] = gd.xi;
 }
 
+__global__ void __launch_bounds__(64) k_gen_ramp(Dev d, BranchOptions o, double baseMVA, int major_iter, const Ctrl* ctrl)
+{
+    if (ctrl != nullptr) {
+        if (ctrl->done) return;
+        major_iter = ctrl->inner + 1;
+    }
+    gen_ramp_lane(d, o, baseMVA, major_iter, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
 // ---------------------------------------------------------------- branch
 // auglag_linelimit_two_level_alternative (acopf_auglag_linelimit_kernel_gpu.jl:1-151):
 // one lane per branch, 64 branches per wavefront.  Per lane, the 32 read-only problem constants
@@ -148,8 +152,11 @@ constexpr int BR_LDS_DOUBLES = BR_LDS_CONST;
 
 // The Dev block is read through a pointer (not by-value kernel arguments): its ~40 pointers would
 // otherwise sit in SGPRs across the whole solver and spill.
-__global__ void __launch_bounds__(BR_BLOCK) k_branch(const Dev* __restrict__ dp, BranchOptions o, double scale, int major_iter, const Ctrl* ctrl,
-                                                     int gen_blocks, double baseMVA)
+// MP = true: the generator blocks solve the ramp subproblems of the multi-period model (separate
+// instantiation so that the single-period kernel's code and register allocation stay untouched).
+template <bool MP>
+__global__ void __launch_bounds__(BR_BLOCK) k_branch_t(const Dev* __restrict__ dp, BranchOptions o, double scale, int major_iter, const Ctrl* ctrl,
+                                                       int gen_blocks, double baseMVA)
 {
     __shared__ double lds[BR_LDS_DOUBLES * BR_BLOCK];
     const Dev& d = *dp;
@@ -161,7 +168,11 @@ __global__ void __launch_bounds__(BR_BLOCK) k_branch(const Dev* __restrict__ dp,
     // launch and one inter-kernel gap less per iteration).  gen_blocks = 0: branches only.
     const int nbr_blocks = gridDim.x - gen_blocks;
     if ((int)blockIdx.x >= nbr_blocks) {
-        generator_update(d, baseMVA, ((int)blockIdx.x - nbr_blocks) * BR_BLOCK + threadIdx.x);
+        const int gi = ((int)blockIdx.x - nbr_blocks) * BR_BLOCK + threadIdx.x;
+        if (MP)   // multi-period model: ramp subproblems run beside the branch solves, same launch
+            gen_ramp_lane(d, o, baseMVA, major_iter, gi);
+        else
+            generator_update(d, baseMVA, gi);
         return;
     }
     const int slot = blockIdx.x * BR_BLOCK + threadIdx.x;

@@ -32,8 +32,15 @@ print("identity        : k_branch %.4f ms  iter %.4f ms primres %.12f" % r)
 restore(); mod.set_branch_lane_order(None); mod.run_fixed(1, first_major_iter=start + 1, beta=1e3)
 a, m, t = mod.branch_counters()
 print("ticks hist", np.bincount(np.minimum(t, 12)), "auglag hist", np.bincount(np.minimum(a, 8)))
-for key_name, key in (("ticks", t.astype(np.int64)), ("ticks,minor", t.astype(np.int64) * 1000 + m), ("auglag,ticks", a.astype(np.int64) * 1000 + t),
-                      ("random", np.random.default_rng(0).permutation(len(t)))):
+# device position of a branch (bus-sorted storage): keep it as the secondary key so that lanes of one
+# bucket still read (mostly) consecutive plane elements
+fr = np.asarray(env.data["brBusIdx"]).reshape(-1, 2)[:, 0]
+pos = np.empty(len(fr), dtype=np.int64); pos[np.argsort(fr, kind="stable")] = np.arange(len(fr))
+wmax = lambda order: np.maximum.reduceat(t[order], np.arange(0, len(t), 64)).sum()
+print("sum over waves of max ticks: identity(device order) %d, sorted by ticks %d, mean ticks x waves %.0f" % (
+    wmax(np.argsort(pos)), wmax(np.argsort(t.astype(np.int64) * (1 << 32) + pos)), t.mean() * len(t) / 64))
+for key_name, key in (("ticks,pos", t.astype(np.int64) * (1 << 32) + pos), ("-ticks,pos", (1000 - t.astype(np.int64)) * (1 << 32) + pos),
+                      ("-min(ticks,8),pos", (1000 - np.minimum(t.astype(np.int64), 8)) * (1 << 32) + pos),                       ):
     order = np.argsort(key, kind="stable")
     r = run(order)
     print("sorted by %-12s: k_branch %.4f ms  iter %.4f ms primres %.12f" % ((key_name,) + r))

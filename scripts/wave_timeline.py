@@ -27,10 +27,12 @@ for rep in range(3):
     act = (tl >> np.uint64(56)).astype(np.int64)
     nt = (clk > 0).sum(axis=1) - 1          # ticks of the wave
     dur = np.array([clk[w, nt[w]] - clk[w, 0] for w in range(nw)])
-    t0 = clk[:, 0].min()
+    t0 = clk[:, 0][clk[:, 0] > 0].min()
     end = np.array([clk[w, nt[w]] for w in range(nw)]).max()
-    print("k_branch %.3f ms | waves %d | wave ticks median %d max %d | wave duration median %.0f max %.0f cycles | first start..last end %.0f cycles"
-          % (msb, nw, np.median(nt), nt.max(), np.median(dur), dur.max(), end - t0))
+    span = float(end - t0)
+    print("k_branch %.3f ms | waves %d | wave ticks median %d max %d | wave duration median %.0f mean %.0f max %.0f clocks | first start..last end %.0f clocks "
+          "(%.2f GHz if that is the kernel time) | sum of wave durations / (1024 SIMDs x span) = %.2f"
+          % (msb, nw, np.median(nt), nt.max(), np.median(dur), dur.mean(), dur.max(), span, span / (msb * 1e6), dur.sum() / (1024.0 * span)))
     # per tick index: mean active lanes and mean cost, over all waves that reach it
     print("  tick: waves, mean active lanes, mean cycles")
     for k in list(range(0, 12)) + [15, 20, 25, 30, 40]:

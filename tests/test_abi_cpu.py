@@ -114,6 +114,23 @@ def test_argument_errors_are_reported_not_thrown(pkg):
     assert L.exaadmm_nvar(None) == -1
     assert L.exaadmm_destroy(None) == 0
     assert L.exaadmm_version().decode().startswith("exaadmm-hip")
+    # multi-period entry points: same convention
+    assert L.exaadmm_mp_create(C.byref(g), C.byref(p), 3, None, None, 0.02, 0, C.byref(h)) == -1
+    assert b"null argument" in L.exaadmm_last_error()
+    assert L.exaadmm_mp_periods(None) == -1 and L.exaadmm_mp_nvar(None) == -1
+    assert L.exaadmm_mp_update_x_gen(None, 1) == -1
+    assert L.exaadmm_mp_download_ramp(None, 0, None, 0) == -1
+
+
+def test_multi_period_model_fails_loudly_without_gpu(pkg):
+    """no CPU path for the multi-period model either"""
+    import numpy as np
+    env = pkg.AdmmEnv(CASE9, 4e2, 4e4, verbose=0)
+    load = (np.tile(env.data["Pd"][:, None], (1, 3)), np.tile(env.data["Qd"][:, None], (1, 3)))
+    with pytest.raises(pkg.ExaAdmmError, match="no HIP device|no CPU fallback"):
+        pkg.ModelMpacopf(env, load, end_period=3)
+    with pytest.raises(pkg.ExaAdmmError, match="out of range"):
+        pkg.ModelMpacopf(env, load, start_period=2, end_period=5)
 
 
 def test_dead_reference_options_are_rejected(pkg):

@@ -200,3 +200,29 @@ def test_warm_start_path_runs_and_converges_like_cold(pkg):
                                   outer_iterlim=a["outer_iterlim"], rho_pq=4e2, rho_va=4e4, outer_eps=a["outer_eps"])
     assert mod.info.status == "Solved"
     assert abs(mod.info.objval - a["objval"]) <= 1.0   # same optimum; iteration counts may differ by the carried multipliers
+
+
+def test_ramp_vectors_round_trip_and_two_periods(pkg):
+    """Edge: T = 2 (one ramp block) and upload / download of the SolutionRamping vectors."""
+    env = pkg.AdmmEnv(CASE9, 4e2, 4e4, verbose=0)
+    pd, qd = _case9_loads(env.data)
+    mod = pkg.ModelMpacopf(env, (pd[:, :2], qd[:, :2]), end_period=2)
+    assert mod.len_horizon == 2 and mod.nvar == 78 + 3
+    rng = np.random.default_rng(0)
+    for name in ("u_curr", "s_curr", "z_curr", "l_curr", "lz", "mu"):
+        a = rng.standard_normal(2 * mod.ngen)
+        mod.upload_ramp(name, a)
+        assert np.array_equal(mod.download_ramp(name), a)
+    # init_solution! resets the ramp vectors but not gen_membuf (multiplier / penalty), like the reference
+    mu = mod.download_ramp("mu")
+    mod.init_solution()
+    assert np.array_equal(mod.download_ramp("mu"), mu)
+    assert np.all(mod.download_ramp("z_curr") == 0.0)
+    vprev = mod.models[0].solution.v_curr[0:2 * mod.ngen:2]
+    assert np.array_equal(mod.solution[1].u_curr, vprev)
+    assert np.array_equal(mod.solution[1].s_curr, -vprev)
+    # a short two-period solve still converges to the sum of two nearly identical single-period optima
+    env2, m2 = pkg.solve_mpacopf(CASE9, load=(pd[:, :2], qd[:, :2]), end_period=2, warm_start=False, outer_iterlim=25,
+                                 rho_pq=4e2, rho_va=4e4, outer_eps=2e-5)
+    assert m2.info.status == "Solved"
+    assert abs(m2.info.objval - 2 * 5303.4) <= 0.01 * 2 * 5303.4

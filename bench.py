@@ -136,7 +136,7 @@ def main():
 
     its = args.steps / dt
     if T > 1:
-        a_it = m_it = float("nan")
+        a_it = m_it = None   # branch counters of the time-expanded model are not broken down per period
         G, L, B = G * T, L * T, B * T   # algorithmic bytes of the time-expanded model (ramp block: +88 B per generator and period)
     else:
         a_it, m_it = mod.branch_stats()

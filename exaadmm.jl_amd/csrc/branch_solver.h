@@ -37,6 +37,18 @@ struct BranchData {
     EXA_HD double Y(int k) const { return Y_[k]; }
 };
 
+// hybrid: multipliers / penalties / targets in registers, the 8 admittance entries in LDS planes
+template <int STRIDE>
+struct BranchDataYRef {
+    double lam_[8], rho_[8], xt_[8];
+    const double* yp;
+    double ls1, ls2, mu, scale;
+    EXA_HD double lam(int k) const { return lam_[k]; }
+    EXA_HD double rho(int k) const { return rho_[k]; }
+    EXA_HD double xt(int k) const { return xt_[k]; }
+    EXA_HD double Y(int k) const { return yp[k * STRIDE]; }
+};
+
 template <int STRIDE>
 struct BranchDataRef {
     const double* p;  // 32 entries: lam[8] rho[8] xt[8] Y[8]
@@ -307,8 +319,7 @@ struct BranchStats {
 // Work that the reference repeats and this loop does not (same operations on the same inputs, so
 // the same bits): sin/cos and the flows are evaluated once per point, by the objective evaluation
 // of the trial point, and carried with it (phi/scs accepted, phit/scst trial); f is recomputed only
-// when the multipliers changed (new subproblem), and the Hessian only when the projected-gradient
-// test did not end the TRON solve.
+// when the multipliers changed (new subproblem).
 template <class D, class MA, class ML>
 EXA_HD void branch_solve(D& d, const BranchOptions& o, const MuPowTable& pw, double (&x)[6], const double (&xl)[6],
                          const double (&xu)[6], MA& A, ML& L, double (&phi)[4], BranchStats& stats)
@@ -351,6 +362,13 @@ EXA_HD void branch_solve(D& d, const BranchOptions& o, const MuPowTable& pw, dou
             // ONE evaluation site for both cases (a second inlined copy would be executed one after
             // the other whenever a wavefront holds lanes of both kinds)
             branch_g(d, x, phi, scs, g, gp);
+#if !defined(EXA_LAZY_H)
+            // The Hessian is assembled with every gradient although the last evaluation of a TRON solve
+            // does not need it: deferring it behind the projected-gradient test keeps ~50 intermediates
+            // alive across the test (+90 registers at the kernel's pressure peak -> scratch spills) and
+            // measures 7 % SLOWER (-DEXA_LAZY_H).
+            branch_h(d, x, gp, A);
+#endif
             if (restart) {
                 // task START: f, g, H at x; delta0 = ||g||  (tron_linelimit_kernel.jl:66-106)
                 it++;
@@ -372,7 +390,9 @@ EXA_HD void branch_solve(D& d, const BranchOptions& o, const MuPowTable& pw, dou
         unsigned long long t1 = EXA_TICK();
         stats.cyc[0] += t1 - t0;
         if (fin == TRON_RUN) {
+#if defined(EXA_LAZY_H)
             if (refresh) branch_h(d, x, gp, A);
+#endif
             tron_compute<6>(st, x, xl, xu, A, L, g, o.cgtol, 6);
             unsigned long long t2 = EXA_TICK();
             stats.cyc[1] += t2 - t1;

@@ -135,17 +135,25 @@ __global__ void __launch_bounds__(64) k_gen_ramp(Dev d, BranchOptions o, double 
 
 // ---------------------------------------------------------------- branch
 // auglag_linelimit_two_level_alternative (acopf_auglag_linelimit_kernel_gpu.jl:1-151):
-// one lane per branch, 64 branches per wavefront.  Per lane, the 32 read-only problem constants
-// (l, rho, v-z, Y) are staged in LDS as [entry][lane] planes (16 KB per wavefront, every access
-// conflict-free and with a compile-time offset); the packed 6x6 Hessian, its Cholesky factor and
-// all vectors / scalars of the solver are registers.  (The reference keeps 1728 B of shared memory
-// per BRANCH and one 32-thread block per branch.)  -DEXA_A_IN_LDS / -DEXA_L_IN_LDS move the
-// matrices to LDS planes as well (6 % slower; kept for bisecting compiler trouble).
+// one lane per branch, 64 branches per wavefront.  Everything a lane needs -- the 32 read-only problem
+// constants (l, rho, v-z, Y), the packed 6x6 Hessian, its Cholesky factor and all vectors / scalars of
+// the solver -- lives in registers (256 VGPR + AGPR spill space, one wave per SIMD); the kernel uses no
+// LDS.  (The reference keeps 1728 B of shared memory per BRANCH and one 32-thread block per branch.)
+// Build variants kept for A/B runs and for bisecting compiler trouble: -DEXA_CONST_IN_LDS stages the
+// constants in LDS as [entry][lane] planes (16 KB per wavefront, conflict-free, compile-time offsets;
+// 3-15 % slower), -DEXA_A_IN_LDS / -DEXA_L_IN_LDS move the matrices there as well (another 6 %).
+#if !defined(EXA_CONST_IN_LDS) && !defined(EXA_A_IN_LDS) && !defined(EXA_L_IN_LDS) && !defined(EXA_CONST_IN_REGS)
+#define EXA_CONST_IN_REGS 1
+#endif
 constexpr int BR_LDS_CONST = 32, BR_LDS_MAT = 21;
 #if defined(EXA_A_IN_LDS) && defined(EXA_L_IN_LDS)
 constexpr int BR_LDS_DOUBLES = BR_LDS_CONST + 2 * BR_LDS_MAT;
 #elif defined(EXA_A_IN_LDS) || defined(EXA_L_IN_LDS)
 constexpr int BR_LDS_DOUBLES = BR_LDS_CONST + BR_LDS_MAT;
+#elif defined(EXA_Y_IN_LDS)
+constexpr int BR_LDS_DOUBLES = 8;
+#elif defined(EXA_CONST_IN_REGS)
+constexpr int BR_LDS_DOUBLES = 0;
 #else
 constexpr int BR_LDS_DOUBLES = BR_LDS_CONST;
 #endif
@@ -158,7 +166,11 @@ template <bool MP>
 __global__ void __launch_bounds__(BR_BLOCK) k_branch_t(const Dev* __restrict__ dp, BranchOptions o, double scale, int major_iter, const Ctrl* ctrl,
                                                        int gen_blocks, double baseMVA)
 {
-    __shared__ double lds[BR_LDS_DOUBLES * BR_BLOCK];
+#if defined(EXA_CONST_IN_REGS) && !defined(EXA_A_IN_LDS) && !defined(EXA_L_IN_LDS) && !defined(EXA_Y_IN_LDS)
+    double* const lds = nullptr;   // no LDS at all in the default build
+#else
+    __shared__ double lds[(BR_LDS_DOUBLES > 0 ? BR_LDS_DOUBLES : 1) * BR_BLOCK];
+#endif
     const Dev& d = *dp;
     if (ctrl != nullptr) {
         if (ctrl->done) return;
@@ -177,16 +189,28 @@ __global__ void __launch_bounds__(BR_BLOCK) k_branch_t(const Dev* __restrict__ d
     }
     const int slot = blockIdx.x * BR_BLOCK + threadIdx.x;
     if (slot >= d.La) return;
-    // lanes of a wavefront execute the union of their control paths: grouping branches that took
-    // similar paths in the previous ADMM iteration (lane_order, refreshed by the host side) cuts
-    // that divergence; which lane solves a branch does not change any result.
+    // which lane solves a branch does not change any result; lane_order exists for experiments
+    // (regrouping lanes by work does not pay in either regime)
     const int b = d.lane_order ? d.lane_order[slot] : slot;
     const int Lp = d.Lp;
     const int base = 2 * d.Gp + b;
     double* my = lds + threadIdx.x;
 
     double ub[8], bnd[8];
-#if defined(EXA_CONST_IN_REGS)
+#if defined(EXA_Y_IN_LDS)
+    BranchDataYRef<BR_BLOCK> bd;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int e = base + k * Lp;
+        ub[k] = d.u[e];
+        bd.lam_[k] = d.l[e];
+        bd.rho_[k] = d.rho[e];
+        bd.xt_[k] = d.v[e] - d.z[e];
+        my[k * BR_BLOCK] = d.Y[b + k * Lp];
+        bnd[k] = d.bnd[b + k * Lp];
+    }
+    bd.yp = my;
+#elif defined(EXA_CONST_IN_REGS)
     BranchData bd;
 #pragma unroll
     for (int k = 0; k < 8; k++) {

@@ -398,16 +398,19 @@ EXA_HD void mask_vec(unsigned fr, double (&v)[N])
 
 // Preconditioned CG on the free block inside || L' w || <= delta  (TRON dtrpcg).
 // gf, w are zero on bound entries.  Returns info (1,2 converged; 3 neg. curvature; 4 boundary; 5 itermax).
+// dtrpcg carries the residual twice: r in the preconditioned variables and t = L r in the original
+// ones (t only feeds the test ||t|| <= tol).  Here t is not stored: ||L r|| is evaluated from r when
+// the test is made (21 FMAs) -- two work vectors (t and the copy of A L^-T p that updates it) less at
+// the kernel's register-pressure peak; the tested value differs from the recurrence in the last bits.
 template <int N, class MA, class ML>
 EXA_BIG int trpcg_masked(unsigned fr, const MA& A, const double (&gf)[N], double delta, const ML& L,
                         const double (&id)[N], double tol, double stol, int itermax, double (&w)[N], int& iters_out)
 {
-    double p[N], q[N], r[N], t[N], z[N];
+    double p[N], q[N], r[N], z[N];
     EXA_UNROLL
     for (int i = 0; i < N; i++) {
         w[i] = 0.0;
-        t[i] = -gf[i];
-        r[i] = t[i];
+        r[i] = -gf[i];
     }
     trsol_n<N>(L, id, r);
     EXA_UNROLL
@@ -426,8 +429,6 @@ EXA_BIG int trpcg_masked(unsigned fr, const MA& A, const double (&gf)[N], double
         trsol_t<N>(L, id, z);
         symv<N>(A, z, q);
         mask_vec<N>(fr, q);
-        EXA_UNROLL
-        for (int i = 0; i < N; i++) z[i] = q[i];
         trsol_n<N>(L, id, q);
 
         double ptq = dot<N>(p, q);
@@ -444,10 +445,18 @@ EXA_BIG int trpcg_masked(unsigned fr, const MA& A, const double (&gf)[N], double
         for (int i = 0; i < N; i++) {
             w[i] = fma(alpha, p[i], w[i]);
             r[i] = fma(-alpha, q[i], r[i]);
-            t[i] = fma(-alpha, z[i], t[i]);
         }
         double rtr = dot<N>(r, r);
-        if (dot<N>(t, t) <= tol2) {
+        // ||t||^2 with t = L r (lower triangular product, row by row)
+        double tt = 0.0;
+        EXA_UNROLL
+        for (int i = 0; i < N; i++) {
+            double ti = 0.0;
+            EXA_UNROLL
+            for (int j = 0; j <= i; j++) ti = fma(L.lo(i, j), r[j], ti);
+            tt = fma(ti, ti, tt);
+        }
+        if (tt <= tol2) {
             iters_out = iters;
             return 1;
         }

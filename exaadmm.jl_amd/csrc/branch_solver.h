@@ -59,17 +59,20 @@ struct BranchDataRef {
     EXA_HD double Y(int k) const { return p[(24 + k) * STRIDE]; }
 };
 
-// constants of the augmented-Lagrangian loop and of the TRON driver
+// Run-time parameters of the augmented-Lagrangian loop, and the TRON driver constants.  The driver
+// constants are hard-wired in the reference (acopf_auglag_linelimit_kernel_gpu.jl:96,
+// acopf_tron_linelimit_kernel.jl:46-51); as compile-time constants they cost no kernel-argument SGPRs
+// (the kernel spills ~100 SGPRs) and fold into the comparisons.
 struct BranchOptions {
     int max_auglag;    // Parameters.max_auglag (50)
     double mu_max;     // Parameters.mu_max (1e8)
-    int max_feval;     // 500   (acopf_auglag_linelimit_kernel_gpu.jl:96)
-    int max_minor;     // 200
-    double gtol;       // 1e-6
-    double frtol;      // 1e-12 (acopf_tron_linelimit_kernel.jl:46-51)
-    double fatol;      // 0
-    double fmin;       // -1e32
-    double cgtol;      // 0.1
+    static constexpr int max_feval = 500;
+    static constexpr int max_minor = 200;
+    static constexpr double gtol = 1e-6;
+    static constexpr double frtol = 1e-12;
+    static constexpr double fatol = 0.0;
+    static constexpr double fmin = -1e32;
+    static constexpr double cgtol = 0.1;
 };
 
 // mu only takes the values 10^k (k = 1..8) in normal operation; host-computed mu^0.1 and

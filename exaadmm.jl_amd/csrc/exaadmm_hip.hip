@@ -210,13 +210,6 @@ static void fill_branch_options(exaadmm_handle* h)
     BranchOptions& o = h->bo;
     o.max_auglag = h->par.max_auglag;
     o.mu_max = h->par.mu_max;
-    o.max_feval = 500;  // acopf_auglag_linelimit_kernel_gpu.jl:96
-    o.max_minor = 200;
-    o.gtol = 1e-6;
-    o.frtol = 1e-12;    // acopf_tron_linelimit_kernel.jl:46-51
-    o.fatol = 0.0;
-    o.fmin = -1e32;
-    o.cgtol = 0.1;
 }
 
 static int upload_mupow_table()

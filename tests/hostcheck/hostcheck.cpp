@@ -61,13 +61,6 @@ extern "C" int hostcheck_branch_solve(double* x_, const double* xl_, const doubl
     BranchOptions o;
     o.max_auglag = max_auglag;
     o.mu_max = mu_max;
-    o.max_feval = 500;
-    o.max_minor = 200;
-    o.gtol = 1e-6;
-    o.frtol = 1e-12;
-    o.fatol = 0.0;
-    o.fmin = -1e32;
-    o.cgtol = 0.1;
     MuPowTable pw;
     double p = 1.0;
     for (int k = 0; k < 8; k++) {
@@ -107,13 +100,6 @@ extern "C" int hostcheck_genramp_solve(double* x_, const double* xl_, const doub
     BranchOptions o;
     o.max_auglag = max_auglag;
     o.mu_max = xi_max;
-    o.max_feval = 500;
-    o.max_minor = 200;
-    o.gtol = 1e-6;
-    o.frtol = 1e-12;
-    o.fatol = 0.0;
-    o.fmin = -1e32;
-    o.cgtol = 0.1;
     MuPowTable pw;
     double p = 1.0;
     for (int k = 0; k < 8; k++) {

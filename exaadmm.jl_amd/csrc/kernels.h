@@ -189,6 +189,9 @@ __global__ void __launch_bounds__(BR_BLOCK) k_branch_t(const Dev* __restrict__ d
     }
     const int slot = blockIdx.x * BR_BLOCK + threadIdx.x;
     if (slot >= d.La) return;
+#if defined(EXA_PROFILE_PHASES)
+    const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+#endif
     // which lane solves a branch does not change any result; lane_order exists for experiments
     // (regrouping lanes by work does not pay in either regime)
     const int b = d.lane_order ? d.lane_order[slot] : slot;
@@ -257,8 +260,14 @@ __global__ void __launch_bounds__(BR_BLOCK) k_branch_t(const Dev* __restrict__ d
     BranchStats st;
 #if defined(EXA_PROFILE_PHASES)
     st.tl = d.st_tl ? d.st_tl + (size_t)(slot / 64) * 128 : nullptr;
+    // force the loads to land before the stamp: consume one loaded value in the asm dependency
+    unsigned long long t_loaded;
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_loaded) : "v"(x[0]) : "memory");
 #endif
     branch_solve(bd, o, c_mupow, x, xl, xu, A, L, phi, st);
+#if defined(EXA_PROFILE_PHASES)
+    const unsigned long long t_solved = __builtin_amdgcn_s_memtime();
+#endif
 
     d.u[base] = phi[0];
     d.u[base + Lp] = phi[1];
@@ -276,6 +285,14 @@ __global__ void __launch_bounds__(BR_BLOCK) k_branch_t(const Dev* __restrict__ d
     d.st_ticks[b] = st.ticks;
 #if defined(EXA_PROFILE_PHASES)
     for (int q = 0; q < 13; q++) d.st_cyc[q * d.Lp + b] = st.cyc[q];
+    if (st.tl) {   // per-wave prologue / epilogue stamps (entries 123..127 of the timeline)
+        unsigned long long t_stored;
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_stored) : : "memory");
+        st.tl[123] = t_entry;
+        st.tl[124] = t_loaded;
+        st.tl[125] = t_solved;
+        st.tl[126] = t_stored;
+    }
 #endif
 }
 

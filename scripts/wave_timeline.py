@@ -25,10 +25,20 @@ for rep in range(3):
     tl = buf.reshape(nw, 128)
     clk = (tl & np.uint64(0x00ffffffffffffff)).astype(np.int64)
     act = (tl >> np.uint64(56)).astype(np.int64)
+    stamps = clk[:, 123:127].copy()
+    clk = clk.copy(); clk[:, 123:127] = 0; act = act.copy(); act[:, 123:127] = 0
     nt = (clk > 0).sum(axis=1) - 1          # ticks of the wave
     dur = np.array([clk[w, nt[w]] - clk[w, 0] for w in range(nw)])
     t0 = clk[:, 0][clk[:, 0] > 0].min()
     end = np.array([clk[w, nt[w]] for w in range(nw)]).max()
+    ok = (stamps > 0).all(axis=1)
+    if ok.any():
+        pro_load = stamps[ok, 1] - stamps[ok, 0]
+        first_tick = clk[ok, 0] - stamps[ok, 1]
+        epi = stamps[ok, 3] - stamps[ok, 2]
+        total = stamps[ok, 3] - stamps[ok, 0]
+        print("  in-kernel stamps per wave (clocks): entry->loads landed median %.0f max %.0f | loads landed->first tick median %.0f | solve end->stores landed median %.0f max %.0f | entry->stores landed median %.0f max %.0f"
+              % (np.median(pro_load), pro_load.max(), np.median(first_tick), np.median(epi), epi.max(), np.median(total), total.max()))
     span = float(end - t0)
     print("k_branch %.3f ms | waves %d | wave ticks median %d max %d | wave duration median %.0f mean %.0f max %.0f clocks | first start..last end %.0f clocks "
           "(%.2f GHz if that is the kernel time) | sum of wave durations / (1024 SIMDs x span) = %.2f"

@@ -2,7 +2,7 @@
 """GPU diagnostic: per-branch auglag/TRON work counters of the HIP path vs the oracle.
 usage: python scripts/diag_branch_counters.py [case] [iters]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import exaadmm_loader

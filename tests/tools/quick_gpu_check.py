@@ -2,7 +2,7 @@
 """Quick GPU sanity check of one library build (EXAADMM_HIP_LIB): case9 anchor + first
 iterations of a synthetic grid against the oracle, with per-branch work counters."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import exaadmm_loader

@@ -2,7 +2,7 @@
 """GPU vs oracle over several seeds / sizes / longer runs than the test suite: fused two-level loop,
 iteration counts and solution distance.  A robustness sweep for changes of the lane code."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import exaadmm_loader

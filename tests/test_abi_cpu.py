@@ -69,13 +69,15 @@ def test_compute_fails_loudly_without_gpu(pkg):
 
 def test_product_never_imports_oracle():
     """no import / include / dlopen of anything under oracle/ from the product tree"""
-    pdir = os.path.join(ROOT, "exaadmm.jl_amd")
     bad = re.compile(r"(import\s+oracle|from\s+oracle|oracle/|oracle\.py|libexaadmm_oracle|acopf_oracle\.h|tron_dense\.h)")
-    for dp, _, files in os.walk(pdir):
-        for f in files:
-            if f.endswith((".py", ".h", ".hip", ".cpp", "Makefile")):
-                txt = open(os.path.join(dp, f)).read()
-                assert not bad.search(txt), (dp, f)
+    # product tree, diagnostics, Julia binding, loader: only tests/, smoke() and bench.py's cpu_baseline may use the oracle
+    for pdir in ("exaadmm.jl_amd", "scripts", "julia", "include"):
+        for dp, _, files in os.walk(os.path.join(ROOT, pdir)):
+            for f in files:
+                if f.endswith((".py", ".h", ".hip", ".cpp", ".jl", "Makefile")):
+                    txt = open(os.path.join(dp, f)).read()
+                    assert not bad.search(txt), (dp, f)
+    assert not bad.search(open(os.path.join(ROOT, "exaadmm_loader.py")).read())
 
 
 def test_synthetic_grid_is_connected_and_sized(pkg):

@@ -405,7 +405,16 @@ EXA_HD void branch_solve(D& d, const BranchOptions& o, const MuPowTable& pw, dou
             t1 = t3;
             st.nfev++;
             bool moved;
-            if (st.nfev >= o.max_feval) {
+            if (!(ftrial - ftrial == 0.0)) {
+                // non-finite objective (NaN / Inf reached the inputs): no comparison of the solver means
+                // anything any more and the guarded loops would spin to their limits for seconds.  Give the
+                // branch up at its last accepted point; the NaN stays visible in the residuals.
+                EXA_UNROLL
+                for (int i = 0; i < 6; i++) x[i] = st.xc[i];
+                it = o.max_auglag;
+                fin = TRON_MAXFEVAL;
+                moved = false;
+            } else if (st.nfev >= o.max_feval) {
                 fin = TRON_MAXFEVAL;  // search stops before the ratio test (tron_linelimit_kernel.jl:76-78)
                 moved = true;
             } else {

@@ -98,7 +98,12 @@ EXA_HD void genramp_solve(GenRampData& d, const BranchOptions& o, const MuPowTab
             tron_compute<3>(st, x, xl, xu, A, L, g, o.cgtol, 3);
             const double ftrial = genramp_f(d, x);
             st.nfev++;
-            if (st.nfev >= o.max_feval) {
+            if (!(ftrial - ftrial == 0.0)) {   // non-finite inputs: give up at the last accepted point
+                EXA_UNROLL
+                for (int i = 0; i < 3; i++) x[i] = st.xc[i];
+                it = o.max_auglag;
+                fin = TRON_MAXFEVAL;
+            } else if (st.nfev >= o.max_feval) {
                 fin = TRON_MAXFEVAL;
             } else {
                 int task;

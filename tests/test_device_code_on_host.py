@@ -153,3 +153,20 @@ def test_lane_generator_ramp_solve_matches_oracle(hc, oracle):
         assert np.abs(ph[6:8] - po[6:8]).max() <= 1e-7 * max(1.0, np.abs(po[6:8]).max())
         same += (ith.value == ito.value and mih.value == mio.value)
     assert same >= 0.97 * ncase
+
+
+def test_lane_code_gives_up_quickly_on_non_finite_inputs(hc):
+    """NaN in the consensus targets must not make a lane spin through its guarded loops
+    (50 x 500 evaluations with 1000-trip line searches = seconds on a GPU): one tick, then out,
+    with a finite point returned."""
+    rng = np.random.default_rng(3)
+    x, xl, xu, p, Y = _random_branch(rng, cold=False)
+    p[18] = np.nan
+    ith, mih, tk = C.c_int(), C.c_int(), C.c_int()
+    hc.hostcheck_branch_solve(_p(x), _p(xl), _p(xu), _p(p), _p(Y), 1e-4, 50, 1e8, C.byref(ith), C.byref(mih), C.byref(tk))
+    assert tk.value <= 2
+    assert np.all(np.isfinite(x)) and np.all(x >= xl) and np.all(x <= xu)
+    xg = np.array([0.5, 0.4, 0.01]); xlg = np.array([0.0, 0.0, -0.02]); xug = np.array([1.0, 1.0, 0.02])
+    pg = np.array([0.0, 0.0, 400.0, 400.0, np.nan, 0.4, 0.0, 10.0])
+    hc.hostcheck_genramp_solve(_p(xg), _p(xlg), _p(xug), _p(pg), 0.1, 10.0, 0.0, 100.0, 50, 1e8, C.byref(ith), C.byref(mih))
+    assert np.all(np.isfinite(xg)) and mih.value <= 2

@@ -446,3 +446,35 @@ def test_case118_full_solve_anchor_gpu(pkg):
     env, mod = pkg.solve_acopf(_find_case("case118.m"), outer_iterlim=25, rho_pq=4e2, rho_va=4e4, outer_eps=2e-5, verbose=0)
     assert mod.info.status == "Solved" and mod.info.outer == a["outer"] and mod.info.cumul == a["cumul"]
     assert abs(mod.info.objval - a["objval"]) <= 1e-6 * a["objval"]
+
+
+def test_non_finite_input_does_not_stall_the_branch_kernel(pkg, syn):
+    """A NaN in one branch's consensus target must cost that branch one solver tick, not the
+    seconds its guarded loops would take to run out; every other branch is unaffected."""
+    import time
+    g = syn.sized_like("case1354pegase", seed=2)
+    env = pkg.AdmmEnv("syn", 1e1, 1e3, verbose=0, grid=g)
+    clean = pkg.ModelAcopf(env)
+    dirty = pkg.ModelAcopf(env)
+    for m in (clean, dirty):
+        m.run_fixed(5, first_major_iter=1, beta=1e3)
+    assert np.array_equal(clean.download("u_curr"), dirty.download("u_curr"))
+    v = dirty.download("v_curr")
+    b = 777
+    v[2 * dirty.ngen + 8 * b + 1] = np.nan
+    dirty.upload("v_curr", v)
+    for m in (clean, dirty):
+        m.info.inner = 6
+    pkg.admm_update_x(env, clean)
+    t0 = time.perf_counter()
+    pkg.admm_update_x(env, dirty)
+    dt = time.perf_counter() - t0
+    assert dt < 0.05, dt                      # a healthy launch takes ~0.1 ms; the unguarded spin ~10 s
+    uc, ud = clean.download("u_curr").reshape(-1), dirty.download("u_curr").reshape(-1)
+    lo, hi = 2 * dirty.ngen + 8 * b, 2 * dirty.ngen + 8 * (b + 1)
+    mask = np.ones(uc.size, dtype=bool)
+    mask[lo:hi] = False
+    assert np.array_equal(uc[mask], ud[mask])
+    assert np.all(np.isfinite(ud[lo:hi]))      # the branch is left at its last accepted (finite) point
+    a, m_, t = dirty.branch_counters()
+    assert t[b] <= 2

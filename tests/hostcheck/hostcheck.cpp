@@ -120,3 +120,22 @@ extern "C" int hostcheck_genramp_solve(double* x_, const double* xl_, const doub
     param[7] = d.xi;
     return 0;
 }
+
+// objective, gradient, Hessian of the generator ramp subproblem (lane code; scale = 1)
+extern "C" double hostcheck_genramp_fgh(const double* x_, const double* param, double c2, double c1, double c0,
+                                        double baseMVA, double* g_, double* Afull)
+{
+    GenRampData d;
+    d.lam_p = param[0]; d.lam_h = param[1]; d.rho_p = param[2]; d.rho_h = param[3];
+    d.xt_p = param[4]; d.xt_h = param[5]; d.mu = param[6]; d.xi = param[7];
+    d.c2 = c2; d.c1 = c1; d.c0 = c0; d.M = baseMVA;
+    double x[3] = {x_[0], x_[1], x_[2]}, g[3];
+    SymMat<3> A;
+    genramp_g(d, x, g);
+    genramp_h(d, A);
+    for (int i = 0; i < 3; i++) {
+        g_[i] = g[i];
+        for (int j = 0; j < 3; j++) Afull[i + 3 * j] = A.get(i, j);
+    }
+    return genramp_f(d, x);
+}

@@ -36,6 +36,8 @@ def hc():
     L.hostcheck_f.argtypes = [dp, dp, dp, C.c_double]
     L.hostcheck_branch_solve.argtypes = [dp, dp, dp, dp, dp, C.c_double, C.c_int, C.c_double, ip, ip, ip]
     L.hostcheck_genramp_solve.argtypes = [dp, dp, dp, dp] + [C.c_double] * 4 + [C.c_int, C.c_double, ip, ip]
+    L.hostcheck_genramp_fgh.restype = C.c_double
+    L.hostcheck_genramp_fgh.argtypes = [dp, dp] + [C.c_double] * 4 + [dp, dp]
     return L
 
 
@@ -170,3 +172,22 @@ def test_lane_code_gives_up_quickly_on_non_finite_inputs(hc):
     pg = np.array([0.0, 0.0, 400.0, 400.0, np.nan, 0.4, 0.0, 10.0])
     hc.hostcheck_genramp_solve(_p(xg), _p(xlg), _p(xug), _p(pg), 0.1, 10.0, 0.0, 100.0, 50, 1e8, C.byref(ith), C.byref(mih))
     assert np.all(np.isfinite(xg)) and mih.value <= 2
+
+
+def test_lane_generator_ramp_callbacks_match_reference_outputs(hc):
+    """f, grad f, Hessian of the generator ramp subproblem against the reference's own callbacks
+    executed at fixture-generation time (tests/golden/gen_genramp_eval_vectors.py); the lane code
+    fixes scale = 1 as the reference's call site does (mpacopf_admm_update_x_cpu.jl:16)."""
+    d = json.load(open(os.path.join(GOLDEN, "genramp_eval_vectors.json")))
+    n = 0
+    for c in d["cases"]:
+        if c["scale"] != 1.0:
+            continue
+        n += 1
+        x, p = np.array(c["x"]), np.array(c["param"])
+        g, A = np.zeros(3), np.zeros(9)
+        f = hc.hostcheck_genramp_fgh(_p(x), _p(p), c["c2"], c["c1"], c["c0"], c["baseMVA"], _p(g), _p(A))
+        assert abs(f - c["f"]) <= 1e-13 * max(1.0, abs(c["f"]))
+        assert np.abs(g - c["g"]).max() <= 1e-13 * max(1.0, np.abs(c["g"]).max())
+        assert np.abs(A.reshape(3, 3) - np.array(c["H"])).max() <= 1e-13 * max(1.0, np.abs(c["H"]).max())
+    assert n >= 8

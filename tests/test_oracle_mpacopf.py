@@ -98,3 +98,20 @@ def test_anchor_is_insensitive_to_the_inferred_digits(oracle, case9_grid):
                                  outer_eps=a["outer_eps"], warm_start=False)
         assert (m.info.status, m.info.outer, m.info.cumul) == (1, a["outer"], a["cumul"])
         assert abs(m.info.objval - a["objval"]) <= a["objval_atol"]
+
+
+def test_generator_ramp_callbacks_match_reference_outputs(oracle):
+    """oracle f / grad / Hessian of the ramp subproblem == the reference's callbacks executed at
+    fixture-generation time (tests/golden/gen_genramp_eval_vectors.py), both scales."""
+    import ctypes as C
+    L = oracle._mp_lib()
+    d = json.load(open(os.path.join(GOLDEN, "genramp_eval_vectors.json")))
+    for c in d["cases"]:
+        x, p = np.array(c["x"]), np.array(c["param"])
+        g, A = np.zeros(3), np.zeros(9)
+        f = L.oracle_genramp_eval_f(oracle._dp(x), oracle._dp(p), c["scale"], c["c2"], c["c1"], c["c0"], c["baseMVA"])
+        L.oracle_genramp_eval_gh(oracle._dp(x), oracle._dp(p), c["scale"], c["c2"], c["c1"], c["c0"], c["baseMVA"],
+                                 oracle._dp(g), oracle._dp(A))
+        assert abs(f - c["f"]) <= 1e-13 * max(1.0, abs(c["f"]))
+        assert np.abs(g - c["g"]).max() <= 1e-13 * max(1.0, np.abs(c["g"]).max())
+        assert np.abs(A.reshape(3, 3) - np.array(c["H"])).max() <= 1e-13 * max(1.0, np.abs(c["H"]).max())

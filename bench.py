@@ -9,6 +9,12 @@ whole grid resident in HBM.  Workload at N=1: BASELINE.json configs[2], case1365
 and ./data; when absent (no network in this environment) a seeded size-matched synthetic grid
 (ngen 4092 / nline 20467 / nbus 13659) is used and the JSON says so.
 
+Benchmark state: the synthetic input includes the ADMM state, defined as the state after PREP (default 20)
+untimed inner iterations of outer iteration 1 from the reference's cold start (init_solution!); the W warm-up
+steps and the K timed steps follow.  (The first ~10 iterations of a cold start cost up to 10x the thousands
+that follow in a solve; without a defined state the figure would depend on W.)  --prep 0 times from the cold
+start.  The CPU baseline is timed from the same state.
+
 For N>1 (launched by torch.distributed.run) the grid is N areas of that size joined by tie
 lines, one area per GPU (weak scaling); see exaadmm.jl_amd/distributed.py and DESIGN.md.
 
@@ -48,16 +54,16 @@ def find_case_file(name):
     return None
 
 
-def cpu_baseline(grid, params, budget_s=15.0, nthreads=1):
+def cpu_baseline(grid, params, budget_s=15.0, nthreads=1, prep=20):
     """Time the oracle (kind=port) on a bounded number of inner iterations.  nthreads=1 is the
     reference's own serial structure; nthreads>1 adds OpenMP over branches (extra information)."""
     from oracle import oracle as O
     m = O.OracleModel(grid, params["rho_pq"], params["rho_va"], scale=params["scale"], nthreads=nthreads)
     m.info.outer = 1
-    # same phase of the algorithm as the GPU run: warm up a few iterations first
+    # same phase of the algorithm as the GPU run: the same untimed preparation iterations first
     n_done, t_used = 0, 0.0
     it = 0
-    for _ in range(2):
+    for _ in range(max(prep, 2)):
         it += 1
         m.inner_prestep(); m.update_x(it); m.update_xbar(); m.update_z(); m.update_l(); m.update_residual()
     while t_used < budget_s and n_done < 500:
@@ -67,8 +73,8 @@ def cpu_baseline(grid, params, budget_s=15.0, nthreads=1):
         t_used += time.perf_counter() - t0
         n_done += 1
     return {"value": n_done / t_used, "unit": "ADMM inner iterations/s", "cores": nthreads, "kind": "port",
-            "sample": "%d inner iterations (after 2 warm-up) of the same grid, C oracle with %d thread(s), %.1f s"
-                      % (n_done, nthreads, t_used)}
+            "sample": "%d inner iterations (after %d untimed preparation iterations) of the same grid, C oracle with %d thread(s), %.1f s"
+                      % (n_done, max(prep, 2), nthreads, t_used)}
 
 
 def main():
@@ -81,6 +87,10 @@ def main():
     ap.add_argument("--full-solve", action="store_true",
                     help="also run a whole solve_acopf (outer 20 x inner 1000) and report cumul/time_overall; minutes on a non-converging instance")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU code path even with one rank")
+    ap.add_argument("--prep", type=int, default=20,
+                    help="untimed preparation iterations that define the benchmark state (the ADMM state after PREP inner "
+                         "iterations from init_solution!): the first iterations of a cold start are several times heavier "
+                         "than the thousands that follow in a solve; 0 = time from the cold start")
     ap.add_argument("--periods", type=int, default=1,
                     help="T > 1: multi-period ACOPF (SURVEY.md §8 f4) over T load levels of the same grid, one time-expanded device model")
     args = ap.parse_args()
@@ -125,12 +135,18 @@ def main():
     mod.sync_params()
     beta = env.params.initial_beta
 
-    # warm-up (untimed): first W inner iterations of outer iteration 1
+    # benchmark state: PREP inner iterations of outer iteration 1 from init_solution! (untimed), then the
+    # W warm-up steps (untimed), then exactly K timed steps
+    done = 0
+    if args.prep > 0:
+        mod.run_fixed(args.prep, first_major_iter=1, beta=beta)
+        done += args.prep
     if args.warmup > 0:
-        mod.run_fixed(args.warmup, first_major_iter=1, beta=beta)
+        mod.run_fixed(args.warmup, first_major_iter=done + 1, beta=beta)
+        done += args.warmup
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    norms, ms_total, ms_branch = mod.run_fixed(args.steps, first_major_iter=args.warmup + 1, beta=beta, time_branch=True)
+    norms, ms_total, ms_branch = mod.run_fixed(args.steps, first_major_iter=done + 1, beta=beta, time_branch=True)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
 
@@ -156,7 +172,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": data,
         "config": {"workload": workload, "ngen": G, "nline": L, "nbus": B, "rho_pq": params["rho_pq"],
                    "rho_va": params["rho_va"], "scale": params["scale"], "tight_factor": 0.99,
-                   "mode": "fixed-count inner iterations, no early break", "parallelism": "1 GPU"},
+                   "mode": "fixed-count inner iterations, no early break", "parallelism": "1 GPU",
+                   "state": "ADMM state after %d untimed preparation iterations from init_solution! (outer 1, beta %.0f)" % (args.prep, beta)},
         "roofline": {"bound": "hbm", "kernel": "k_branch", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": branch_bytes, "kernel_ms": ms_branch,
@@ -182,24 +199,25 @@ def main():
         om = O.OracleMpModel(grid, mp_load[0], mp_load[1], params["rho_pq"], params["rho_va"], scale=params["scale"])
         om.par.beta = beta
         n_done, t_used, it = 0, 0.0, 0
+        skip = max(args.prep, 2)
         while t_used < 15.0 and n_done < 200:
             it += 1
             t1 = time.perf_counter()
             om.inner_prestep(); om.update_x(it); om.update_xbar(); om.update_z(); om.update_l(); om.update_residual()
-            if it > 2:
+            if it > skip:
                 t_used += time.perf_counter() - t1
                 n_done += 1
         out["cpu_baseline"] = {"value": n_done / t_used, "unit": "ADMM inner iterations/s", "cores": 1, "kind": "port",
-                               "sample": "%d inner iterations (after 2 warm-up) of the same %d-period model, serial C oracle, %.1f s" % (n_done, T, t_used)}
+                               "sample": "%d inner iterations (after %d untimed preparation iterations) of the same %d-period model, serial C oracle, %.1f s" % (n_done, skip, T, t_used)}
         out["speedup_vs_cpu_baseline"] = its / out["cpu_baseline"]["value"]
     elif not args.no_cpu_baseline:
-        cb = cpu_baseline(grid, params)
+        cb = cpu_baseline(grid, params, prep=args.prep)
         out["cpu_baseline"] = cb
         out["speedup_vs_cpu_baseline"] = its / cb["value"]
         ncpu = min(os.cpu_count() or 1, 16)
         if ncpu > 1:   # extra: the same port with OpenMP over the branch loop (capped: more threads are slower)
-            out["cpu_baseline_all_cores"] = cpu_baseline(grid, params, budget_s=8.0, nthreads=ncpu)
-    print(json.dumps(out))
+            out["cpu_baseline_all_cores"] = cpu_baseline(grid, params, budget_s=8.0, nthreads=ncpu, prep=args.prep)
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

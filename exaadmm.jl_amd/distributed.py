@@ -26,6 +26,7 @@ import ctypes as C
 import json
 import math
 import os
+import sys
 import time
 
 import numpy as np
@@ -476,12 +477,14 @@ def bench_main(args, rank, world, local_rank):
         sums = bk.update_zl_partial(beta)
         dist.all_reduce(sums)
 
-    run(args.warmup, 1)
+    prep = max(0, getattr(args, "prep", 0))     # untimed preparation iterations that define the benchmark state
+    run(prep, 1)
+    run(args.warmup, prep + 1)
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run(args.steps, args.warmup + 1)
+    run(args.steps, prep + args.warmup + 1)
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
@@ -491,6 +494,14 @@ def bench_main(args, rank, world, local_rank):
     res = torch.sqrt(be.sums).cpu().numpy()
     cuts = torch.tensor([part.n_cut], dtype=torch.float64, device="cuda")
     dist.all_reduce(cuts)
+    # every rank pushes out whatever the runtime libraries buffered on C stdio (RCCL version banner) BEFORE
+    # rank 0 prints, so that the JSON line is the last line of the job's stdout
+    try:
+        sys.stdout.flush()
+        C.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    dist.barrier()
     if rank == 0:
         its = args.steps / dt
         G, Ln, Bn = int(grid["ngen"]), int(grid["nline"]), int(grid["nbus"])
@@ -501,6 +512,7 @@ def bench_main(args, rank, world, local_rank):
             "config": {"workload": "synthetic-%s-sized x %d areas" % (args.case, world), "ngen": G, "nline": Ln, "nbus": Bn,
                        "rho_pq": params["rho_pq"], "rho_va": params["rho_va"], "scale": params["scale"],
                        "cut_branches": int(cuts.cpu()[0]), "mode": "fixed-count inner iterations, no early break",
+                       "state": "ADMM state after %d untimed preparation iterations from init_solution!" % prep,
                        "value_is": "N x (inner iterations/s of the N-area grid): iterations/s per benchmark-sized area, summed over areas",
                        "parallelism": "bus/branch partition x%d, halo all_to_all + residual all_reduce (RCCL)" % world},
             "grid_iterations_per_s": its,
@@ -509,6 +521,20 @@ def bench_main(args, rank, world, local_rank):
                          "traffic": None, "note": "whole-iteration algorithmic bytes of the N-area grid / wall time"},
             "solver": {"primres": float(res[0])},
         }
-        print(json.dumps(out))
+        # RCCL writes a version banner through C stdio at communicator creation; when stdout is a pipe it
+        # would be flushed at process exit, AFTER this line.  Flush C stdio first so that the JSON line is
+        # the last line of stdout.
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
     dist.barrier()
     dist.destroy_process_group()
+    try:
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass

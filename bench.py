@@ -9,9 +9,9 @@ whole grid resident in HBM.  Workload at N=1: BASELINE.json configs[2], case1365
 and ./data; when absent (no network in this environment) a seeded size-matched synthetic grid
 (ngen 4092 / nline 20467 / nbus 13659) is used and the JSON says so.
 
-Benchmark state: the synthetic input includes the ADMM state, defined as the state after PREP (default 20)
+Benchmark state: the synthetic input includes the ADMM state, defined as the state after PREP (default 100)
 untimed inner iterations of outer iteration 1 from the reference's cold start (init_solution!); the W warm-up
-steps and the K timed steps follow.  (The first ~10 iterations of a cold start cost up to 10x the thousands
+steps and the K timed steps follow.  (The cost of an iteration decays over the first ~80 iterations of a cold start, from 5x to 1x the thousands
 that follow in a solve; without a defined state the figure would depend on W.)  --prep 0 times from the cold
 start.  The CPU baseline is timed from the same state.
 
@@ -54,7 +54,7 @@ def find_case_file(name):
     return None
 
 
-def cpu_baseline(grid, params, budget_s=15.0, nthreads=1, prep=20):
+def cpu_baseline(grid, params, budget_s=15.0, nthreads=1, prep=100):
     """Time the oracle (kind=port) on a bounded number of inner iterations.  nthreads=1 is the
     reference's own serial structure; nthreads>1 adds OpenMP over branches (extra information)."""
     from oracle import oracle as O
@@ -87,7 +87,7 @@ def main():
     ap.add_argument("--full-solve", action="store_true",
                     help="also run a whole solve_acopf (outer 20 x inner 1000) and report cumul/time_overall; minutes on a non-converging instance")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU code path even with one rank")
-    ap.add_argument("--prep", type=int, default=20,
+    ap.add_argument("--prep", type=int, default=100,
                     help="untimed preparation iterations that define the benchmark state (the ADMM state after PREP inner "
                          "iterations from init_solution!): the first iterations of a cold start are several times heavier "
                          "than the thousands that follow in a solve; 0 = time from the cold start")

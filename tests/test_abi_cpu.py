@@ -174,3 +174,20 @@ def test_loader_pglib_format_has_ten_generator_columns(pkg, oracle, tmp_path):
     a = pkg.opf_loaddata(str(p), case_format="pglib")
     b = oracle.grid_from_matpower(CASE9)
     assert a["ngen"] == 3 and np.allclose(a["pgmax"], b["pgmax"]) and np.allclose(a["c2"], b["c2"])
+
+
+def test_c_driver_builds_as_plain_c_and_fails_loudly_without_gpu(pkg):
+    """tools/exaadmm_solve.c: the header is valid C11, the driver links against the library, and
+    without a GPU it exits with code 2 and the library's message (no CPU path)."""
+    import subprocess
+    csrc = os.path.join(ROOT, "exaadmm.jl_amd", "csrc")
+    subprocess.check_call(["make", "-s", "-C", csrc, "../../tools/exaadmm_solve"])
+    exe = os.path.join(ROOT, "tools", "exaadmm_solve")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage:" in r.stderr
+    r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "no_such_case.m"), "--quiet"], capture_output=True, text=True)
+    assert r.returncode == 2 and "cannot open" in r.stderr
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([exe, CASE9, "--quiet"], capture_output=True, text=True)
+        assert r.returncode == 2 and "no CPU fallback" in r.stderr

@@ -478,3 +478,21 @@ def test_non_finite_input_does_not_stall_the_branch_kernel(pkg, syn):
     assert np.all(np.isfinite(ud[lo:hi]))      # the branch is left at its last accepted (finite) point
     a, m_, t = dirty.branch_counters()
     assert t[b] <= 2
+
+
+def test_plain_c_driver_solves_case9():
+    """tools/exaadmm_solve (C, no Python in the loop): native MATPOWER loader + C ABI + fused two-level
+    solve; prints the reference's statistics block.  Anchor: Solved / 20 / 705 / 5303.435."""
+    import re
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "tools", "exaadmm_solve")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "exaadmm.jl_amd", "csrc"), "../../tools/exaadmm_solve"])
+    r = subprocess.run([exe, CASE9, "--outer", "25", "--outer_eps", "2e-5", "--quiet"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    out = r.stdout
+    assert "Solved" in out
+    assert int(re.search(r"Cumulative iterations[ .]*(\d+)", out).group(1)) == 705
+    assert int(re.search(r"Outer iterations[ .]*(\d+)", out).group(1)) == 20
+    assert abs(float(re.search(r"Objective value[ .]*([-+0-9.eE]+)", out).group(1)) - 5303.435) <= 1e-2

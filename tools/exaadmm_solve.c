@@ -1,0 +1,96 @@
+/*
+ * exaadmm_solve -- command-line driver over the C ABI (include/exaadmm_hip.h), plain C.
+ * What `julia -e 'ExaAdmm.solve_acopf(case; ...)'` does with the reference (interface/solve_acopf.jl:1-46,
+ * utils/print_statistics.jl:1-21): load a MATPOWER case with the library's native loader, build the device
+ * model, run the two-level ADMM on one MI355X, print the statistics block.
+ *
+ *   exaadmm_solve case.m [--rho_pq R] [--rho_va R] [--scale S] [--tight_factor F] [--outer N] [--inner N]
+ *                        [--outer_eps E] [--gpu K] [--pglib] [--quiet]
+ *
+ * Exit code 0 = solved, 1 = iteration limit, 2 = error (message on stderr).
+ */
+#include "exaadmm_hip.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+static int fail(const char *what)
+{
+    const char *m = exaadmm_last_error();
+    if (!m || !*m) m = exaadmm_io_error();
+    fprintf(stderr, "exaadmm_solve: %s: %s\n", what, m ? m : "?");
+    return 2;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 2 || strcmp(argv[1], "-h") == 0 || strcmp(argv[1], "--help") == 0) {
+        fprintf(stderr, "usage: %s case.m [--rho_pq R] [--rho_va R] [--scale S] [--tight_factor F] [--outer N] "
+                        "[--inner N] [--outer_eps E] [--gpu K] [--pglib] [--quiet]\n(%s)\n", argv[0], exaadmm_version());
+        return 2;
+    }
+    const char *path = argv[1];
+    double rho_pq = 4e2, rho_va = 4e4, tight = 1.0;
+    int gpu = 0, quiet = 0;
+    const char *fmt = "matpower";
+    exaadmm_params par;
+    exaadmm_default_params(&par);
+    for (int i = 2; i < argc; i++) {
+        const char *a = argv[i];
+        const char *v = (i + 1 < argc) ? argv[i + 1] : NULL;
+#define OPT(name) (strcmp(a, name) == 0 && v && ++i)
+        if (OPT("--rho_pq")) rho_pq = atof(v);
+        else if (OPT("--rho_va")) rho_va = atof(v);
+        else if (OPT("--scale")) par.scale = atof(v);
+        else if (OPT("--tight_factor")) tight = atof(v);
+        else if (OPT("--outer")) par.outer_iterlim = atoi(v);
+        else if (OPT("--inner")) par.inner_iterlim = atoi(v);
+        else if (OPT("--outer_eps")) par.outer_eps = atof(v);
+        else if (OPT("--gpu")) gpu = atoi(v);
+        else if (strcmp(a, "--pglib") == 0) fmt = "pglib";
+        else if (strcmp(a, "--quiet") == 0) quiet = 1;
+        else {
+            fprintf(stderr, "exaadmm_solve: unknown or incomplete option %s\n", a);
+            return 2;
+        }
+#undef OPT
+    }
+    par.verbose = quiet ? 0 : 1;
+
+    exaadmm_case *cs = NULL;
+    if (exaadmm_load_matpower(path, tight, fmt, &cs) != EXAADMM_OK) return fail("load");
+    exaadmm_grid grid;
+    if (exaadmm_case_grid(cs, &grid) != EXAADMM_OK) return fail("grid");
+    exaadmm_handle *h = NULL;
+    if (exaadmm_create(&grid, &par, gpu, &h) != EXAADMM_OK) {
+        exaadmm_case_free(cs);
+        return fail("create");
+    }
+    int rc = exaadmm_init_solution(h, rho_pq, rho_va);
+    exaadmm_info info;
+    memset(&info, 0, sizeof(info));
+    if (rc == EXAADMM_OK) rc = exaadmm_solve_two_level(h, &info);
+    if (rc != EXAADMM_OK) {
+        fail("solve");
+        exaadmm_destroy(h);
+        exaadmm_case_free(cs);
+        return 2;
+    }
+    /* print_statistics (utils/print_statistics.jl:1-21) */
+    printf(" ** Statistics of %s (%lld generators, %lld branches, %lld buses)\n", path, (long long)grid.ngen,
+           (long long)grid.nline, (long long)grid.nbus);
+    printf("Status  . . . . . . . . . . . . . . . . %s\n", info.status == 1 ? "Solved" : "IterationLimit");
+    printf("Objective value  . . . . . . . . . . . %12.6e\n", info.objval);
+    printf("Residual  . . . . . . . . . . . . . . . %12.6e\n", info.mismatch);
+    printf("Cumulative iterations . . . . . . . . . %5d\n", info.cumul);
+    printf("Outer iterations  . . . . . . . . . . . %5d\n", info.outer);
+    printf("Time per iteration  . . . . . . . . . . %12.6f (secs/iter)\n", info.cumul > 0 ? info.time_overall / info.cumul : 0.0);
+    printf("Overall time  . . . . . . . . . . . . . %12.6f (secs)\n", info.time_overall);
+    printf("Generator + branch time (sampled) . . . %12.6f (secs)\n", info.time_x_update);
+    printf("Bus time (sampled)  . . . . . . . . . . %12.6f (secs)\n", info.time_xbar_update);
+    printf("z, l, residual time (sampled) . . . . . %12.6f (secs)\n", info.time_zl_update);
+    exaadmm_destroy(h);
+    exaadmm_case_free(cs);
+    return info.status == 1 ? 0 : 1;
+}

@@ -226,3 +226,26 @@ def test_ramp_vectors_round_trip_and_two_periods(pkg):
                                  rho_pq=4e2, rho_va=4e4, outer_eps=2e-5)
     assert m2.info.status == "Solved"
     assert abs(m2.info.objval - 2 * 5303.4) <= 0.01 * 2 * 5303.4
+
+
+def test_plain_c_driver_solves_three_period_case9(tmp_path):
+    """tools/exaadmm_solve --load_prefix: load files in the reference's format (nbus x T matrices),
+    multi-period solve through the C ABI without Python; reference anchor 20 / 729 / 15901.48."""
+    import re
+    import subprocess
+    from conftest import ROOT
+    env_grid = exaadmm_loader.load_package().opf_loaddata(CASE9)
+    pd, qd = _case9_loads(env_grid)
+    np.savetxt(tmp_path / "load.Pd", pd, fmt="%.17g")
+    np.savetxt(tmp_path / "load.Qd", qd, fmt="%.17g")
+    exe = os.path.join(ROOT, "tools", "exaadmm_solve")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "exaadmm.jl_amd", "csrc"), "../../tools/exaadmm_solve"])
+    r = subprocess.run([exe, CASE9, "--outer", "25", "--outer_eps", "2e-5", "--quiet", "--load_prefix", str(tmp_path / "load"),
+                        "--start_period", "1", "--end_period", "3"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    out = r.stdout
+    assert "3 periods" in out and "Solved" in out
+    assert int(re.search(r"Cumulative iterations[ .]*(\d+)", out).group(1)) == G["solve"]["cumul"]
+    assert int(re.search(r"Outer iterations[ .]*(\d+)", out).group(1)) == G["solve"]["outer"]
+    assert abs(float(re.search(r"Objective value[ .]*([-+0-9.eE]+)", out).group(1)) - G["solve"]["objval"]) <= 2e-2

@@ -6,6 +6,10 @@
  *
  *   exaadmm_solve case.m [--rho_pq R] [--rho_va R] [--scale S] [--tight_factor F] [--outer N] [--inner N]
  *                        [--outer_eps E] [--gpu K] [--pglib] [--quiet]
+ *                        [--load_prefix P --start_period A --end_period B [--ramp_ratio R]]
+ *
+ * With --load_prefix the multi-period model is solved (interface/solve_mpacopf.jl with warm_start=false):
+ * P.Pd / P.Qd are whitespace matrices nbus x T (utils/opfdata.jl:121-130), periods A..B (1-based) are used.
  *
  * Exit code 0 = solved, 1 = iteration limit, 2 = error (message on stderr).
  */
@@ -14,6 +18,30 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+
+/* reads an nbus x T whitespace matrix; returns period-major T x nbus (columns one after another) */
+static double *read_load(const char *path, long nbus, int *T)
+{
+    FILE *f = fopen(path, "r");
+    if (!f) return NULL;
+    size_t cap = 1024, n = 0;
+    double *v = (double *)malloc(cap * sizeof(double)), x;
+    while (fscanf(f, "%lf", &x) == 1) {
+        if (n == cap) v = (double *)realloc(v, (cap *= 2) * sizeof(double));
+        v[n++] = x;
+    }
+    fclose(f);
+    if (nbus <= 0 || n == 0 || n % (size_t)nbus != 0) {
+        free(v);
+        return NULL;
+    }
+    *T = (int)(n / (size_t)nbus);
+    double *out = (double *)malloc(n * sizeof(double));
+    for (long b = 0; b < nbus; b++)
+        for (int t = 0; t < *T; t++) out[(size_t)t * nbus + b] = v[(size_t)b * *T + t];
+    free(v);
+    return out;
+}
 
 static int fail(const char *what)
 {
@@ -31,8 +59,9 @@ int main(int argc, char **argv)
         return 2;
     }
     const char *path = argv[1];
-    double rho_pq = 4e2, rho_va = 4e4, tight = 1.0;
-    int gpu = 0, quiet = 0;
+    double rho_pq = 4e2, rho_va = 4e4, tight = 1.0, ramp_ratio = 0.02;
+    int gpu = 0, quiet = 0, p0 = 1, p1 = 1;
+    const char *load_prefix = NULL;
     const char *fmt = "matpower";
     exaadmm_params par;
     exaadmm_default_params(&par);
@@ -48,6 +77,10 @@ int main(int argc, char **argv)
         else if (OPT("--inner")) par.inner_iterlim = atoi(v);
         else if (OPT("--outer_eps")) par.outer_eps = atof(v);
         else if (OPT("--gpu")) gpu = atoi(v);
+        else if (OPT("--load_prefix")) load_prefix = v;
+        else if (OPT("--start_period")) p0 = atoi(v);
+        else if (OPT("--end_period")) p1 = atoi(v);
+        else if (OPT("--ramp_ratio")) ramp_ratio = atof(v);
         else if (strcmp(a, "--pglib") == 0) fmt = "pglib";
         else if (strcmp(a, "--quiet") == 0) quiet = 1;
         else {
@@ -63,7 +96,29 @@ int main(int argc, char **argv)
     exaadmm_grid grid;
     if (exaadmm_case_grid(cs, &grid) != EXAADMM_OK) return fail("grid");
     exaadmm_handle *h = NULL;
-    if (exaadmm_create(&grid, &par, gpu, &h) != EXAADMM_OK) {
+    int rc_create;
+    if (load_prefix) {
+        char fn[4096];
+        int T1 = 0, T2 = 0;
+        snprintf(fn, sizeof(fn), "%s.Pd", load_prefix);
+        double *pd = read_load(fn, (long)grid.nbus, &T1);
+        snprintf(fn, sizeof(fn), "%s.Qd", load_prefix);
+        double *qd = read_load(fn, (long)grid.nbus, &T2);
+        if (!pd || !qd || T1 != T2 || p0 < 1 || p1 < p0 || p1 > T1) {
+            fprintf(stderr, "exaadmm_solve: load files %s.Pd/.Qd missing, not nbus x T, or periods out of range\n", load_prefix);
+            free(pd);
+            free(qd);
+            exaadmm_case_free(cs);
+            return 2;
+        }
+        rc_create = exaadmm_mp_create(&grid, &par, p1 - p0 + 1, pd + (size_t)(p0 - 1) * grid.nbus, qd + (size_t)(p0 - 1) * grid.nbus,
+                                      ramp_ratio, gpu, &h);
+        free(pd);
+        free(qd);
+    } else {
+        rc_create = exaadmm_create(&grid, &par, gpu, &h);
+    }
+    if (rc_create != EXAADMM_OK) {
         exaadmm_case_free(cs);
         return fail("create");
     }
@@ -78,8 +133,8 @@ int main(int argc, char **argv)
         return 2;
     }
     /* print_statistics (utils/print_statistics.jl:1-21) */
-    printf(" ** Statistics of %s (%lld generators, %lld branches, %lld buses)\n", path, (long long)grid.ngen,
-           (long long)grid.nline, (long long)grid.nbus);
+    printf(" ** Statistics of %s (%lld generators, %lld branches, %lld buses, %d period%s)\n", path, (long long)grid.ngen,
+           (long long)grid.nline, (long long)grid.nbus, exaadmm_mp_periods(h), exaadmm_mp_periods(h) == 1 ? "" : "s");
     printf("Status  . . . . . . . . . . . . . . . . %s\n", info.status == 1 ? "Solved" : "IterationLimit");
     printf("Objective value  . . . . . . . . . . . %12.6e\n", info.objval);
     printf("Residual  . . . . . . . . . . . . . . . %12.6e\n", info.mismatch);

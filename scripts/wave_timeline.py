@@ -14,13 +14,14 @@ case = sys.argv[1] if len(sys.argv) > 1 else "case13659pegase"
 g = syn.sized_like(case, seed=0)
 env = pkg.AdmmEnv("syn", 5e1, 5e3, verbose=0, grid=g)
 mod = pkg.ModelAcopf(env)
-mod.run_fixed(60, first_major_iter=1, beta=1e3)
+nwarm = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+mod.run_fixed(nwarm, first_major_iter=1, beta=1e3)
 Lp = ((g["nline"] + 63) // 64) * 64
 nw = Lp // 64
 buf = np.zeros(2 * Lp, dtype=np.uint64)
 pkg._check(L.exaadmm_debug_wave_timeline(mod.handle, buf.ctypes.data_as(C.POINTER(C.c_uint64)), buf.size), "tl")
 for rep in range(3):
-    norms, ms, msb = mod.run_fixed(1, first_major_iter=61 + rep, beta=1e3, time_branch=True)
+    norms, ms, msb = mod.run_fixed(1, first_major_iter=nwarm + 1 + rep, beta=1e3, time_branch=True)
     pkg._check(L.exaadmm_debug_wave_timeline(mod.handle, buf.ctypes.data_as(C.POINTER(C.c_uint64)), buf.size), "tl")
     tl = buf.reshape(nw, 128)
     clk = (tl & np.uint64(0x00ffffffffffffff)).astype(np.int64)

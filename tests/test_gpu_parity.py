@@ -496,3 +496,15 @@ def test_plain_c_driver_solves_case9():
     assert int(re.search(r"Cumulative iterations[ .]*(\d+)", out).group(1)) == 705
     assert int(re.search(r"Outer iterations[ .]*(\d+)", out).group(1)) == 20
     assert abs(float(re.search(r"Objective value[ .]*([-+0-9.eE]+)", out).group(1)) - 5303.435) <= 1e-2
+
+
+def test_relaxed_check_every_is_opt_in_and_bounded(pkg):
+    """check_every = k > 1 (opt-in relaxation): the inner-loop test is evaluated every k-th iteration only,
+    so each inner loop runs at most k-1 iterations longer than with the reference semantics."""
+    env0, ref = pkg.solve_acopf(CASE9, outer_iterlim=25, rho_pq=4e2, rho_va=4e4, outer_eps=2e-5, verbose=0)
+    env1, rel = pkg.solve_acopf(CASE9, outer_iterlim=25, rho_pq=4e2, rho_va=4e4, outer_eps=2e-5, verbose=0, check_every=4)
+    assert ref.info.cumul == 705 and ref.info.status == "Solved"
+    assert rel.info.status == "Solved"
+    assert rel.info.cumul % 4 == 0 or rel.info.inner % 4 == 0
+    assert 705 - 3 * 25 <= rel.info.cumul <= 705 + 3 * 25
+    assert abs(rel.info.objval - ref.info.objval) <= 1e-4 * abs(ref.info.objval)   # a different (longer) trajectory to the same tolerance

@@ -249,3 +249,25 @@ def test_plain_c_driver_solves_three_period_case9(tmp_path):
     assert int(re.search(r"Cumulative iterations[ .]*(\d+)", out).group(1)) == G["solve"]["cumul"]
     assert int(re.search(r"Outer iterations[ .]*(\d+)", out).group(1)) == G["solve"]["outer"]
     assert abs(float(re.search(r"Objective value[ .]*([-+0-9.eE]+)", out).group(1)) - G["solve"]["objval"]) <= 2e-2
+
+
+def test_lane_per_bus_kernel_carries_the_ramp_terms_too(pkg, syn):
+    """EXAADMM_BUS_KERNEL=lane (one lane per bus, the A/B twin of the lane-group kernel) must give
+    bit-identical multi-period results: both evaluate the reference's ramp form of the generator terms."""
+    grid = syn.sized_like("case118", seed=6)
+    al = np.array([1.0, 0.99, 1.015])
+    pd = np.stack([grid["Pd"] * a for a in al], 1)
+    qd = np.stack([grid["Qd"] * a for a in al], 1)
+    env = pkg.AdmmEnv("syn118", 1e1, 1e3, verbose=0, grid=grid)
+    a = pkg.ModelMpacopf(env, (pd, qd), end_period=3)
+    os.environ["EXAADMM_BUS_KERNEL"] = "lane"
+    try:
+        b = pkg.ModelMpacopf(env, (pd, qd), end_period=3)
+    finally:
+        del os.environ["EXAADMM_BUS_KERNEL"]
+    ra = a.run_fixed(12, first_major_iter=1, beta=1e3)[0]
+    rb = b.run_fixed(12, first_major_iter=1, beta=1e3)[0]
+    assert np.array_equal(ra, rb)
+    for name in ("u_curr", "v_curr", "z_curr"):
+        assert np.array_equal(a.download(name), b.download(name)), name
+    assert np.array_equal(a.download_ramp("u_curr"), b.download_ramp("u_curr"))

@@ -982,8 +982,8 @@ extern "C" int exaadmm_update_x(exaadmm_handle* h, int major_iter)
 {
     REQUIRE(h, "null handle");
     HIPCHK(hipSetDevice(h->device));
-    launch_gen(h, nullptr, major_iter);
-    launch_branch(h, major_iter, h->ctrl_mode ? h->d_ctrl : nullptr);
+    // generators (multi-period: ramp subproblems) ride in the branch launch: one kernel boundary less
+    launch_branch(h, major_iter, h->ctrl_mode ? h->d_ctrl : nullptr, true);
     h->residual_vectors_valid = false;
     return sync_check(h);
 }

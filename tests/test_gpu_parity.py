@@ -508,3 +508,26 @@ def test_relaxed_check_every_is_opt_in_and_bounded(pkg):
     assert rel.info.cumul % 4 == 0 or rel.info.inner % 4 == 0
     assert 705 - 3 * 25 <= rel.info.cumul <= 705 + 3 * 25
     assert abs(rel.info.objval - ref.info.objval) <= 1e-4 * abs(ref.info.objval)   # a different (longer) trajectory to the same tolerance
+
+
+def test_plain_c_driver_rolling_horizon_matches_python_mirror(pkg, case9_grid, tmp_path):
+    """tools/exaadmm_solve --rolling: the rolling-horizon procedure (row f3) driven from C through
+    exaadmm_set_load / exaadmm_set_pg_bounds gives the per-period iteration counts of the Python mirror."""
+    import re
+    import subprocess
+    from conftest import ROOT
+    fac = np.array([1.0, 1.01, 0.995, 1.015])
+    np.savetxt(str(tmp_path / "load.Pd"), np.outer(case9_grid["Pd"], fac), fmt="%.17g")
+    np.savetxt(str(tmp_path / "load.Qd"), np.outer(case9_grid["Qd"], fac), fmt="%.17g")
+    env, mod, res = pkg.solve_acopf_rolling(CASE9, load_prefix=str(tmp_path / "load"), start_period=1, end_period=4,
+                                            ramp_ratio=0.02, rho_pq=4e2, rho_va=4e4, outer_iterlim=25, outer_eps=2e-5, tight_factor=1.0)
+    exe = os.path.join(ROOT, "tools", "exaadmm_solve")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "exaadmm.jl_amd", "csrc"), "../../tools/exaadmm_solve"])
+    r = subprocess.run([exe, CASE9, "--outer", "25", "--outer_eps", "2e-5", "--quiet", "--load_prefix", str(tmp_path / "load"),
+                        "--start_period", "1", "--end_period", "4", "--rolling"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    cum = [int(x) for x in re.findall(r"Cumulative iterations[ .]*(\d+)", r.stdout)]
+    obj = [float(x) for x in re.findall(r"Objective value[ .]*([-+0-9.eE]+)", r.stdout)]
+    assert cum == [res[t]["cumul"] for t in range(4)]
+    assert all(abs(obj[t] - res[t]["objval"]) <= 1e-5 * abs(res[t]["objval"]) for t in range(4))

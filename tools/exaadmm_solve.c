@@ -10,6 +10,9 @@
  *
  * With --load_prefix the multi-period model is solved (interface/solve_mpacopf.jl with warm_start=false):
  * P.Pd / P.Qd are whitespace matrices nbus x T (utils/opfdata.jl:121-130), periods A..B (1-based) are used.
+ * With --rolling in addition, the periods are solved one after another instead (interface/solve_acopf_rolling.jl,
+ * models/acopf/acopf_admm_rolling_cpu.jl:16-48): load swap, warm start from the previous period, generation
+ * bounds limited to +-ramp_ratio*pgmax around the previous dispatch.
  *
  * Exit code 0 = solved, 1 = iteration limit, 2 = error (message on stderr).
  */
@@ -60,7 +63,7 @@ int main(int argc, char **argv)
     }
     const char *path = argv[1];
     double rho_pq = 4e2, rho_va = 4e4, tight = 1.0, ramp_ratio = 0.02;
-    int gpu = 0, quiet = 0, p0 = 1, p1 = 1;
+    int gpu = 0, quiet = 0, p0 = 1, p1 = 1, rolling = 0;
     const char *load_prefix = NULL;
     const char *fmt = "matpower";
     exaadmm_params par;
@@ -83,6 +86,7 @@ int main(int argc, char **argv)
         else if (OPT("--ramp_ratio")) ramp_ratio = atof(v);
         else if (strcmp(a, "--pglib") == 0) fmt = "pglib";
         else if (strcmp(a, "--quiet") == 0) quiet = 1;
+        else if (strcmp(a, "--rolling") == 0) rolling = 1;
         else {
             fprintf(stderr, "exaadmm_solve: unknown or incomplete option %s\n", a);
             return 2;
@@ -97,13 +101,14 @@ int main(int argc, char **argv)
     if (exaadmm_case_grid(cs, &grid) != EXAADMM_OK) return fail("grid");
     exaadmm_handle *h = NULL;
     int rc_create;
+    double *pd = NULL, *qd = NULL;
     if (load_prefix) {
         char fn[4096];
         int T1 = 0, T2 = 0;
         snprintf(fn, sizeof(fn), "%s.Pd", load_prefix);
-        double *pd = read_load(fn, (long)grid.nbus, &T1);
+        pd = read_load(fn, (long)grid.nbus, &T1);
         snprintf(fn, sizeof(fn), "%s.Qd", load_prefix);
-        double *qd = read_load(fn, (long)grid.nbus, &T2);
+        qd = read_load(fn, (long)grid.nbus, &T2);
         if (!pd || !qd || T1 != T2 || p0 < 1 || p1 < p0 || p1 > T1) {
             fprintf(stderr, "exaadmm_solve: load files %s.Pd/.Qd missing, not nbus x T, or periods out of range\n", load_prefix);
             free(pd);
@@ -111,17 +116,56 @@ int main(int argc, char **argv)
             exaadmm_case_free(cs);
             return 2;
         }
+    } else if (rolling) {
+        fprintf(stderr, "exaadmm_solve: --rolling needs --load_prefix\n");
+        exaadmm_case_free(cs);
+        return 2;
+    }
+    if (load_prefix && !rolling)
         rc_create = exaadmm_mp_create(&grid, &par, p1 - p0 + 1, pd + (size_t)(p0 - 1) * grid.nbus, qd + (size_t)(p0 - 1) * grid.nbus,
                                       ramp_ratio, gpu, &h);
+    else
+        rc_create = exaadmm_create(&grid, &par, gpu, &h);
+    if (rc_create != EXAADMM_OK) {
         free(pd);
         free(qd);
-    } else {
-        rc_create = exaadmm_create(&grid, &par, gpu, &h);
-    }
-    if (rc_create != EXAADMM_OK) {
         exaadmm_case_free(cs);
         return fail("create");
     }
+    if (rolling) {
+        /* admm_restart_rolling (acopf_admm_rolling_cpu.jl:16-48) */
+        const long G = (long)grid.ngen, nvar = (long)exaadmm_nvar(h);
+        double *u = (double *)malloc((size_t)nvar * sizeof(double));
+        double *lo = (double *)malloc((size_t)(G > 0 ? G : 1) * sizeof(double)), *hi = (double *)malloc((size_t)(G > 0 ? G : 1) * sizeof(double));
+        int rc = exaadmm_init_solution(h, rho_pq, rho_va), all_solved = 1;
+        exaadmm_info info;
+        for (int t = p0; rc == EXAADMM_OK && t <= p1; t++) {
+            rc = exaadmm_set_load(h, pd + (size_t)(t - 1) * grid.nbus, qd + (size_t)(t - 1) * grid.nbus, grid.nbus);
+            if (rc == EXAADMM_OK) rc = exaadmm_solve_two_level(h, &info);
+            if (rc != EXAADMM_OK) break;
+            printf(" ** Statistics of time period %d\n", t);
+            printf("Status  . . . . . . . . . . . . . . . . . %s\n", info.status == 1 ? "Solved" : "IterationLimit");
+            printf("Objective value . . . . . . . . . . . . . %.6e\n", info.objval);
+            printf("Residual  . . . . . . . . . . . . . . . . %.6e\n", info.mismatch);
+            printf("Cumulative iterations . . . . . . . . . . %d\n", info.cumul);
+            printf("Time (secs) . . . . . . . . . . . . . . . %5.3f\n", info.time_overall);
+            all_solved = all_solved && info.status == 1;
+            rc = exaadmm_download_solution(h, EXAADMM_U_CURR, u, nvar);
+            for (long g = 0; g < G; g++) {   /* update_real_power_current_bounds (:1-14) */
+                const double r = ramp_ratio * grid.pgmax[g];
+                lo[g] = grid.pgmin[g] > u[2 * g] - r ? grid.pgmin[g] : u[2 * g] - r;
+                hi[g] = grid.pgmax[g] < u[2 * g] + r ? grid.pgmax[g] : u[2 * g] + r;
+            }
+            if (rc == EXAADMM_OK && G > 0) rc = exaadmm_set_pg_bounds(h, lo, hi, G);
+        }
+        free(u); free(lo); free(hi); free(pd); free(qd);
+        if (rc != EXAADMM_OK) fail("rolling solve");
+        exaadmm_destroy(h);
+        exaadmm_case_free(cs);
+        return rc != EXAADMM_OK ? 2 : (all_solved ? 0 : 1);
+    }
+    free(pd);
+    free(qd);
     int rc = exaadmm_init_solution(h, rho_pq, rho_va);
     exaadmm_info info;
     memset(&info, 0, sizeof(info));

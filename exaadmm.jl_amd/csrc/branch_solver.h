@@ -37,18 +37,6 @@ struct BranchData {
     EXA_HD double Y(int k) const { return Y_[k]; }
 };
 
-// hybrid: multipliers / penalties / targets in registers, the 8 admittance entries in LDS planes
-template <int STRIDE>
-struct BranchDataYRef {
-    double lam_[8], rho_[8], xt_[8];
-    const double* yp;
-    double ls1, ls2, mu, scale;
-    EXA_HD double lam(int k) const { return lam_[k]; }
-    EXA_HD double rho(int k) const { return rho_[k]; }
-    EXA_HD double xt(int k) const { return xt_[k]; }
-    EXA_HD double Y(int k) const { return yp[k * STRIDE]; }
-};
-
 template <int STRIDE>
 struct BranchDataRef {
     const double* p;  // 32 entries: lam[8] rho[8] xt[8] Y[8]

@@ -150,8 +150,6 @@ constexpr int BR_LDS_CONST = 32, BR_LDS_MAT = 21;
 constexpr int BR_LDS_DOUBLES = BR_LDS_CONST + 2 * BR_LDS_MAT;
 #elif defined(EXA_A_IN_LDS) || defined(EXA_L_IN_LDS)
 constexpr int BR_LDS_DOUBLES = BR_LDS_CONST + BR_LDS_MAT;
-#elif defined(EXA_Y_IN_LDS)
-constexpr int BR_LDS_DOUBLES = 8;
 #elif defined(EXA_CONST_IN_REGS)
 constexpr int BR_LDS_DOUBLES = 0;
 #else
@@ -166,7 +164,7 @@ template <bool MP>
 __global__ void __launch_bounds__(BR_BLOCK) k_branch_t(const Dev* __restrict__ dp, BranchOptions o, double scale, int major_iter, const Ctrl* ctrl,
                                                        int gen_blocks, double baseMVA)
 {
-#if defined(EXA_CONST_IN_REGS) && !defined(EXA_A_IN_LDS) && !defined(EXA_L_IN_LDS) && !defined(EXA_Y_IN_LDS)
+#if defined(EXA_CONST_IN_REGS) && !defined(EXA_A_IN_LDS) && !defined(EXA_L_IN_LDS)
     double* const lds = nullptr;   // no LDS at all in the default build
 #else
     __shared__ double lds[(BR_LDS_DOUBLES > 0 ? BR_LDS_DOUBLES : 1) * BR_BLOCK];
@@ -200,20 +198,7 @@ __global__ void __launch_bounds__(BR_BLOCK) k_branch_t(const Dev* __restrict__ d
     double* my = lds + threadIdx.x;
 
     double ub[8], bnd[8];
-#if defined(EXA_Y_IN_LDS)
-    BranchDataYRef<BR_BLOCK> bd;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const int e = base + k * Lp;
-        ub[k] = d.u[e];
-        bd.lam_[k] = d.l[e];
-        bd.rho_[k] = d.rho[e];
-        bd.xt_[k] = d.v[e] - d.z[e];
-        my[k * BR_BLOCK] = d.Y[b + k * Lp];
-        bnd[k] = d.bnd[b + k * Lp];
-    }
-    bd.yp = my;
-#elif defined(EXA_CONST_IN_REGS)
+#if defined(EXA_CONST_IN_REGS)
     BranchData bd;
 #pragma unroll
     for (int k = 0; k < 8; k++) {

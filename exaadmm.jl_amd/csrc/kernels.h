@@ -405,7 +405,7 @@ __global__ void k_bus(Dev d, double baseMVA, const Ctrl* ctrl)
 //     of its own component from the registers it already holds.
 // Buses with more than BUS_W incident components are processed in chunks.
 constexpr int BUS_W = 8;
-constexpr int BUS_BLOCK = 256;
+constexpr int BUS_BLOCK = 256;   // measured at 13 659 buses: 64 -> 15.1, 128 -> 14.5, 256 -> 12.4, 512 -> 11.9, 1024 -> 13.2 us; 512 loses 5 % of the non-branch time at 1M branches
 constexpr int BUS_REC = 16;  // doubles per record: (u,z,l,rho) x (p,q,w,theta) or (u,z,l,rho) x (pg,qg)
 enum { END_GEN = 0, END_FROM = 1, END_TO = 2 };
 

@@ -531,3 +531,27 @@ def test_plain_c_driver_rolling_horizon_matches_python_mirror(pkg, case9_grid, t
     obj = [float(x) for x in re.findall(r"Objective value[ .]*([-+0-9.eE]+)", r.stdout)]
     assert cum == [res[t]["cumul"] for t in range(4)]
     assert all(abs(obj[t] - res[t]["objval"]) <= 1e-5 * abs(res[t]["objval"]) for t in range(4))
+
+
+def test_checkpoint_and_resume_through_the_abi(pkg, syn):
+    """The state of the path is the Solution vectors + membuf rows 25-27/29 (+ the ramp-limited
+    generator bounds): downloading them, building a NEW device model and uploading them resumes the
+    iteration bit for bit (what a Julia-side checkpoint of mod.solution / mod.membuf relies on)."""
+    g = syn.sized_like("case1354pegase", seed=5)
+    env = pkg.AdmmEnv("syn", 1e1, 1e3, verbose=0, grid=g)
+    a = pkg.ModelAcopf(env)
+    a.run_fixed(30, first_major_iter=1, beta=1e3)
+    names = ("u_curr", "v_curr", "z_curr", "z_prev", "l_curr", "lz", "rho")
+    snap = {n: a.download(n) for n in names}
+    mb = a.membuf.copy()
+    ra = a.run_fixed(10, first_major_iter=31, beta=1e3)[0]
+
+    b = pkg.ModelAcopf(env)                      # fresh handle = "restart of the process"
+    for n in names:
+        b.upload(n, snap[n])
+    b.membuf = mb
+    rb = b.run_fixed(10, first_major_iter=31, beta=1e3)[0]
+    assert np.array_equal(ra, rb)
+    for n in names:
+        assert np.array_equal(a.download(n), b.download(n)), n
+    assert np.array_equal(a.membuf, b.membuf)

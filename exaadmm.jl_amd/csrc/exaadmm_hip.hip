@@ -99,6 +99,14 @@ struct exaadmm_handle {
     bool residual_vectors_valid = false;
     bool async_mode = false;
     bool bus_lane_kernel = false;
+    // speculative branch launch (kernels.h, k_branch_t): second set of the buffers the branch kernel writes,
+    // the two Dev variants (odd / even iteration) on host and device, a pinned word for the batch base
+    bool spec_on = false;
+    double *u_alt = nullptr, *ls1_alt = nullptr, *ls2_alt = nullptr, *mu_alt = nullptr;
+    Dev dspec[2];
+    Dev* d_dspec[2] = {nullptr, nullptr};
+    int* h_base = nullptr;
+    hipGraphExec_t spec_graph = nullptr;
     bool ctrl_mode = false;
     exaadmm_info info;
     std::vector<hipEvent_t> ev;
@@ -201,6 +209,10 @@ static void invalidate_graph(exaadmm_handle* h)
     if (h->batch_graph) {
         (void)hipGraphExecDestroy(h->batch_graph);
         h->batch_graph = nullptr;
+    }
+    if (h->spec_graph) {
+        (void)hipGraphExecDestroy(h->spec_graph);
+        h->spec_graph = nullptr;
     }
 }
 
@@ -346,6 +358,7 @@ extern "C" int exaadmm_create(const exaadmm_grid* g, const exaadmm_params* p, in
         const char* e = getenv("EXAADMM_BUS_KERNEL");
         h->bus_lane_kernel = (e != nullptr && strcmp(e, "lane") == 0);
         h->use_graph = (getenv("EXAADMM_NO_GRAPH") == nullptr);
+        h->spec_on = (getenv("EXAADMM_NO_SPEC") == nullptr);   // speculative branch launch (A/B switch)
     }
     TRY(upload_mupow_table());
 
@@ -480,6 +493,8 @@ extern "C" int exaadmm_destroy(exaadmm_handle* h)
     if (h->d_owned) (void)hipFree(h->d_owned);
     if (h->d_lane_order) (void)hipFree(h->d_lane_order);
     if (h->batch_graph) (void)hipGraphExecDestroy(h->batch_graph);
+    if (h->spec_graph) (void)hipGraphExecDestroy(h->spec_graph);
+    if (h->h_base) (void)hipHostFree(h->h_base);
     if (h->h_ctrl) (void)hipHostFree(h->h_ctrl);
     if (h->h_sums) (void)hipHostFree(h->h_sums);
     for (auto e : h->ev) (void)hipEventDestroy(e);
@@ -900,9 +915,9 @@ static void launch_branch(exaadmm_handle* h, int major_iter, const Ctrl* c, bool
     const int nb = (int)grid_for(h->d.La, BR_BLOCK).x;
     const int ng = (with_generators && h->G > 0) ? (int)grid_for(h->G, BR_BLOCK).x : 0;
     if (h->T > 1)
-        hipLaunchKernelGGL((k_branch_t<true>), dim3(nb + ng), dim3(BR_BLOCK), 0, h->stream, h->d_dev, h->bo, h->par.scale, major_iter, c, ng, h->baseMVA);
+        hipLaunchKernelGGL((k_branch_t<true>), dim3(nb + ng), dim3(BR_BLOCK), 0, h->stream, h->d_dev, h->bo, h->par.scale, major_iter, const_cast<Ctrl*>(c), ng, h->baseMVA, -1);
     else
-        hipLaunchKernelGGL((k_branch_t<false>), dim3(nb + ng), dim3(BR_BLOCK), 0, h->stream, h->d_dev, h->bo, h->par.scale, major_iter, c, ng, h->baseMVA);
+        hipLaunchKernelGGL((k_branch_t<false>), dim3(nb + ng), dim3(BR_BLOCK), 0, h->stream, h->d_dev, h->bo, h->par.scale, major_iter, const_cast<Ctrl*>(c), ng, h->baseMVA, -1);
 }
 static void launch_bus(exaadmm_handle* h, const Ctrl* c)
 {
@@ -916,7 +931,7 @@ static void launch_fused_zl(exaadmm_handle* h, double beta, const Ctrl* c)
     if (h->T > 1)
         launch_mp_elem<MP_FUSED_ZL>(h, beta, c);
     else
-        hipLaunchKernelGGL(k_fused_zl, dim3(h->ew_blocks), dim3(EW_BLOCK), 0, h->stream, h->d, beta, c);
+        hipLaunchKernelGGL(k_fused_zl, dim3(h->ew_blocks), dim3(EW_BLOCK), 0, h->stream, h->d, beta, c, (int*)nullptr);
 }
 // single-period: d_sums receives the four SUMS OF SQUARES; multi-period: the four NORMS (max over periods)
 static void launch_final(exaadmm_handle* h, Ctrl* c, double* out = nullptr)
@@ -926,7 +941,7 @@ static void launch_final(exaadmm_handle* h, Ctrl* c, double* out = nullptr)
                            h->T, out ? out : h->d_sums, c);
     else
         hipLaunchKernelGGL(k_final_reduce, dim3(1), dim3(EW_BLOCK), 0, h->stream, h->d.partials, h->ew_blocks,
-                           out ? out : h->d_sums, c);
+                           out ? out : h->d_sums, c, 0);
 }
 
 static int sync_check(exaadmm_handle* h, bool force)
@@ -1179,6 +1194,136 @@ extern "C" int exaadmm_debug_wave_timeline(exaadmm_handle* h, unsigned long long
     return EXAADMM_OK;
 }
 
+// ------------------------------------------------------------------ speculative branch launch
+// (kernels.h, k_branch_t: the final reduction of iteration k rides in the branch launch of iteration k+1)
+static bool spec_eligible(const exaadmm_handle* h)
+{
+    return h->spec_on && h->T == 1 && h->d.owned == nullptr && h->d.La == h->L && h->d.Ba == h->B && !h->ctrl_mode;
+}
+
+static int spec_prepare(exaadmm_handle* h)
+{
+    if (!h->u_alt) {
+        int rc;
+        if ((rc = dev_alloc(h, &h->u_alt, (size_t)h->N))) return rc;
+        if ((rc = dev_alloc(h, &h->ls1_alt, (size_t)h->Lp))) return rc;
+        if ((rc = dev_alloc(h, &h->ls2_alt, (size_t)h->Lp))) return rc;
+        if ((rc = dev_alloc(h, &h->mu_alt, (size_t)h->Lp))) return rc;
+        if ((rc = dev_alloc(h, &h->d_dspec[0], 1))) return rc;
+        if ((rc = dev_alloc(h, &h->d_dspec[1], 1))) return rc;
+        if (hipHostMalloc((void**)&h->h_base, sizeof(int), hipHostMallocDefault) != hipSuccess) {
+            set_err("hipHostMalloc failed");
+            return EXAADMM_ERR_HIP;
+        }
+        // padding entries (never written by the branch kernel) must agree in both sets
+        HIPCHK(hipMemcpyAsync(h->u_alt, h->d.u, (size_t)h->N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemsetAsync(h->ls1_alt, 0, (size_t)h->Lp * sizeof(double), h->stream));
+        HIPCHK(hipMemsetAsync(h->ls2_alt, 0, (size_t)h->Lp * sizeof(double), h->stream));
+        HIPCHK(hipMemsetAsync(h->mu_alt, 0, (size_t)h->Lp * sizeof(double), h->stream));
+    }
+    // odd iteration (j even): read the primary set, write the alternate one; even iteration: the reverse
+    Dev a = h->d, b = h->d;
+    a.u_in = h->d.u;      a.u = h->u_alt;
+    a.ls1_in = h->d.ls1;  a.ls1 = h->ls1_alt;
+    a.ls2_in = h->d.ls2;  a.ls2 = h->ls2_alt;
+    a.mu_in = h->d.mu;    a.mu = h->mu_alt;
+    b.u_in = h->u_alt;    b.ls1_in = h->ls1_alt;  b.ls2_in = h->ls2_alt;  b.mu_in = h->mu_alt;
+    a.npartials = b.npartials = h->ew_blocks;
+    if (memcmp(&a, &h->dspec[0], sizeof(Dev)) != 0 || memcmp(&b, &h->dspec[1], sizeof(Dev)) != 0) {
+        invalidate_graph(h);
+        h->dspec[0] = a;
+        h->dspec[1] = b;
+        HIPCHK(hipMemcpyAsync(h->d_dspec[0], &h->dspec[0], sizeof(Dev), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_dspec[1], &h->dspec[1], sizeof(Dev), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return 0;
+}
+
+// iteration base + j + 1 of the speculative loop (j = position inside the batch; base is even)
+static void enqueue_iteration_spec(exaadmm_handle* h, Ctrl* c, int j, bool sample = false, hipEvent_t* bev = nullptr)
+{
+    const int par = j & 1;
+    const Dev& dv = h->dspec[par];
+    const int nb = (int)grid_for(h->d.La, BR_BLOCK).x;
+    const int ng = (h->G > 0) ? (int)grid_for(h->G, BR_BLOCK).x : 0;
+    if (sample) (void)hipEventRecord(h->tev[0], h->stream);
+    if (bev) (void)hipEventRecord(bev[0], h->stream);
+    hipLaunchKernelGGL((k_branch_t<false>), dim3(nb + ng + 1), dim3(BR_BLOCK), 0, h->stream, h->d_dspec[par], h->bo, h->par.scale, 0, c,
+                       ng, h->baseMVA, j);
+    if (bev) (void)hipEventRecord(bev[1], h->stream);
+    if (sample) (void)hipEventRecord(h->tev[1], h->stream);
+    if (h->bus_lane_kernel)
+        hipLaunchKernelGGL(k_bus, grid_for(h->d.Ba, 64), dim3(64), 0, h->stream, dv, h->baseMVA, c);
+    else
+        hipLaunchKernelGGL(k_bus_group, grid_for(h->d.Ba, BUS_BLOCK / BUS_W), dim3(BUS_BLOCK), 0, h->stream, dv, h->baseMVA, c);
+    if (sample) (void)hipEventRecord(h->tev[2], h->stream);
+    hipLaunchKernelGGL(k_fused_zl, dim3(h->ew_blocks), dim3(EW_BLOCK), 0, h->stream, dv, 0.0, c, &c->pending);
+    if (sample) (void)hipEventRecord(h->tev[3], h->stream);
+}
+
+// after a speculative loop of `iters` completed iterations the valid iterate sits in the alternate set
+// when `iters` is odd: bring it home so that every other entry point keeps using the primary buffers
+static int spec_finish(exaadmm_handle* h, int iters)
+{
+    if (iters & 1) {
+        HIPCHK(hipMemcpyAsync(h->d.u, h->u_alt, (size_t)h->N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d.ls1, h->ls1_alt, (size_t)h->Lp * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d.ls2, h->ls2_alt, (size_t)h->Lp * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d.mu, h->mu_alt, (size_t)h->Lp * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    }
+    return 0;
+}
+
+static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
+{
+    int rc = spec_prepare(h);
+    if (rc) return rc;
+    const int batch = 8;
+    const bool graph_ok = h->use_graph && h->stream == h->own_stream;
+    float ms_sample[3] = {0.f, 0.f, 0.f};
+    int enq = 0;
+    bool first = true;
+    while (enq < max_inner) {
+        const int nb = std::min(batch, max_inner - enq);
+        *h->h_base = enq;   // the stream is idle here (synchronised at the end of every batch)
+        HIPCHK(hipMemcpyAsync(&h->d_ctrl->base, h->h_base, sizeof(int), hipMemcpyHostToDevice, h->stream));
+        if (!first && graph_ok && nb == batch) {
+            if (!h->spec_graph) {
+                hipGraph_t g = nullptr;
+                HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+                for (int j = 0; j < batch; j++) enqueue_iteration_spec(h, h->d_ctrl, j);
+                HIPCHK(hipStreamEndCapture(h->stream, &g));
+                hipError_t e = hipGraphInstantiate(&h->spec_graph, g, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(g);
+                if (e != hipSuccess) {
+                    set_err("hipGraphInstantiate failed: %s", hipGetErrorString(e));
+                    return EXAADMM_ERR_HIP;
+                }
+            }
+            HIPCHK(hipGraphLaunch(h->spec_graph, h->stream));
+        } else {
+            for (int j = 0; j < nb; j++) enqueue_iteration_spec(h, h->d_ctrl, j, first && j == 0);
+        }
+        enq += nb;
+        HIPCHK(hipMemcpyAsync(hc, h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
+        if ((rc = sync_check(h, true))) return rc;
+        if (first) {
+            for (int q = 0; q < 3; q++)
+                if (hipEventElapsedTime(&ms_sample[q], h->tev[q], h->tev[q + 1]) != hipSuccess) ms_sample[q] = 0.f;
+            first = false;
+        }
+        if (hc->done) break;
+    }
+    // the last enqueued iteration has no successor whose branch launch would reduce its sums
+    hipLaunchKernelGGL(k_final_reduce, dim3(1), dim3(EW_BLOCK), 0, h->stream, h->d.partials, h->ew_blocks, h->d_sums, h->d_ctrl, 1);
+    HIPCHK(hipMemcpyAsync(hc, h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
+    if ((rc = sync_check(h, true))) return rc;
+    if ((rc = spec_finish(h, hc->inner))) return rc;
+    for (int q = 0; q < 3; q++) h->acc_ms[q] += (double)ms_sample[q] * hc->inner;
+    return 0;
+}
+
 // ------------------------------------------------------------------ fused loops
 static void enqueue_iteration(exaadmm_handle* h, Ctrl* c, bool sample = false)
 {
@@ -1221,6 +1366,14 @@ extern "C" int exaadmm_run_inner(exaadmm_handle* h, int outer, int max_inner, do
         invalidate_graph(h);
         HIPCHK(hipMemcpyAsync(h->d_dev, &h->d, sizeof(Dev), hipMemcpyHostToDevice, h->stream));
         h->dev_dirty = false;
+    }
+    if (spec_eligible(h)) {
+        int rc = run_inner_spec(h, max_inner, hc);
+        if (rc) return rc;
+        if (inner_done) *inner_done = hc->inner;
+        if (out)
+            for (int j = 0; j < 4; j++) out[j] = hc->res[j];
+        return EXAADMM_OK;
     }
     float ms_sample[3] = {0.f, 0.f, 0.f};
     bool first = true;
@@ -1328,6 +1481,42 @@ extern "C" int exaadmm_run_fixed(exaadmm_handle* h, int iters, int first_major_i
         h->ev.push_back(e);
     }
     h->residual_vectors_valid = false;
+    if (spec_eligible(h)) {
+        // same kernels as the fused loop, with a control block that never stops: the reduction of iteration k
+        // rides in the branch launch of iteration k+1, the last one is reduced by a stand-alone launch
+        int rc = spec_prepare(h);
+        if (rc) return rc;
+        Ctrl* hc = h->h_ctrl;
+        memset(hc, 0, sizeof(Ctrl));
+        hc->max_inner = 0x7fffffff;
+        hc->check_every = 1;
+        hc->eps_pri = -1.0;
+        hc->beta = beta;
+        hc->base = first_major_iter - 1;
+        HIPCHK(hipMemcpyAsync(h->d_ctrl, hc, sizeof(Ctrl), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipEventRecord(h->ev[0], h->stream));
+        for (int i = 0; i < iters; i++) enqueue_iteration_spec(h, h->d_ctrl, i, false, time_branch ? &h->ev[2 + 2 * i] : nullptr);
+        hipLaunchKernelGGL(k_final_reduce, dim3(1), dim3(EW_BLOCK), 0, h->stream, h->d.partials, h->ew_blocks, h->d_sums, h->d_ctrl, 1);
+        HIPCHK(hipEventRecord(h->ev[1], h->stream));
+        if ((rc = spec_finish(h, iters))) return rc;
+        double s[4];
+        if ((rc = fetch_sums(h, s, true))) return rc;
+        if (out)
+            for (int j = 0; j < 4; j++) out[j] = s[j];
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+        if (ms_total) *ms_total = ms;
+        if (time_branch) {
+            double acc = 0.0;
+            for (int i = 0; i < iters; i++) {
+                HIPCHK(hipEventElapsedTime(&ms, h->ev[2 + 2 * i], h->ev[3 + 2 * i]));
+                acc += ms;
+            }
+            *ms_branch = acc / iters;
+        }
+        return EXAADMM_OK;
+    }
     HIPCHK(hipEventRecord(h->ev[0], h->stream));
     for (int i = 0; i < iters; i++) {
         if (time_branch) HIPCHK(hipEventRecord(h->ev[2 + 2 * i], h->stream));

@@ -503,8 +503,14 @@ __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group(Dev d, double baseMVA, 
     if (loop_done(ctrl)) return;
     const int grp = threadIdx.x / BUS_W, lane = threadIdx.x % BUS_W;
     const int I = blockIdx.x * (BUS_BLOCK / BUS_W) + grp;
+#if defined(EXA_PROFILE_PHASES)
+    unsigned long long tb0 = __builtin_amdgcn_s_memtime(), tb1 = 0, tb2 = 0, tb3 = 0, tb4 = 0;
+#endif
     if (I >= d.Ba) return;   // whole groups leave together
     const int e0 = d.EndStart[I], n = d.EndStart[I + 1] - e0;
+#if defined(EXA_PROFILE_PHASES)
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb1) : "v"(n) : "memory");
+#endif
 
     // leader state (meaningful in lane 0 only)
     double common_wi = 0.0, common_ti = 0.0, inv_rhosum_p = 0.0, inv_rhosum_q = 0.0;
@@ -520,6 +526,9 @@ __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group(Dev d, double baseMVA, 
             const int code = d.EndCode[e0 + c0 + lane];
             kind = code >> 28;
             bus_load_end(d, code, r, idx);
+#if defined(EXA_PROFILE_PHASES)
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb2) : "v"(r[0]) : "memory");
+#endif
             kinds[grp][lane] = kind;
             if (idx[2] <= -2) {  // generator with a ramp partner (mpacopf_bus_kernel_cpu.jl:53-62)
                 const double den = r[3] + r[11];
@@ -590,6 +599,9 @@ __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group(Dev d, double baseMVA, 
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const double mu1 = res[grp][0], mu2 = res[grp][1], wi = res[grp][2], ti = res[grp][3];
+#if defined(EXA_PROFILE_PHASES)
+    tb3 = __builtin_amdgcn_s_memtime();
+#endif
 
     for (int c0 = 0; c0 < n; c0 += BUS_W) {
         const int m = min(BUS_W, n - c0);
@@ -613,6 +625,13 @@ __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group(Dev d, double baseMVA, 
             }
         }
     }
+#if defined(EXA_PROFILE_PHASES)
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb4) : : "memory");
+    if (d.st_tl && threadIdx.x == 0 && blockIdx.x < 256) {   // per block: entry, CSR landed, gathers landed, leader done, stores landed
+        unsigned long long* q = d.st_tl + (size_t)blockIdx.x * 8;
+        q[0] = tb0; q[1] = tb1; q[2] = tb2; q[3] = tb3; q[4] = tb4;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------- elementwise, step-wise

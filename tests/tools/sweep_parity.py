@@ -10,8 +10,9 @@ pkg = exaadmm_loader.load_package()
 syn = exaadmm_loader.load_submodule("synthetic")
 from oracle import oracle as O
 bad = 0
-for case, rho, inner in (("case118", (4e2, 4e4), 150), ("case1354pegase", (1e1, 1e3), 120)):
-    for seed in range(6):
+for case, rho, inner, nseed in (("case118", (4e2, 4e4), 150, 6), ("case1354pegase", (1e1, 1e3), 120, 6),
+                                ("case13659pegase", (5e1, 5e3), 60, 2)):
+    for seed in range(nseed):
         g = syn.sized_like(case, seed=seed)
         kw = dict(outer_iterlim=3, inner_iterlim=inner, rho_pq=rho[0], rho_va=rho[1], scale=1e-4)
         env, mod = pkg.solve_acopf(case, grid=g, verbose=0, **kw)

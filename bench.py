@@ -98,6 +98,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU).  This parent has
+        # not touched the GPU (no torch.cuda / HIP call yet), it only forwards the children's output and exit code.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stderr.write("bench.py: launching %d ranks: %s\n" % (args.gpus, " ".join(cmd)))
+        raise SystemExit(subprocess.call(cmd))
+    if world > 1 and args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d; launch with --nproc-per-node equal to --gpus" % (args.gpus, world))
     if args.gpus > 1 or world > 1 or args.force_dist:
         import exaadmm_loader
         dist_mod = exaadmm_loader.load_submodule("distributed")

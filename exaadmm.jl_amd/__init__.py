@@ -89,6 +89,11 @@ def library():
     L = C.CDLL(LIB_PATH)
     H = C.c_void_p
     L.exaadmm_version.restype = C.c_char_p
+    ver = L.exaadmm_version().decode()
+    if "-sgpr-regalloc=basic" not in ver:
+        # ROCm 7.2 miscompiles the branch kernel with the default SGPR allocator (csrc/Makefile)
+        raise ExaAdmmError("%s was not built through csrc/Makefile (version string %r lacks -sgpr-regalloc=basic): "
+                           "its branch kernel cannot be trusted" % (LIB_PATH, ver))
     L.exaadmm_last_error.restype = C.c_char_p
     L.exaadmm_io_error.restype = C.c_char_p
     L.exaadmm_default_params.argtypes = [C.POINTER(Parameters)]
@@ -745,16 +750,16 @@ def solve_mpacopf(case, load_prefix=None, load=None, case_format="matpower", sta
         mb = mod.membuf
         Ln = mod.nline
         single = ModelAcopf(env)
+        mb0 = single.membuf.copy()   # membuf as constructed (zeros, row 29 = rateA): every models[i] starts from it
         for t in range(mod.len_horizon):
             _check(library().exaadmm_init_solution(single.handle, env.initial_rho_pq, env.initial_rho_va), "exaadmm_init_solution")
-            if t > 0:   # copy(models[1]) in the reference: membuf of period 1 as constructed (zeros)
-                pass
+            single.membuf = mb0
             single.set_load(mod._pd[t], mod._qd[t])
             admm_two_level(env, single, fused=fused)
             mb[:, t * Ln:(t + 1) * Ln] = single.membuf
         single.close()
-        mod.init_solution()
-        mod.membuf = mb
+        mod.membuf = mb          # the periods' solved multipliers ...
+        mod.init_solution()      # ... survive init_solution! (it resets the vectors only), as in the reference
     admm_two_level(env, mod, fused=fused)
     if verbose > 0:
         print_statistics(env, mod)

@@ -96,6 +96,12 @@ EXA_HD void flow_trig(const D& d, const double (&x)[6], double sn, double cs, Fl
     t.vi2 = x[0] * x[0];
     t.vj2 = x[1] * x[1];
     t.vv = x[0] * x[1];
+#if defined(EXA_EXACT_ORACLE_ARITH)
+    t.E0 = x[0] * x[1] * cs;   // vi_vj_cos
+    t.F0 = x[0] * x[1] * sn;   // vi_vj_sin
+    t.E2 = t.F2 = 0.0;
+    return;
+#endif
     t.E0 = d.Y(2) * cs + d.Y(3) * sn;
     t.F0 = d.Y(3) * cs - d.Y(2) * sn;
     t.E2 = d.Y(6) * cs - d.Y(7) * sn;
@@ -106,10 +112,19 @@ EXA_HD void flow_trig(const D& d, const double (&x)[6], double sn, double cs, Fl
 template <class D>
 EXA_HD void flows_from_trig(const D& d, const FlowTrig& t, double (&phi)[4])
 {
+#if defined(EXA_EXACT_ORACLE_ARITH)
+    // operation order of the CPU path (acopf_eval_linelimit_kernel_cpu.jl:11-16, in the form the tests' CPU
+    // restatement evaluates it); t.E0 / t.F0 carry vi vj cos / vi vj sin in this build
+    phi[0] = d.Y(0) * t.vi2 + d.Y(2) * t.E0 + d.Y(3) * t.F0;
+    phi[1] = -d.Y(1) * t.vi2 - d.Y(3) * t.E0 + d.Y(2) * t.F0;
+    phi[2] = d.Y(4) * t.vj2 + d.Y(6) * t.E0 - d.Y(7) * t.F0;
+    phi[3] = -d.Y(5) * t.vj2 - d.Y(7) * t.E0 - d.Y(6) * t.F0;
+#else
     phi[0] = d.Y(0) * t.vi2 + t.vv * t.E0;
     phi[1] = -d.Y(1) * t.vi2 - t.vv * t.F0;
     phi[2] = d.Y(4) * t.vj2 + t.vv * t.E2;
     phi[3] = -d.Y(5) * t.vj2 + t.vv * t.F2;
+#endif
 }
 
 // flows at x; sc[0] = sin, sc[1] = cos of the angle difference are returned for later g/H evaluations at x
@@ -168,13 +183,113 @@ EXA_HD double branch_f_known(const D& d, const double (&x)[6], const double (&ph
 struct GradParts {
     FlowTrig t;
     double E[4], F[4], J[4][3], w[4], r[4], d1[3], d2[3], wvi, wvj;
+#if defined(EXA_EXACT_ORACLE_ARITH)
+    double Apk[21];   // packed lower triangle of the Hessian, assembled with the gradient
+#endif
 };
+
+#if defined(EXA_EXACT_ORACLE_ARITH)
+// Gradient and Hessian in the operation order of the tests' CPU restatement of the reference callbacks
+// (acopf_eval_linelimit_kernel_cpu.jl:48-605; chain-rule form): the flows are re-evaluated from x inside
+// the derivative code and every sum runs in that restatement's order, so results are bitwise comparable.
+template <class D>
+EXA_BIG void branch_gh_exact(const D& d, const double (&x)[6], double (&g)[6], GradParts& q)
+{
+    const double a_[4] = {d.Y(0), -d.Y(1), 0.0, 0.0}, b_[4] = {0.0, 0.0, d.Y(4), -d.Y(5)};
+    const double al[4] = {d.Y(2), -d.Y(3), d.Y(6), -d.Y(7)}, be[4] = {d.Y(3), d.Y(2), -d.Y(7), -d.Y(6)};
+    const double vi = x[0], vj = x[1];
+    const double cs = cos(x[2] - x[3]), sn = sin(x[2] - x[3]);
+    const double mu = d.mu, scale = d.scale;
+    double phi[4], J[4][4], H[4][4][4];
+    for (int k = 0; k < 4; k++) {
+        const double E = al[k] * cs + be[k] * sn;
+        const double F = -al[k] * sn + be[k] * cs;
+        phi[k] = a_[k] * vi * vi + b_[k] * vj * vj + vi * vj * E;
+        J[k][0] = 2 * a_[k] * vi + vj * E;
+        J[k][1] = 2 * b_[k] * vj + vi * E;
+        J[k][2] = vi * vj * F;
+        J[k][3] = -J[k][2];
+        for (int i = 0; i < 4; i++)
+            for (int j = 0; j < 4; j++) H[k][i][j] = 0.0;
+        H[k][0][0] = 2 * a_[k];
+        H[k][1][1] = 2 * b_[k];
+        H[k][0][1] = H[k][1][0] = E;
+        H[k][0][2] = H[k][2][0] = vj * F;
+        H[k][0][3] = H[k][3][0] = -vj * F;
+        H[k][1][2] = H[k][2][1] = vi * F;
+        H[k][1][3] = H[k][3][1] = -vi * F;
+        H[k][2][2] = -vi * vj * E;
+        H[k][3][3] = -vi * vj * E;
+        H[k][2][3] = H[k][3][2] = vi * vj * E;
+    }
+    const double c1 = (phi[0] * phi[0] + phi[1] * phi[1]) + x[4];
+    const double c2 = (phi[2] * phi[2] + phi[3] * phi[3]) + x[5];
+    const double m1 = d.ls1 + mu * c1;
+    const double m2 = d.ls2 + mu * c2;
+    double w[4], r[4];
+    for (int k = 0; k < 4; k++) {
+        const double mk = (k < 2) ? m1 : m2;
+        w[k] = d.lam(k) + d.rho(k) * (phi[k] - d.xt(k)) + 2 * phi[k] * mk;
+        r[k] = d.rho(k) + 2 * mk;
+    }
+    double d1[4], d2[4];
+    for (int i = 0; i < 4; i++) {
+        d1[i] = 2 * (phi[0] * J[0][i] + phi[1] * J[1][i]);
+        d2[i] = 2 * (phi[2] * J[2][i] + phi[3] * J[3][i]);
+    }
+    double gy[4];
+    for (int i = 0; i < 4; i++) {
+        double sacc = 0.0;
+        for (int k = 0; k < 4; k++) sacc += w[k] * J[k][i];
+        gy[i] = sacc;
+    }
+    const double wvi = d.lam(4) + d.rho(4) * (vi * vi - d.xt(4));
+    const double wvj = d.lam(5) + d.rho(5) * (vj * vj - d.xt(5));
+    gy[0] += wvi * (2 * vi);
+    gy[1] += wvj * (2 * vj);
+    gy[2] += d.lam(6) + d.rho(6) * (x[2] - d.xt(6));
+    gy[3] += d.lam(7) + d.rho(7) * (x[3] - d.xt(7));
+    g[0] = scale * gy[0];
+    g[1] = scale * gy[1];
+    g[2] = scale * gy[2];
+    g[3] = scale * gy[3];
+    g[4] = scale * m1;
+    g[5] = scale * m2;
+    double Hy[4][4];
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j <= i; j++) {
+            double sacc = 0.0;
+            for (int k = 0; k < 4; k++) sacc += w[k] * H[k][i][j] + r[k] * J[k][i] * J[k][j];
+            sacc += mu * (d1[i] * d1[j] + d2[i] * d2[j]);
+            Hy[i][j] = sacc;
+        }
+    Hy[0][0] += 2 * wvi + 4 * d.rho(4) * vi * vi;
+    Hy[1][1] += 2 * wvj + 4 * d.rho(5) * vj * vj;
+    Hy[2][2] += d.rho(6);
+    Hy[3][3] += d.rho(7);
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j <= i; j++) q.Apk[i * (i + 1) / 2 + j] = scale * Hy[i][j];
+    for (int i = 0; i < 4; i++) {
+        q.Apk[4 * 5 / 2 + i] = scale * (mu * d1[i]);
+        q.Apk[5 * 6 / 2 + i] = scale * (mu * d2[i]);
+    }
+    q.Apk[4 * 5 / 2 + 4] = scale * mu;
+    q.Apk[5 * 6 / 2 + 4] = 0.0;
+    q.Apk[5 * 6 / 2 + 5] = scale * mu;
+}
+#endif
 
 // gradient at x from flows and sin/cos known at x
 template <class D>
 EXA_BIG void branch_g(const D& d, const double (&x)[6], const double (&phi)[4], const double (&scs)[2],
                       double (&g)[6], GradParts& q)
 {
+#if defined(EXA_EXACT_ORACLE_ARITH)
+    (void)phi;
+    (void)scs;
+    branch_gh_exact(d, x, g, q);
+    return;
+#endif
     flow_trig(d, x, scs[0], scs[1], q.t);
     const FlowTrig& t = q.t;
     const double vi = x[0], vj = x[1], vv = t.vv, sc = d.scale, mu = d.mu;
@@ -223,6 +338,11 @@ EXA_BIG void branch_g(const D& d, const double (&x)[6], const double (&phi)[4], 
 template <class D, class MA>
 EXA_BIG void branch_h(const D& d, const double (&x)[6], const GradParts& q, MA& A)
 {
+#if defined(EXA_EXACT_ORACLE_ARITH)
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j <= i; j++) A.lo(i, j) = q.Apk[i * (i + 1) / 2 + j];
+    return;
+#endif
     const FlowTrig& t = q.t;
     const double vi = x[0], vj = x[1], vv = t.vv, sc = d.scale, mu = d.mu;
     const double* w = q.w;

@@ -103,6 +103,7 @@ struct exaadmm_handle {
     // the two Dev variants (odd / even iteration) on host and device, a pinned word for the batch base
     bool spec_on = false;
     double *u_alt = nullptr, *ls1_alt = nullptr, *ls2_alt = nullptr, *mu_alt = nullptr;
+    int *st_alt[3] = {nullptr, nullptr, nullptr};   // per-branch counters of the alternate set (auglag, minor, ticks)
     Dev dspec[2];
     Dev* d_dspec[2] = {nullptr, nullptr};
     int* h_base = nullptr;
@@ -183,7 +184,12 @@ static double* vec_ptr(exaadmm_handle* h, int which)
     }
 }
 
-extern "C" const char* exaadmm_version(void) { return "exaadmm-hip 0.1 (gfx950)"; }
+#ifndef EXA_BUILD_FLAGS
+#error "build through csrc/Makefile: it pins the code-generation flags the branch kernel needs (EXA_BUILD_FLAGS)"
+#endif
+// the flags the library was compiled with travel in the version string: k_branch is only known to be
+// compiled correctly with -mllvm -sgpr-regalloc=basic (DESIGN.md "compiler note"); loaders check for it
+extern "C" const char* exaadmm_version(void) { return "exaadmm-hip 0.2 (gfx950) [" EXA_BUILD_FLAGS "]"; }
 extern "C" const char* exaadmm_last_error(void) { return g_err.c_str(); }
 
 extern "C" void exaadmm_default_params(exaadmm_params* p)
@@ -301,6 +307,11 @@ extern "C" int exaadmm_create(const exaadmm_grid* g, const exaadmm_params* p, in
         return EXAADMM_ERR_NO_DEVICE;
     }
 
+    {
+        const int64_t la0 = g->nline_active > 0 ? g->nline_active : g->nline;
+        const int64_t ba0 = g->nbus_active > 0 ? g->nbus_active : g->nbus;
+        REQUIRE(la0 <= g->nline && ba0 <= g->nbus, "nline_active / nbus_active out of range");
+    }
     exaadmm_handle* h = new exaadmm_handle();
     h->device = device_id;
     h->G = (int)g->ngen;
@@ -320,8 +331,6 @@ extern "C" int exaadmm_create(const exaadmm_grid* g, const exaadmm_params* p, in
     fill_branch_options(h);
     {
         const int64_t la = g->nline_active > 0 ? g->nline_active : g->nline;
-        const int64_t ba = g->nbus_active > 0 ? g->nbus_active : g->nbus;
-        REQUIRE(la <= g->nline && ba <= g->nbus, "nline_active / nbus_active out of range");
         const char* e = getenv("EXAADMM_BRANCH_ORDER");
         const bool by_bus = !(e != nullptr && strcmp(e, "input") == 0);
         std::vector<int> order(h->L);
@@ -403,10 +412,15 @@ extern "C" int exaadmm_create(const exaadmm_grid* g, const exaadmm_params* p, in
         TRY(dev_alloc(h, &d.st_ticks, (size_t)h->Lp));
         TRY(dev_alloc(h, &d.st_cyc, (size_t)13 * h->Lp));
         TRY(dev_alloc(h, &d.st_tl, (size_t)2 * h->Lp));
-        (void)hipMemset(d.st_tl, 0, (size_t)2 * h->Lp * sizeof(unsigned long long));
-        (void)hipMemset(d.st_auglag, 0, h->Lp * sizeof(int));
-        (void)hipMemset(d.st_minor, 0, h->Lp * sizeof(int));
-        (void)hipMemset(d.st_ticks, 0, h->Lp * sizeof(int));
+        if (hipMemset(d.st_tl, 0, (size_t)2 * h->Lp * sizeof(unsigned long long)) != hipSuccess ||
+            hipMemset(d.st_cyc, 0, (size_t)13 * h->Lp * sizeof(unsigned long long)) != hipSuccess ||
+            hipMemset(d.st_auglag, 0, h->Lp * sizeof(int)) != hipSuccess ||
+            hipMemset(d.st_minor, 0, h->Lp * sizeof(int)) != hipSuccess ||
+            hipMemset(d.st_ticks, 0, h->Lp * sizeof(int)) != hipSuccess) {
+            set_err("hipMemset failed");
+            exaadmm_destroy(h);
+            return EXAADMM_ERR_HIP;
+        }
     }
     // generator constants
     {
@@ -692,10 +706,10 @@ extern "C" int exaadmm_init_solution(exaadmm_handle* h, double rho_pq, double rh
         if ((rc = exaadmm_upload_solution(h, w, zero.data(), nvar))) return rc;
     if ((rc = exaadmm_upload_solution(h, EXAADMM_V_CURR, v.data(), nvar))) return rc;
     if ((rc = exaadmm_upload_solution(h, EXAADMM_RHO, rho.data(), nvar))) return rc;
-    std::vector<double> mb(31 * (size_t)h->L, 0.0);
-    for (int l = 0; l < h->L; l++) mb[28 + 31 * (size_t)l] = h->rateA_h[l];
-    if ((rc = exaadmm_upload_membuf(h, mb.data(), 31, h->L))) return rc;
-    if (h->G > 0 && (rc = exaadmm_set_pg_bounds(h, id->pgmin.data(), id->pgmax.data(), h->G))) return rc;
+    // membuf (rows 25-27: line-limit multipliers and penalty; row 29: rateA) and pgmin_curr / pgmax_curr are
+    // NOT touched: the reference fills them in the ModelAcopf constructor (acopf_model.jl:61-64,87-89) --
+    // here exaadmm_create -- and init_solution! leaves them alone, which solve_mpacopf's warm start and the
+    // rolling horizon rely on.  exaadmm_upload_membuf / exaadmm_set_pg_bounds reset them explicitly.
     if (h->T > 1) {
         // init_solution! of the multi-period model (mpacopf_init_solution_cpu.jl:1-20): ramp blocks zero,
         // rho = rho_pq, phat_{t-1} = pbar_{t-1} (= v of the previous period), s = p_t - phat = -phat
@@ -1209,6 +1223,10 @@ static int spec_prepare(exaadmm_handle* h)
         if ((rc = dev_alloc(h, &h->ls1_alt, (size_t)h->Lp))) return rc;
         if ((rc = dev_alloc(h, &h->ls2_alt, (size_t)h->Lp))) return rc;
         if ((rc = dev_alloc(h, &h->mu_alt, (size_t)h->Lp))) return rc;
+        for (auto& q : h->st_alt) {
+            if ((rc = dev_alloc(h, &q, (size_t)h->Lp))) return rc;
+            HIPCHK(hipMemsetAsync(q, 0, (size_t)h->Lp * sizeof(int), h->stream));
+        }
         if ((rc = dev_alloc(h, &h->d_dspec[0], 1))) return rc;
         if ((rc = dev_alloc(h, &h->d_dspec[1], 1))) return rc;
         if (hipHostMalloc((void**)&h->h_base, sizeof(int), hipHostMallocDefault) != hipSuccess) {
@@ -1227,6 +1245,9 @@ static int spec_prepare(exaadmm_handle* h)
     a.ls1_in = h->d.ls1;  a.ls1 = h->ls1_alt;
     a.ls2_in = h->d.ls2;  a.ls2 = h->ls2_alt;
     a.mu_in = h->d.mu;    a.mu = h->mu_alt;
+    // the per-branch counters follow the iterate: a launch that the stop test discards (it runs one iteration
+    // ahead) must not overwrite the counters of the last accepted x-update
+    a.st_auglag = h->st_alt[0];  a.st_minor = h->st_alt[1];  a.st_ticks = h->st_alt[2];
     b.u_in = h->u_alt;    b.ls1_in = h->ls1_alt;  b.ls2_in = h->ls2_alt;  b.mu_in = h->mu_alt;
     a.npartials = b.npartials = h->ew_blocks;
     if (memcmp(&a, &h->dspec[0], sizeof(Dev)) != 0 || memcmp(&b, &h->dspec[1], sizeof(Dev)) != 0) {
@@ -1271,6 +1292,9 @@ static int spec_finish(exaadmm_handle* h, int iters)
         HIPCHK(hipMemcpyAsync(h->d.ls1, h->ls1_alt, (size_t)h->Lp * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(h->d.ls2, h->ls2_alt, (size_t)h->Lp * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(h->d.mu, h->mu_alt, (size_t)h->Lp * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        int* prim[3] = {h->d.st_auglag, h->d.st_minor, h->d.st_ticks};
+        for (int q = 0; q < 3; q++)
+            HIPCHK(hipMemcpyAsync(prim[q], h->st_alt[q], (size_t)h->Lp * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
     }
     return 0;
 }

@@ -172,8 +172,11 @@ constexpr int BR_LDS_DOUBLES = BR_LDS_CONST;
 // k_final_reduce does) while the other blocks already solve, reading the previous iterate from the *_in
 // buffers and writing the other set, so that a stop detected by the reduction leaves the iterate of the
 // stopping iteration intact.  One kernel boundary (4.3 us) less per iteration, no device-scope fence.
+#if !defined(EXA_BR_WAVES)
+#define EXA_BR_WAVES 1   // minimum waves per SIMD the register allocation must allow (2 -> at most 256 VGPR + AGPR)
+#endif
 template <bool MP>
-__global__ void __launch_bounds__(BR_BLOCK) k_branch_t(const Dev* __restrict__ dp, BranchOptions o, double scale, int major_iter, Ctrl* ctrl,
+__global__ void __launch_bounds__(BR_BLOCK, EXA_BR_WAVES) k_branch_t(const Dev* __restrict__ dp, BranchOptions o, double scale, int major_iter, Ctrl* ctrl,
                                                        int gen_blocks, double baseMVA, int spec_j)
 {
 #if defined(EXA_CONST_IN_REGS) && !defined(EXA_A_IN_LDS) && !defined(EXA_L_IN_LDS)

@@ -9,9 +9,9 @@
 //  * The reference runs ONE 32-thread block per branch and keeps x, g, A, B, L and
 //    11 work vectors in shared memory, with 26-31 of 32 lanes idle.  Here one LANE
 //    owns one branch and every loop has a compile-time trip count N, so after
-//    unrolling all vectors and both packed-symmetric matrices live in VGPRs
-//    (512 per lane on gfx950); only the 35 read-only problem constants are staged
-//    through LDS by the caller.
+//    unrolling all vectors, both packed-symmetric matrices and the 32 read-only
+//    problem constants live in registers (512 per lane on gfx950); the default build
+//    uses no LDS (SymRef / BranchDataRef are the LDS-staged A/B variants).
 //  * The face loop of the subspace CG does not compact the free variables into
 //    a smaller system (that needs run-time indexing -> scratch memory).  It keeps
 //    a free-variable MASK and works on the N x N system whose bound rows/columns
@@ -53,6 +53,17 @@
 #define EXA_CLK() 0ull
 #endif
 
+// -DEXA_EXACT_ORACLE_ARITH: the dense algebra is evaluated exactly as the CPU path evaluates it (the tests' CPU
+// restatement of ExaTron's dense routines): products and sums rounded separately instead of fused, divisions by
+// the pivots instead of multiplications by their reciprocals, the scaled / shifted Cholesky on every call, dtrpcg's
+// second residual carried by recurrence, norms compared as norms.  Slower; exists so that the deviation of the
+// default ("fast") arithmetic from the CPU path is a measured quantity (tests/test_gpu_exact_arith.py).
+#if defined(EXA_EXACT_ORACLE_ARITH)
+#define EXA_FMA(a, b, c) ((a) * (b) + (c))
+#else
+#define EXA_FMA(a, b, c) fma((a), (b), (c))
+#endif
+
 namespace exa {
 
 // task / termination codes (numbering of acopf_tron_linelimit_kernel.jl)
@@ -82,7 +93,7 @@ EXA_HD double dot(const double (&a)[N], const double (&b)[N])
 {
     double s = 0.0;
     EXA_UNROLL
-    for (int i = 0; i < N; i++) s = fma(a[i], b[i], s);
+    for (int i = 0; i < N; i++) s = EXA_FMA(a[i], b[i], s);
     return s;
 }
 
@@ -100,7 +111,7 @@ EXA_HD void symv(const MA& A, const double (&x)[N], double (&w)[N])
     for (int i = 0; i < N; i++) {
         double s = 0.0;
         EXA_UNROLL
-        for (int j = 0; j < N; j++) s = fma(A.get(i, j), x[j], s);
+        for (int j = 0; j < N; j++) s = EXA_FMA(A.get(i, j), x[j], s);
         w[i] = s;
     }
 }
@@ -167,7 +178,7 @@ EXA_HD void quad_model(const MA& A, const double (&g)[N], const double (&s)[N], 
     double wa[N];
     symv<N>(A, s, wa);
     gts = dot<N>(g, s);
-    q = fma(0.5, dot<N>(s, wa), gts);
+    q = EXA_FMA(0.5, dot<N>(s, wa), gts);
 }
 
 // Cauchy step (TRON dcauchy).  alpha persists across calls.
@@ -231,22 +242,34 @@ EXA_HD void trsol_n(const ML& L, const double (&id)[N], double (&r)[N])
 {
     EXA_UNROLL
     for (int j = 0; j < N; j++) {
+#if defined(EXA_EXACT_ORACLE_ARITH)
+        double t = r[j] / L.lo(j, j);
+#else
         double t = r[j] * id[j];
+#endif
         EXA_UNROLL
-        for (int k = j + 1; k < N; k++) r[k] = fma(-L.lo(k, j), t, r[k]);
+        for (int k = j + 1; k < N; k++) r[k] = EXA_FMA(-L.lo(k, j), t, r[k]);
         r[j] = t;
     }
 }
 template <int N, class ML>
 EXA_HD void trsol_t(const ML& L, const double (&id)[N], double (&r)[N])
 {
+#if defined(EXA_EXACT_ORACLE_ARITH)
+    r[N - 1] = r[N - 1] / L.lo(N - 1, N - 1);
+#else
     r[N - 1] = r[N - 1] * id[N - 1];
+#endif
     EXA_UNROLL
     for (int j = N - 2; j >= 0; j--) {
         double t = 0.0;
         EXA_UNROLL
-        for (int k = j + 1; k < N; k++) t = fma(L.lo(k, j), r[k], t);
+        for (int k = j + 1; k < N; k++) t = EXA_FMA(L.lo(k, j), r[k], t);
+#if defined(EXA_EXACT_ORACLE_ARITH)
+        r[j] = (r[j] - t) / L.lo(j, j);
+#else
         r[j] = (r[j] - t) * id[j];
+#endif
     }
 }
 
@@ -262,7 +285,7 @@ EXA_HD bool chol_inplace(ML& L, double (&rd)[N])
         for (int k = 0; k < j; k++) {
             double ljk = L.lo(j, k);
             EXA_UNROLL
-            for (int i = j; i < N; i++) L.lo(i, j) = fma(-L.lo(i, k), ljk, L.lo(i, j));
+            for (int i = j; i < N; i++) L.lo(i, j) = EXA_FMA(-L.lo(i, k), ljk, L.lo(i, j));
         }
         double d = L.lo(j, j);
         ok = ok && (d > 0.0);
@@ -271,7 +294,11 @@ EXA_HD bool chol_inplace(ML& L, double (&rd)[N])
         const double r = 1.0 / d;
         rd[j] = r;
         EXA_UNROLL
+#if defined(EXA_EXACT_ORACLE_ARITH)
+        for (int i = j + 1; i < N; i++) L.lo(i, j) /= d;
+#else
         for (int i = j + 1; i < N; i++) L.lo(i, j) *= r;
+#endif
     }
     return ok;
 }
@@ -300,6 +327,9 @@ EXA_BIG void icfs_masked(unsigned fr, const MA& A, ML& L, double (&id)[N])
         m[i] = f ? 1.0 : 0.0;
         pos = pos && (!f || A.lo(i, i) > 0.0);
     }
+#if defined(EXA_EXACT_ORACLE_ARITH)
+    pos = false;   // always the scaled / shifted factorisation of dicfs
+#endif
     if (pos) {
         EXA_UNROLL
         for (int i = 0; i < N; i++) {
@@ -317,7 +347,7 @@ EXA_BIG void icfs_masked(unsigned fr, const MA& A, ML& L, double (&id)[N])
         EXA_UNROLL
         for (int i = 0; i < N; i++) {
             double aij = A.get(i, j) * m[i];
-            s = fma(aij, aij, s);
+            s = EXA_FMA(aij, aij, s);
         }
         double nrm = sqrt(s);
         const bool sc = ((fr >> j) & 1u) && nrm > 0.0;
@@ -363,7 +393,11 @@ EXA_BIG void icfs_masked(unsigned fr, const MA& A, ML& L, double (&id)[N])
                 EXA_UNROLL
                 for (int i = 0; i < N; i++) {
                     EXA_UNROLL
+#if defined(EXA_EXACT_ORACLE_ARITH)
+                    for (int j = 0; j <= i; j++) L.lo(i, j) = L.lo(i, j) / wa2[i];
+#else
                     for (int j = 0; j <= i; j++) L.lo(i, j) = L.lo(i, j) * wi2[i];
+#endif
                     id[i] = rdv[i] * wa2[i];
                 }
                 return;
@@ -407,10 +441,16 @@ EXA_BIG int trpcg_masked(unsigned fr, const MA& A, const double (&gf)[N], double
                         const double (&id)[N], double tol, double stol, int itermax, double (&w)[N], int& iters_out)
 {
     double p[N], q[N], r[N], z[N];
+#if defined(EXA_EXACT_ORACLE_ARITH)
+    double t[N], zc[N];
+#endif
     EXA_UNROLL
     for (int i = 0; i < N; i++) {
         w[i] = 0.0;
         r[i] = -gf[i];
+#if defined(EXA_EXACT_ORACLE_ARITH)
+        t[i] = r[i];
+#endif
     }
     trsol_n<N>(L, id, r);
     EXA_UNROLL
@@ -429,6 +469,10 @@ EXA_BIG int trpcg_masked(unsigned fr, const MA& A, const double (&gf)[N], double
         trsol_t<N>(L, id, z);
         symv<N>(A, z, q);
         mask_vec<N>(fr, q);
+#if defined(EXA_EXACT_ORACLE_ARITH)
+        EXA_UNROLL
+        for (int i = 0; i < N; i++) zc[i] = q[i];
+#endif
         trsol_n<N>(L, id, q);
 
         double ptq = dot<N>(p, q);
@@ -437,24 +481,38 @@ EXA_BIG int trpcg_masked(unsigned fr, const MA& A, const double (&gf)[N], double
 
         if (ptq <= 0.0 || alpha >= sigma) {
             EXA_UNROLL
-            for (int i = 0; i < N; i++) w[i] = fma(sigma, p[i], w[i]);
+            for (int i = 0; i < N; i++) w[i] = EXA_FMA(sigma, p[i], w[i]);
             iters_out = iters;
             return (ptq <= 0.0) ? 3 : 4;
         }
         EXA_UNROLL
         for (int i = 0; i < N; i++) {
-            w[i] = fma(alpha, p[i], w[i]);
-            r[i] = fma(-alpha, q[i], r[i]);
+            w[i] = EXA_FMA(alpha, p[i], w[i]);
+            r[i] = EXA_FMA(-alpha, q[i], r[i]);
         }
         double rtr = dot<N>(r, r);
+#if defined(EXA_EXACT_ORACLE_ARITH)
+        EXA_UNROLL
+        for (int i = 0; i < N; i++) t[i] = EXA_FMA(-alpha, zc[i], t[i]);
+        (void)tol2;
+        (void)stol2;
+        if (nrm2<N>(t) <= tol) {
+            iters_out = iters;
+            return 1;
+        }
+        if (sqrt(rtr) <= stol) {
+            iters_out = iters;
+            return 2;
+        }
+#else
         // ||t||^2 with t = L r (lower triangular product, row by row)
         double tt = 0.0;
         EXA_UNROLL
         for (int i = 0; i < N; i++) {
             double ti = 0.0;
             EXA_UNROLL
-            for (int j = 0; j <= i; j++) ti = fma(L.lo(i, j), r[j], ti);
-            tt = fma(ti, ti, tt);
+            for (int j = 0; j <= i; j++) ti = EXA_FMA(L.lo(i, j), r[j], ti);
+            tt = EXA_FMA(ti, ti, tt);
         }
         if (tt <= tol2) {
             iters_out = iters;
@@ -464,9 +522,10 @@ EXA_BIG int trpcg_masked(unsigned fr, const MA& A, const double (&gf)[N], double
             iters_out = iters;
             return 2;
         }
+#endif
         double beta = rtr / rho;
         EXA_UNROLL
-        for (int i = 0; i < N; i++) p[i] = fma(beta, p[i], r[i]);
+        for (int i = 0; i < N; i++) p[i] = EXA_FMA(beta, p[i], r[i]);
         rho = rtr;
     }
     iters_out = itermax;
@@ -490,7 +549,7 @@ EXA_BIG void prsrch_masked(unsigned fr, double (&x)[N], const double (&xl)[N], c
         symv<N>(A, wa1, wa2);
         mask_vec<N>(fr, wa2);
         double gts = dot<N>(gf, wa1);
-        double q = fma(0.5, dot<N>(wa1, wa2), gts);
+        double q = EXA_FMA(0.5, dot<N>(wa1, wa2), gts);
         if (q <= mu0 * gts)
             search = false;
         else
@@ -571,7 +630,11 @@ EXA_BIG void spcg(double (&x)[N], const double (&xl)[N], const double (&xu)[N], 
             double gi = ((fr >> i) & 1u) ? (w[i] + g[i]) : 0.0;
             gn2 += gi * gi;
         }
+#if defined(EXA_EXACT_ORACLE_ARITH)
+        if (sqrt(gn2) <= rtol * gfnorm) return;
+#else
         if (gn2 <= (rtol * rtol) * gfn2) return;   // ||g_free(new)|| <= rtol ||g_free||, compared as squares
+#endif
         if (infotr == 3 || infotr == 4) return;
         if (iters > itermax) return;
     }

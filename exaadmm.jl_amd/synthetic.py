@@ -18,7 +18,7 @@ CASE_SIZES = {
 }
 
 
-def synthetic_grid(ngen, nline, nbus, seed=0, tight_factor=0.99, locality=64, feasible=True):
+def synthetic_grid(ngen, nline, nbus, seed=0, tight_factor=0.99, locality=64, feasible=True, recipe="acflow", cost="pegase"):
     """Random connected grid: spanning tree over the buses (each bus attaches to one of the
     `locality` previous buses, which gives the banded structure of real networks) plus
     extra local edges up to nline.  Returns the dict layout used by AdmmEnv(grid=...),
@@ -27,7 +27,17 @@ def synthetic_grid(ngen, nline, nbus, seed=0, tight_factor=0.99, locality=64, fe
     feasible=True (default) makes the instance a solvable OPF like the real cases instead of
     random numbers: every load is supplied by the electrically nearest generator (capacities
     are raised where needed), a DC power flow of that dispatch gives the line flows, and the
-    thermal limits are set with margin above those flows."""
+    thermal limits are set with margin above those flows.
+
+    recipe="acflow" (default since round 2) goes one step further so that the two-level solve of the
+    reference CONVERGES on the instance like it does on the real cases: a voltage profile (|V| near 1,
+    angles of the DC flow) is pushed through the AC branch equations, and loads / dispatch are defined
+    from the resulting bus injections, so a strictly feasible AC operating point exists by construction
+    (voltages, generator P and Q, thermal limits all with margin).  recipe="dc" keeps the round-1
+    instance (DC-feasible only; the ADMM diverges on it from beta ~ 2e5).
+    cost="pegase": linear unit cost as in the MATPOWER pegase files (the README's rho_pq = 1e1 / 5e1
+    are tuned to that cost scale); cost="market": quadratic costs c1 ~ U(10, 40), c2 ~ U(0, 0.02)
+    (ACTIVSg-like, solved with rho_pq = 3e4 upstream)."""
     assert nline >= nbus - 1 and ngen >= 1
     rng = np.random.default_rng(seed)
     M = 100.0
@@ -94,13 +104,45 @@ def synthetic_grid(ngen, nline, nbus, seed=0, tight_factor=0.99, locality=64, fe
         theta[1:] = spla.spsolve(Bm[1:, 1:].tocsc(), inj[1:])
         flow = np.abs((theta[fr] - theta[to]) * w) * M                     # MW
         rate = np.where(unlimited, 0.0, np.maximum(1.6 * flow, 60.0) * rng.uniform(1.0, 1.5, nline))
+    YshR = YshI = None
+    if feasible and recipe == "acflow":
+        # bus shunts first (they enter the balance): MW / MVAr at 1 p.u. (opfdata.jl:453-456)
+        has_sh = rng.random(nbus) < 0.08
+        YshR = np.where(has_sh, rng.uniform(0.0, 5.0, nbus), 0.0) / M
+        YshI = np.where(has_sh, rng.uniform(-20.0, 20.0, nbus), 0.0) / M
+        Vm = np.clip(1.0 + 0.012 * rng.standard_normal(nbus), 0.96, 1.04)
+        V = Vm * np.exp(1j * theta)
+        Sf = V[fr] * np.conj(Yff * V[fr] + Yft * V[to])      # from-end flow, p.u. (opfdata.jl:428-447)
+        St = V[to] * np.conj(Ytt * V[to] + Ytf * V[fr])
+        # balance of the reference's bus update (acopf_bus_kernel_cpu.jl): sum pg - Pd = sum pij + YshR w,
+        # sum qg - Qd = sum qij - YshI w
+        need = (np.bincount(fr, weights=Sf.real, minlength=nbus) + np.bincount(to, weights=St.real, minlength=nbus) + YshR * Vm ** 2) * M
+        needq = (np.bincount(fr, weights=Sf.imag, minlength=nbus) + np.bincount(to, weights=St.imag, minlength=nbus) - YshI * Vm ** 2) * M
+        ng_at = np.bincount(gbus, minlength=nbus)
+        Qd = 0.25 * Pd
+        # generator buses: dispatch = injection + load, shared equally by the units at the bus; what does not fit
+        # into [10 %, 70 %] of the units' capacity (reactive: +-35 %) stays with the load
+        cap = np.bincount(gbus, weights=Pmax, minlength=nbus)
+        want = need + Pd
+        pg_bus = np.where(ng_at > 0, np.clip(want, 0.10 * cap, 0.70 * cap), 0.0)
+        Pd = pg_bus - need
+        wantq = needq + Qd
+        qg_bus = np.where(ng_at > 0, np.clip(wantq, -0.35 * cap, 0.35 * cap), 0.0)
+        Qd = qg_bus - needq
+        flowS = np.maximum(np.abs(Sf), np.abs(St)) * M
+        rate = np.where(unlimited, 0.0, np.maximum(1.5 * flowS, 40.0) * rng.uniform(1.0, 1.5, nline))
     g = {"ngen": ngen, "nline": nline, "nbus": nbus, "baseMVA": M, "bus_ref": 0}
     g["pgmin"] = np.zeros(ngen)
     g["pgmax"] = Pmax / M
     g["qgmin"] = -0.5 * Pmax / M
     g["qgmax"] = 0.5 * Pmax / M
-    g["c2"] = rng.uniform(0.0, 0.1, ngen)
-    g["c1"] = rng.uniform(1.0, 40.0, ngen)
+    c2_r, c1_r = rng.uniform(0.0, 0.1, ngen), rng.uniform(1.0, 40.0, ngen)   # (drawn in every recipe: keeps the stream aligned)
+    if recipe == "acflow" and cost == "pegase":
+        g["c2"], g["c1"] = np.zeros(ngen), np.ones(ngen)
+    elif recipe == "acflow":
+        g["c2"], g["c1"] = 0.2 * c2_r, 10.0 + 0.75 * c1_r
+    else:
+        g["c2"], g["c1"] = c2_r, c1_r
     g["c0"] = np.zeros(ngen)
     for nm, Y in (("Yff", Yff), ("Yft", Yft), ("Ytt", Ytt), ("Ytf", Ytf)):
         g[nm + "R"] = np.ascontiguousarray(Y.real)
@@ -116,9 +158,11 @@ def synthetic_grid(ngen, nline, nbus, seed=0, tight_factor=0.99, locality=64, fe
     g["brBusIdx"] = np.stack([fr, to], 1).ravel()
     g["Pd"], g["Qd"], g["Vmin"], g["Vmax"] = Pd, Qd, Vmin, Vmax
     # bus shunts on ~8 % of the buses (MW / MVAr at 1 p.u., divided by baseMVA: opfdata.jl:453-456)
-    has_sh = rng.random(nbus) < 0.08
-    g["YshR"] = np.where(has_sh, rng.uniform(0.0, 5.0, nbus), 0.0) / M
-    g["YshI"] = np.where(has_sh, rng.uniform(-20.0, 20.0, nbus), 0.0) / M
+    if YshR is None:
+        has_sh = rng.random(nbus) < 0.08
+        YshR = np.where(has_sh, rng.uniform(0.0, 5.0, nbus), 0.0) / M
+        YshI = np.where(has_sh, rng.uniform(-20.0, 20.0, nbus), 0.0) / M
+    g["YshR"], g["YshI"] = YshR, YshI
 
     def csr(owner, n):
         order = np.argsort(owner, kind="stable").astype(np.int64)

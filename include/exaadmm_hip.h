@@ -111,8 +111,10 @@ int exaadmm_set_params(exaadmm_handle *h, const exaadmm_params *p);
 int exaadmm_get_params(exaadmm_handle *h, exaadmm_params *p);
 int64_t exaadmm_nvar(exaadmm_handle *h);
 
-/* init_solution! + membuf fill + pg bound copy
- * (acopf_init_solution_gpu.jl:1-64, acopf_model.jl:61-64,87-89) */
+/* init_solution! (acopf_init_solution_gpu.jl:1-64): resets the Solution vectors (and the ramp blocks of a
+ * multi-period handle) only.  membuf (line-limit multipliers / penalty, rateA) and pgmin_curr / pgmax_curr
+ * are filled by exaadmm_create, like the ModelAcopf constructor does (acopf_model.jl:61-64,87-89), and
+ * survive this call -- solve_mpacopf's warm start and the rolling horizon depend on that. */
 int exaadmm_init_solution(exaadmm_handle *h, double rho_pq, double rho_va);
 
 /* host <-> device, reference layout */

@@ -191,3 +191,68 @@ def test_lane_generator_ramp_callbacks_match_reference_outputs(hc):
         assert np.abs(g - c["g"]).max() <= 1e-13 * max(1.0, np.abs(c["g"]).max())
         assert np.abs(A.reshape(3, 3) - np.array(c["H"])).max() <= 1e-13 * max(1.0, np.abs(c["H"]).max())
     assert n >= 8
+
+
+@pytest.fixture(scope="module")
+def hc_exact():
+    """the same lane code compiled with -DEXA_EXACT_ORACLE_ARITH (the CPU path's operation order)"""
+    so = os.path.join(HC_DIR, "libhostcheck_exact.so")
+    srcs = [os.path.join(HC_DIR, "hostcheck.cpp"), os.path.join(CSRC, "tron_device.h"),
+            os.path.join(CSRC, "branch_solver.h"), os.path.join(CSRC, "genramp_solver.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(s_) > os.path.getmtime(so) for s_ in srcs):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mfma",
+                               "-DEXA_EXACT_ORACLE_ARITH", "-I", CSRC, srcs[0], "-o", so, "-lm"])
+    L = C.CDLL(so)
+    L.hostcheck_branch_solve.argtypes = [dp, dp, dp, dp, dp, C.c_double, C.c_int, C.c_double, ip, ip, ip]
+    L.hostcheck_genramp_solve.argtypes = [dp, dp, dp, dp] + [C.c_double] * 4 + [C.c_int, C.c_double, ip, ip]
+    return L
+
+
+@pytest.mark.parametrize("cold", [True, False])
+def test_exact_arith_build_is_bitwise_the_oracle_on_branches(hc_exact, oracle, cold):
+    """-DEXA_EXACT_ORACLE_ARITH: same libm on the host, so the lane code must reproduce the oracle BIT FOR BIT
+    (x, multipliers, penalty, iteration counts) on every problem -- this pins the flattened tick loop, the
+    masked (uncompacted) face loop and every TRON routine of tron_device.h to the CPU restatement; what is left
+    to the default build is arithmetic only (FMA, reciprocal pivots, Cholesky shortcut, re-derived f/g/H), whose
+    effect tests/tools/classify_mismatches.py counts (profiles/r02_branch_arith_mismatch_classes.txt)."""
+    rng = np.random.default_rng(70 if cold else 110)
+    OL = oracle.lib()
+    for _ in range(400):
+        x, xl, xu, p, Y = _random_branch(rng, cold)
+        scale = float(rng.choice([1e-4, 1e-5]))
+        xo, po = x.copy(), p.copy()
+        ito, mio = C.c_int(), C.c_int()
+        OL.oracle_branch_solve(_p(xo), _p(xl), _p(xu), _p(po), _p(Y), scale, 50, 1e8,
+                               C.cast(C.byref(ito), oracle.c_int_p), C.cast(C.byref(mio), oracle.c_int_p))
+        xh, ph = x.copy(), p.copy()
+        ith, mih, tk = C.c_int(), C.c_int(), C.c_int()
+        hc_exact.hostcheck_branch_solve(_p(xh), _p(xl), _p(xu), _p(ph), _p(Y), scale, 50, 1e8,
+                                        C.byref(ith), C.byref(mih), C.byref(tk))
+        assert (ith.value, mih.value) == (ito.value, mio.value)
+        assert np.array_equal(xh, xo) and np.array_equal(ph[24:27], po[24:27])
+
+
+def test_exact_arith_build_is_bitwise_the_oracle_on_ramp_subproblems(hc_exact, oracle):
+    rng = np.random.default_rng(230)
+    oracle._mp_lib()
+    OL = oracle.lib()
+    for _ in range(600):
+        pmax = rng.uniform(0.5, 5.0)
+        pmin = rng.choice([0.0, 0.1 * pmax])
+        ramp = 0.02 * pmax
+        xl = np.array([pmin, pmin, -ramp])
+        xu = np.array([pmax, pmax, ramp])
+        x = np.array([rng.uniform(pmin, pmax), rng.uniform(pmin, pmax), rng.uniform(-ramp, ramp)])
+        rho = float(rng.choice([10.0, 50.0, 400.0]))
+        param = np.array([rng.normal(0, 5), rng.normal(0, 5), rho, rho, rng.uniform(pmin, pmax),
+                          rng.uniform(pmin, pmax), rng.choice([0.0, rng.normal(0, 20)]), 10.0 ** rng.integers(1, 5)])
+        c2, c1, c0, M = rng.uniform(0.0, 0.2), rng.uniform(1, 40), rng.uniform(0, 500), 100.0
+        xo, po = x.copy(), param.copy()
+        ito, mio = C.c_int(), C.c_int()
+        OL.oracle_genramp_solve(_p(xo), _p(xl), _p(xu), _p(po), 1.0, c2, c1, c0, M, 50, 1e8,
+                                C.cast(C.byref(ito), oracle.c_int_p), C.cast(C.byref(mio), oracle.c_int_p))
+        xh, ph = x.copy(), param.copy()
+        ith, mih = C.c_int(), C.c_int()
+        hc_exact.hostcheck_genramp_solve(_p(xh), _p(xl), _p(xu), _p(ph), c2, c1, c0, M, 50, 1e8, C.byref(ith), C.byref(mih))
+        assert (ith.value, mih.value) == (ito.value, mio.value)
+        assert np.array_equal(xh, xo) and np.array_equal(ph, po)

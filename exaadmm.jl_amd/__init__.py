@@ -72,6 +72,8 @@ class Info(C.Structure):
         return "Solved" if self.status_code == 1 else "IterationLimit"
 
 
+OWN_STREAM = C.c_void_p(-1).value   # EXAADMM_OWN_STREAM: (void *)~0
+
 VECTORS = {"u_curr": 0, "v_curr": 1, "l_curr": 2, "rho": 3, "rd": 4, "rp": 5, "z_curr": 6,
            "z_prev": 7, "lz": 8, "Ax_plus_By": 9}
 
@@ -126,6 +128,7 @@ def library():
     L.exaadmm_download_branch_counters.argtypes = [H, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                                    C.POINTER(C.c_int32), C.c_int64]
     L.exaadmm_set_branch_lane_order.argtypes = [H, C.POINTER(C.c_int32), C.c_int64]
+    L.exaadmm_branch_kernel_occupancy.argtypes = [H, C.POINTER(C.c_int)]
     L.exaadmm_run_inner.argtypes = [H, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int), c_double_p]
     L.exaadmm_solve_two_level.argtypes = [H, C.POINTER(Info)]
     L.exaadmm_run_fixed.argtypes = [H, C.c_int, C.c_int, C.c_double, c_double_p, c_double_p, c_double_p]
@@ -142,6 +145,12 @@ def library():
     L.exaadmm_ctrl_step.argtypes = [H, C.c_void_p]
     L.exaadmm_ctrl_read.argtypes = [H, C.POINTER(C.c_int), C.POINTER(C.c_int), c_double_p]
     L.exaadmm_ctrl_end.argtypes = [H]
+    L.exaadmm_dist_unique_id.argtypes = [C.c_char_p, C.c_int64]
+    L.exaadmm_dist_attach.argtypes = [H, C.c_int, C.c_int, C.c_char_p, C.c_int64, C.c_int64, c_i64_p]
+    L.exaadmm_dist_detach.argtypes = [H]
+    L.exaadmm_dist_run_inner.argtypes = [H, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int), c_double_p]
+    L.exaadmm_dist_run_fixed.argtypes = [H, C.c_int, C.c_int, C.c_double, c_double_p, c_double_p]
+    L.exaadmm_dist_norm_z.argtypes = [H, c_double_p]
     L.exaadmm_mp_create.argtypes = [C.POINTER(Grid), C.POINTER(Parameters), C.c_int, c_double_p, c_double_p,
                                     C.c_double, C.c_int, C.POINTER(H)]
     L.exaadmm_mp_periods.argtypes = [H]
@@ -342,6 +351,12 @@ class ModelAcopf:
         _check(library().exaadmm_download_branch_counters(self._h, a.ctypes.data_as(ip), m.ctypes.data_as(ip),
                                                           t.ctypes.data_as(ip), self.nline), "branch counters")
         return a, m, t
+
+    def branch_kernel_occupancy(self):
+        """resident wavefronts per SIMD allowed by the branch kernel's register footprint"""
+        w = C.c_int()
+        _check(library().exaadmm_branch_kernel_occupancy(self._h, C.byref(w)), "exaadmm_branch_kernel_occupancy")
+        return w.value
 
     def set_branch_lane_order(self, order):
         if order is None:

@@ -60,7 +60,11 @@ struct HaloSlot {
     int count = 0;
 };
 
+struct exaadmm_dist;   // RCCL communicator + halo buffers of a partition (dist_native.h)
+extern "C" int exaadmm_dist_detach(exaadmm_handle* h);
+
 struct exaadmm_handle {
+    exaadmm_dist* dist = nullptr;
     int device = 0;
     int G = 0, L = 0, B = 0, Gp = 0, Lp = 0, N = 0;
     int64_t nvar = 0;
@@ -499,6 +503,7 @@ extern "C" int exaadmm_destroy(exaadmm_handle* h)
     if (!h) return EXAADMM_OK;
     (void)hipSetDevice(h->device);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
+    (void)exaadmm_dist_detach(h);
     for (void* p : h->allocs) (void)hipFree(p);
     for (auto& s : h->halo) {
         if (s.d_idx) (void)hipFree(s.d_idx);
@@ -1161,6 +1166,21 @@ extern "C" int exaadmm_download_branch_counters(exaadmm_handle* h, int32_t* a, i
     return EXAADMM_OK;
 }
 
+// Resident wavefronts per SIMD the branch kernel's register / LDS footprint allows (occupancy API, 64-thread
+// blocks: blocks per CU / 4 SIMDs).  Diagnostics for bench.py's roofline block.
+extern "C" int exaadmm_branch_kernel_occupancy(exaadmm_handle* h, int* waves_per_simd)
+{
+    REQUIRE(h && waves_per_simd, "null argument");
+    HIPCHK(hipSetDevice(h->device));
+    int blocks = 0;
+    if (h->T > 1)
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_branch_t<true>, BR_BLOCK, 0));
+    else
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_branch_t<false>, BR_BLOCK, 0));
+    *waves_per_simd = blocks / 4;
+    return EXAADMM_OK;
+}
+
 // Lane assignment of the branch kernel: lane i solves reference branch order[i] (a permutation of
 // the active branches).  NULL restores the identity.  Results do not depend on it.
 extern "C" int exaadmm_set_branch_lane_order(exaadmm_handle* h, const int32_t* order, int64_t n)
@@ -1708,3 +1728,6 @@ extern "C" int exaadmm_set_owned_mask(exaadmm_handle* h, const uint8_t* mask, in
     h->d.owned = h->d_owned;
     return EXAADMM_OK;
 }
+
+// ------------------------------------------------------------------ distributed inner loop inside the library (RCCL)
+#include "dist_native.h"

@@ -61,51 +61,49 @@ def init_state(grid, rho_pq, rho_va):
 
 
 def bfs_bus_order(grid):
-    """Breadth-first bus order from bus 0 (bandwidth-reducing relabel for contiguous partitions)."""
+    """Breadth-first bus order from bus 0 (bandwidth-reducing relabel for contiguous partitions);
+    every connected component is appended in turn."""
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import breadth_first_order
     B, Ln = int(grid["nbus"]), int(grid["nline"])
     bb = np.asarray(grid["brBusIdx"]).reshape(Ln, 2)
-    adj = [[] for _ in range(B)]
-    for f, t in bb:
-        adj[f].append(t)
-        adj[t].append(f)
+    adj = sp.coo_matrix((np.ones(2 * Ln, dtype=np.int8), (np.concatenate([bb[:, 0], bb[:, 1]]), np.concatenate([bb[:, 1], bb[:, 0]]))),
+                        shape=(B, B)).tocsr()
     seen = np.zeros(B, dtype=bool)
     order = []
-    for s in range(B):
-        if seen[s]:
+    for s0 in range(B):
+        if seen[s0]:
             continue
-        seen[s] = True
-        q = [s]
-        while q:
-            nq = []
-            for a in q:
-                order.append(a)
-                for b in adj[a]:
-                    if not seen[b]:
-                        seen[b] = True
-                        nq.append(b)
-            q = nq
-    return np.asarray(order, dtype=np.int64)
+        o = breadth_first_order(adj, s0, directed=False, return_predecessors=False)
+        seen[o] = True
+        order.append(o)
+        if seen.all():
+            break
+    return np.concatenate(order).astype(np.int64)
 
 
 class Partition:
     """Rank r's share of a global grid (all indices zero-based)."""
 
-    def __init__(self, grid, world, rank, bus_owner=None):
+    def __init__(self, grid, world, rank, bus_owner=None, reorder=True):
+        """bus_owner: explicit owner per bus.  Default: contiguous ranges of a breadth-first bus order
+        (reorder=True), which keeps the cut small whatever numbering the case file uses; reorder=False cuts the
+        loader's own bus order into ranges (only sensible for grids that are banded in that order)."""
         G, Ln, B = int(grid["ngen"]), int(grid["nline"]), int(grid["nbus"])
         self.world, self.rank = world, rank
         self.nvar_global = 2 * G + 8 * Ln
         if bus_owner is None:
             bounds = [(B * p) // world for p in range(world + 1)]
+            order = bfs_bus_order(grid) if (reorder and world > 1) else np.arange(B, dtype=np.int64)
             bus_owner = np.zeros(B, dtype=np.int64)
             for p in range(world):
-                bus_owner[bounds[p]:bounds[p + 1]] = p
+                bus_owner[order[bounds[p]:bounds[p + 1]]] = p
         self.bus_owner = bus_owner
         bb = np.asarray(grid["brBusIdx"]).reshape(Ln, 2)
         fr_own, to_own = bus_owner[bb[:, 0]], bus_owner[bb[:, 1]]
         gstart, gidx = np.asarray(grid["GenStart"]), np.asarray(grid["GenIdx"])
         gen_bus = np.empty(G, dtype=np.int64)
-        for b in range(B):
-            gen_bus[gidx[gstart[b]:gstart[b + 1]]] = b
+        gen_bus[gidx[:G]] = np.repeat(np.arange(B, dtype=np.int64), np.diff(gstart))
 
         self.buses = np.flatnonzero(bus_owner == rank)
         self.gens = np.flatnonzero(bus_owner[gen_bus] == rank)
@@ -167,24 +165,23 @@ class Partition:
         # halo index lists (vector id, local reference-layout index)
         ls = 2 * Gl
 
+        to_side = np.asarray(TO_SIDE, dtype=np.int64)
+
         def entries(branches, vecs):
-            which, idx = [], []
-            for vec in vecs:
-                loc = br_l[branches]
-                for b in loc:
-                    for k in TO_SIDE:
-                        which.append(vec)
-                        idx.append(ls + 8 * b + k)
+            loc = br_l[np.asarray(branches, dtype=np.int64)]
+            one = (ls + 8 * loc[:, None] + to_side[None, :]).ravel()           # per branch: its 4 to-side entries
+            idx = np.tile(one, len(vecs))                                        # vector-major, like the round-1 lists
+            which = np.repeat(np.asarray(vecs, dtype=np.int32), one.size)
             return which, idx
 
         def plan(peer_lists, vecs):
             which, idx, counts = [], [], []
             for p in range(world):
                 w, i = entries(peer_lists[p], vecs)
-                which += w
-                idx += i
-                counts.append(len(i))
-            return (np.asarray(which, dtype=np.int32), np.asarray(idx, dtype=np.int64), counts)
+                which.append(w)
+                idx.append(i)
+                counts.append(int(i.size))
+            return (np.concatenate(which).astype(np.int32), np.concatenate(idx).astype(np.int64), counts)
 
         self.plan_send_uzl = plan(self.send_uzl, (U, Z, L_))   # slot 0: gather on the owner
         self.plan_recv_uzl = plan(self.recv_uzl, (U, Z, L_))   # slot 1: scatter into the ghosts
@@ -237,6 +234,50 @@ class HipBackend:
         stream = torch.cuda.current_stream(self.dev).cuda_stream
         pkg._check(self.lib.exaadmm_set_stream(h, C.c_void_p(stream)), "exaadmm_set_stream")
         pkg._check(self.lib.exaadmm_set_async(h, 1), "exaadmm_set_async")
+
+    # ---- distributed loop inside the library (csrc/dist_native.h): RCCL called from C++ on the handle's own stream
+    native = False
+
+    def attach_native(self, dist):
+        """Collective over the ranks of `dist` (torch.distributed, used only to hand the 128-byte RCCL id around):
+        creates the library-side communicator and halo buffers.  From here on run_inner / run_fixed / norm_z run
+        inside the library, eight iterations per host visit."""
+        pkg, lib, h, p = self.pkg, self.lib, self.mod.handle, self.part
+        world, rank = dist.get_world_size(), dist.get_rank()
+        ident = [None]
+        if world > 1:
+            if rank == 0:
+                buf = C.create_string_buffer(128)
+                pkg._check(lib.exaadmm_dist_unique_id(buf, 128), "exaadmm_dist_unique_id")
+                ident[0] = buf.raw
+            dist.broadcast_object_list(ident, src=0)
+        counts = np.asarray([p.plan_send_uzl[2], p.plan_recv_uzl[2], p.plan_send_v[2], p.plan_recv_v[2]], dtype=np.int64)
+        assert counts.shape == (4, world)
+        self.torch.cuda.synchronize(self.dev)
+        pkg._check(lib.exaadmm_set_stream(h, C.c_void_p(pkg.OWN_STREAM)), "exaadmm_set_stream")
+        pkg._check(lib.exaadmm_set_async(h, 0), "exaadmm_set_async")
+        pkg._check(lib.exaadmm_dist_attach(h, world, rank, ident[0], 128 if ident[0] else 0, p.nvar_global,
+                                           counts.ctypes.data_as(pkg.c_i64_p)), "exaadmm_dist_attach")
+        self.native = True
+
+    def run_inner_native(self, outer, max_inner, beta):
+        done = C.c_int()
+        res = np.zeros(4)
+        self.pkg._check(self.lib.exaadmm_dist_run_inner(self.mod.handle, int(outer), int(max_inner), float(beta), C.byref(done),
+                                                        self.pkg._dp(res)), "exaadmm_dist_run_inner")
+        return done.value, res
+
+    def run_fixed_native(self, iters, first_major_iter, beta):
+        res = np.zeros(4)
+        ms = C.c_double()
+        self.pkg._check(self.lib.exaadmm_dist_run_fixed(self.mod.handle, int(iters), int(first_major_iter), float(beta),
+                                                        self.pkg._dp(res), C.byref(ms)), "exaadmm_dist_run_fixed")
+        return res, ms.value
+
+    def norm_z_native(self):
+        v = C.c_double()
+        self.pkg._check(self.lib.exaadmm_dist_norm_z(self.mod.handle, C.byref(v)), "exaadmm_dist_norm_z")
+        return v.value
 
     def new_buffer(self, n):
         return self.torch.zeros(max(int(n), 1), dtype=self.torch.float64, device=self.dev)
@@ -366,6 +407,8 @@ class DistributedAcopf:
         """inner while-loop of admm_two_level.jl:34-63; loop control on the device, one host
         round trip per `batch` iterations; exact per-iteration break semantics."""
         be = self.be
+        if getattr(be, "native", False):      # the whole loop runs inside the library (RCCL from C++)
+            return be.run_inner_native(outer, max_inner, beta)
         be.ctrl_begin(outer, max_inner, beta)
         enq = 0
         done, inner, res = False, 0, np.zeros(4)
@@ -379,6 +422,8 @@ class DistributedAcopf:
         return inner, res
 
     def norm_z(self):
+        if getattr(self.be, "native", False):
+            return self.be.norm_z_native()
         sums = self.be.sumsq_z_partial()
         self._all_reduce(sums)
         return math.sqrt(float(sums.cpu()[2]))
@@ -430,11 +475,17 @@ DEFAULT_PAR = dict(initial_beta=1e3, inc_c=6.0, theta=0.8, outer_eps=2e-4, outer
 
 
 # --------------------------------------------------------------------------- bench (N > 1)
+SHARDED_CASES = ("case_ACTIVSg70k", "synthetic1M")     # BASELINE.json configs 4, 5: ONE grid cut N ways (strong scaling)
+
+
 def bench_main(args, rank, world, local_rank):
-    """bench.py --gpus N: weak scaling.  The grid is N areas of the benchmark size generated as one
-    banded synthetic grid (N x ngen, N x nline, N x nbus) and cut into N contiguous bus ranges,
-    one per GPU; cut branches are the tie lines.  A step = one inner iteration of the whole grid.
-    value = N x iterations/s: ADMM iterations/s normalised to one benchmark-sized area."""
+    """bench.py --gpus N.
+    default case (case13659pegase): WEAK scaling -- one banded synthetic grid of N areas of the benchmark size
+    (N x ngen, N x nline, N x nbus) cut into N bus ranges, one per GPU; cut branches are the tie lines;
+    value = N x (inner iterations/s of the N-area grid) = area-iterations/s.
+    --case case_ACTIVSg70k / synthetic1M: STRONG scaling -- the one grid of that size sharded N ways
+    (BASELINE.json configs 4 and 5); value = inner iterations/s of that grid.
+    The per-iteration sequence runs inside the library (csrc/dist_native.h, RCCL called from C++)."""
     import torch
     import torch.distributed as dist
     import exaadmm_loader
@@ -452,17 +503,32 @@ def bench_main(args, rank, world, local_rank):
     world = dist.get_world_size()
     params = B.CASE_PARAMS[args.case]
     g0, l0, b0 = syn.CASE_SIZES[args.case]
-    grid = syn.synthetic_grid(world * g0, world * l0, world * b0, seed=0)
+    sharded = args.case in SHARDED_CASES
+    gkw = dict(cost="market") if args.case == "case_ACTIVSg70k" else {}
+    if sharded:
+        grid = syn.synthetic_grid(g0, l0, b0, seed=0, **gkw)
+        workload = "synthetic-%s-sized sharded %d ways" % (args.case, world)
+    else:
+        grid = syn.synthetic_grid(world * g0, world * l0, world * b0, seed=0)
+        workload = "synthetic-%s-sized x %d areas" % (args.case, world)
     part = Partition(grid, world, rank)
     st = init_state(grid, params["rho_pq"], params["rho_va"])
     be = HipBackend(pkg, part, params["rho_pq"], params["rho_va"], params={"scale": params["scale"]}, device_index=local_rank)
     be.mod.sync_params()
     model = DistributedAcopf(part, be, dist, st, dict(DEFAULT_PAR))
+    native = os.environ.get("EXAADMM_DIST_PYTHON_LOOP") is None
+    if native:
+        be.attach_native(dist)
     beta = DEFAULT_PAR["initial_beta"]
 
     def run(n, first):
-        for i in range(n):                   # fixed count: plain (un-armed) step-wise launches
-            model_inner_fixed(model, first + i, beta)
+        if n <= 0:
+            return
+        if native:
+            be.run_fixed_native(n, first, beta)          # eight-deep batches are not needed here: no break test
+        else:
+            for i in range(n):                           # round-1 path: Python issues every step and collective
+                model_inner_fixed(model, first + i, beta)
 
     def model_inner_fixed(m, major_iter, beta):
         bk, p = m.be, m.part
@@ -491,8 +557,11 @@ def bench_main(args, rank, world, local_rank):
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = float(dt.cpu()[0])
-    res = torch.sqrt(be.sums).cpu().numpy()
-    cuts = torch.tensor([part.n_cut], dtype=torch.float64, device="cuda")
+    if native:
+        res, _ = be.run_fixed_native(1, prep + args.warmup + args.steps + 1, beta)     # norms of one more iteration
+    else:
+        res = torch.sqrt(be.sums).cpu().numpy()
+    cuts = torch.tensor([part.n_cut, part.n_native], dtype=torch.float64, device="cuda")
     dist.all_reduce(cuts)
     # every rank pushes out whatever the runtime libraries buffered on C stdio (RCCL version banner) BEFORE
     # rank 0 prints, so that the JSON line is the last line of the job's stdout
@@ -505,36 +574,39 @@ def bench_main(args, rank, world, local_rank):
     if rank == 0:
         its = args.steps / dt
         G, Ln, Bn = int(grid["ngen"]), int(grid["nline"]), int(grid["nbus"])
+        value = its if sharded else world * its
         out = {
-            "metric": "ADMM inner iterations/sec", "value": world * its, "unit": "iterations/s",
+            "metric": "ADMM inner iterations/sec", "value": value, "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "synthetic-%s-sized x %d areas" % (args.case, world), "ngen": G, "nline": Ln, "nbus": Bn,
-                       "rho_pq": params["rho_pq"], "rho_va": params["rho_va"], "scale": params["scale"],
-                       "cut_branches": int(cuts.cpu()[0]), "mode": "fixed-count inner iterations, no early break",
-                       "state": "ADMM state after %d untimed preparation iterations from init_solution!" % prep,
-                       "value_is": "N x (inner iterations/s of the N-area grid): iterations/s per benchmark-sized area, summed over areas",
-                       "parallelism": "bus/branch partition x%d, halo all_to_all + residual all_reduce (RCCL)" % world},
+            "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "value_is": ("inner iterations/s of the one grid, sharded over the GPUs" if sharded else
+                         "N x (inner iterations/s of the N-area grid): iterations/s per benchmark-sized area, summed over the N areas "
+                         "(equal to plain iterations/s at N = 1); the N-area grid itself iterates at grid_iterations_per_s"),
             "grid_iterations_per_s": its,
+            "config": {"workload": workload, "ngen": G, "nline": Ln, "nbus": Bn,
+                       "rho_pq": params["rho_pq"], "rho_va": params["rho_va"], "scale": params["scale"],
+                       "cut_branches": int(cuts.cpu()[0]), "cut_fraction": float(cuts.cpu()[0] / max(cuts.cpu()[1], 1.0)),
+                       "mode": "fixed-count inner iterations, no early break",
+                       "state": "ADMM state after %d untimed preparation iterations from init_solution!" % prep,
+                       "loop": "inside the library, RCCL from C++ (dist_native.h)" if native else "Python-driven steps + torch collectives",
+                       "parallelism": "bus/branch partition x%d (breadth-first bus ranges), per iteration 2 halo exchanges "
+                                      "(grouped ncclSend/ncclRecv) + one 32-byte all-reduce (RCCL)" % world},
             "roofline": {"bound": "hbm", "achieved": B.BYTES_PER_ITER(G, Ln, Bn) * its / 1e9, "peak": world * B.HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": B.BYTES_PER_ITER(G, Ln, Bn) * its / 1e9 / (world * B.HBM_PEAK_GBS),
-                         "traffic": None, "note": "whole-iteration algorithmic bytes of the N-area grid / wall time"},
+                         "traffic": None, "note": "whole-iteration algorithmic bytes of the grid / wall time"},
             "solver": {"primres": float(res[0])},
         }
-        # RCCL writes a version banner through C stdio at communicator creation; when stdout is a pipe it
-        # would be flushed at process exit, AFTER this line.  Flush C stdio first so that the JSON line is
-        # the last line of stdout.
         try:
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
+            C.CDLL(None).fflush(None)
         except Exception:
             pass
         print(json.dumps(out), flush=True)
     dist.barrier()
+    if native:
+        pkg._check(be.lib.exaadmm_dist_detach(be.mod.handle), "exaadmm_dist_detach")
     dist.destroy_process_group()
     try:
-        import ctypes
         sys.stdout.flush()
-        ctypes.CDLL(None).fflush(None)
+        C.CDLL(None).fflush(None)
     except Exception:
         pass

@@ -93,7 +93,10 @@ def synthetic_grid(ngen, nline, nbus, seed=0, tight_factor=0.99, locality=64, fe
         if ngen > 1:
             left = np.abs(gbus[k - 1] - np.arange(nbus)) <= np.abs(gbus[k] - np.arange(nbus))
             k = np.where(left, k - 1, k)
-        Pg = 1.02 * np.bincount(k, weights=Pd, minlength=ngen)
+        # round 1 ("dc") gave every unit 2 % more than its loads and let the reference bus absorb the surplus: on a
+        # banded grid that surplus travels the whole band (angles of tens of radians at 13 659 buses, beyond the
+        # +-2 pi angle bounds).  "acflow" balances every generator's area exactly: only local flows remain.
+        Pg = (1.02 if recipe != "acflow" else 1.0) * np.bincount(k, weights=Pd, minlength=ngen)
         Pmax = np.maximum(Pmax, Pg / 0.6)
         inj = (np.bincount(gbus, weights=Pg, minlength=nbus) - Pd) / M
         inj[0] -= inj.sum()                      # slack at the reference bus
@@ -106,11 +109,48 @@ def synthetic_grid(ngen, nline, nbus, seed=0, tight_factor=0.99, locality=64, fe
         rate = np.where(unlimited, 0.0, np.maximum(1.6 * flow, 60.0) * rng.uniform(1.0, 1.5, nline))
     YshR = YshI = None
     if feasible and recipe == "acflow":
-        # bus shunts first (they enter the balance): MW / MVAr at 1 p.u. (opfdata.jl:453-456)
+        rx = rng.uniform(0.08, 0.35, nline)        # transmission-like r / x
+
+        def dc_angles(xx):
+            ww = 1.0 / (xx * (1.0 + rx * rx))      # series susceptance x / (r^2 + x^2): the DC flows then match the AC ones to first order
+            Bm_ = sp.coo_matrix((np.concatenate([ww, ww, -ww, -ww]), (np.concatenate([fr, to, fr, to]), np.concatenate([fr, to, to, fr]))),
+                                shape=(nbus, nbus)).tocsr()
+            th = np.zeros(nbus)
+            th[1:] = spla.spsolve(Bm_[1:, 1:].tocsc(), inj[1:])
+            return th
+
+        # (1) lines are as strong as what they carry, like a planned network: where the DC flow of the local dispatch
+        #     opens an angle of more than 0.08 rad, the reactance shrinks (a second circuit / a higher voltage level);
+        #     resistance follows with a transmission-like r/x
+        theta = dc_angles(x)
+        for _ in range(12):
+            dth = np.abs(theta[fr] - theta[to])
+            if dth.max() <= 0.10:
+                break
+            x = np.where(dth > 0.08, x * 0.08 / np.maximum(dth, 1e-12), x)
+            theta = dc_angles(x)
+        r = x * rx
+        ratio = np.where(is_tr, 1.0 + (ratio - 1.0) * np.minimum(0.5, 2.0 * x), 1.0)   # taps within +-3 %, milder on strong branches
+        shift = shift * np.minimum(1.0, x / 0.2)                          # phase shifters: the shift they force is b * phi; keep it ~0.2 p.u.
+        tap = ratio * np.exp(1j * shift * np.pi / 180.0)
+        bc = np.where(is_tr, 0.0, np.minimum(bc, 0.3 * x))               # charging in proportion to the line length
+        Ys = 1.0 / (r + 1j * x)
+        Ytt = Ys + 1j * bc / 2
+        Yff = Ytt / (tap * np.conj(tap))
+        Yft = -Ys / np.conj(tap)
+        Ytf = -Ys / tap
+        assert np.abs(theta).max() < 3.0 and np.abs(theta[fr] - theta[to]).max() < 0.2, "synthetic grid: DC angles out of range"
+        # (2) voltage magnitudes: smooth over the graph (neighbours differ by ~1e-3, not by independent draws)
+        w = 1.0 / x
+        Lap = sp.coo_matrix((np.concatenate([w, w, -w, -w]), (np.concatenate([fr, to, fr, to]), np.concatenate([fr, to, to, fr]))),
+                            shape=(nbus, nbus)).tocsc()
+        sm = spla.spsolve(sp.identity(nbus, format="csc") + Lap / np.median(w), rng.standard_normal(nbus))
+        Vm = np.clip(1.0 + 0.01 * sm / max(np.abs(sm).max(), 1e-12), 0.97, 1.03)
+        # bus shunts (they enter the balance): MW / MVAr at 1 p.u. (opfdata.jl:453-456)
         has_sh = rng.random(nbus) < 0.08
         YshR = np.where(has_sh, rng.uniform(0.0, 5.0, nbus), 0.0) / M
         YshI = np.where(has_sh, rng.uniform(-20.0, 20.0, nbus), 0.0) / M
-        Vm = np.clip(1.0 + 0.012 * rng.standard_normal(nbus), 0.96, 1.04)
+        # (3) push the voltage profile through the AC branch equations; loads and dispatch follow from the injections
         V = Vm * np.exp(1j * theta)
         Sf = V[fr] * np.conj(Yff * V[fr] + Yft * V[to])      # from-end flow, p.u. (opfdata.jl:428-447)
         St = V[to] * np.conj(Ytt * V[to] + Ytf * V[fr])
@@ -120,8 +160,8 @@ def synthetic_grid(ngen, nline, nbus, seed=0, tight_factor=0.99, locality=64, fe
         needq = (np.bincount(fr, weights=Sf.imag, minlength=nbus) + np.bincount(to, weights=St.imag, minlength=nbus) - YshI * Vm ** 2) * M
         ng_at = np.bincount(gbus, minlength=nbus)
         Qd = 0.25 * Pd
-        # generator buses: dispatch = injection + load, shared equally by the units at the bus; what does not fit
-        # into [10 %, 70 %] of the units' capacity (reactive: +-35 %) stays with the load
+        # generator buses: dispatch = injection + load, shared by the units at the bus; what does not fit into
+        # [10 %, 70 %] of the units' capacity (reactive: +-35 %) stays with the load
         cap = np.bincount(gbus, weights=Pmax, minlength=nbus)
         want = need + Pd
         pg_bus = np.where(ng_at > 0, np.clip(want, 0.10 * cap, 0.70 * cap), 0.0)

@@ -146,6 +146,8 @@ int exaadmm_branch_stats(exaadmm_handle *h, double *avg_auglag_it, double *avg_m
 /* per-branch work counters of the last x-update: augmented-Lagrangian iterations, TRON minor
  * iterations (summed), solver-loop trips of the lane (divergence diagnostics) */
 int exaadmm_download_branch_counters(exaadmm_handle *h, int32_t *auglag_it, int32_t *minor_it, int32_t *ticks, int64_t nline);
+/* resident wavefronts per SIMD that the branch kernel's register / LDS footprint allows (occupancy API) */
+int exaadmm_branch_kernel_occupancy(exaadmm_handle *h, int *waves_per_simd);
 /* lane assignment of the branch kernel: lane i solves branch order[i] (zero-based reference branch
  * ids, a permutation of the active branches; NULL = identity).  Grouping branches with similar
  * solver work into the same wavefront reduces divergence; results do not depend on it. */
@@ -201,6 +203,27 @@ int exaadmm_ctrl_begin(exaadmm_handle *h, int outer, int max_inner, double beta,
 int exaadmm_ctrl_step(exaadmm_handle *h, const double *dev_sums4);
 int exaadmm_ctrl_read(exaadmm_handle *h, int *done, int *inner, double res[4]);
 int exaadmm_ctrl_end(exaadmm_handle *h);
+
+/* ---- distributed inner loop inside the library (one process per GPU, RCCL over xGMI) ----
+ * The per-iteration sequence  x-update -> halo A (u,z,l of cut branches) -> bus update -> halo B (v back) ->
+ * z/l/residual on owned elements -> all-reduce of the 4 partial sums -> device-side loop control  is enqueued from
+ * C++ on the handle's own stream, eight iterations per host visit; RCCL (grouped ncclSend/ncclRecv per peer, one
+ * 32-byte ncclAllReduce) is bound at run time.  The halo index lists are those of exaadmm_set_halo_index:
+ * slot 0 = what this rank sends after the x-update, slot 1 = where the received block is scattered,
+ * slot 2 / 3 = the same for the v entries travelling back; within a slot the entries are grouped per peer in rank order.
+ * exaadmm_dist_unique_id: called on ONE rank, the 128 bytes go to all ranks by the caller's own means
+ * (torch.distributed, MPI, a file).  exaadmm_dist_attach: collective over the ranks.  counts: 4 x nranks int64,
+ * [send u/z/l | recv u/z/l | send v | recv v] per peer, in doubles.  nranks = 1 needs no id (NULL). */
+int exaadmm_dist_unique_id(void *out128, int64_t nbytes);
+int exaadmm_dist_attach(exaadmm_handle *h, int nranks, int rank, const void *unique_id, int64_t id_bytes,
+                        int64_t nvar_global, const int64_t *counts);
+int exaadmm_dist_detach(exaadmm_handle *h);
+/* inner while-loop of admm_two_level.jl:34-63 over all partitions: eps_pri from the GLOBAL nvar, identical
+ * break decision on every rank (all ranks see the same all-reduced sums) */
+int exaadmm_dist_run_inner(exaadmm_handle *h, int outer, int max_inner, double beta, int *inner_done, double out[4]);
+/* K iterations without convergence test (benchmark mode); out = norms of the last one; ms_total = device time */
+int exaadmm_dist_run_fixed(exaadmm_handle *h, int iters, int first_major_iter, double beta, double out[4], double *ms_total);
+int exaadmm_dist_norm_z(exaadmm_handle *h, double *out); /* admm_outer_prestep over all partitions */
 
 /* ---- multi-period ACOPF: ModelMpacopf (src/models/mpacopf/mpacopf_model.jl:40-112) ----
  * T periods of the same network with their own loads, coupled through generator ramp constraints

@@ -116,3 +116,42 @@ def test_relaxed_check_every_runs_at_most_k_minus_1_iterations_longer(tmp_path, 
     assert int(out["outer"]) == ref.info.outer
     assert ref.info.cumul <= int(out["cumul"]) <= ref.info.cumul + 3 * ref.info.outer
     assert np.isfinite(out["u"]).all() and np.abs(out["u"] - ref.sol["u_curr"]).max() < 0.5
+
+
+def test_default_partition_keeps_the_cut_small_whatever_the_bus_numbering():
+    """Real case files number their buses arbitrarily: cutting the loader's order into ranges would cut almost
+    every branch.  The default partition cuts a breadth-first order instead (Partition(reorder=True))."""
+    dm = exaadmm_loader.load_submodule("distributed")
+    syn = exaadmm_loader.load_submodule("synthetic")
+    g = syn.synthetic_grid(60, 2000, 1300, seed=9, locality=16)
+    rng = np.random.default_rng(0)
+    perm = rng.permutation(1300)                       # shuffle the bus labels: the banded structure is hidden
+    inv = np.argsort(perm)
+    h = dict(g)
+    bb = perm[np.asarray(g["brBusIdx"])]
+    h["brBusIdx"] = bb
+    for k in ("Pd", "Qd", "Vmin", "Vmax", "YshR", "YshI"):
+        h[k] = np.asarray(g[k])[inv]
+    gb = perm[np.asarray(g["gen_bus"])]
+
+    def csr(owner, n):
+        order = np.argsort(owner, kind="stable").astype(np.int64)
+        start = np.zeros(n + 1, dtype=np.int64)
+        np.add.at(start, owner + 1, 1)
+        return np.cumsum(start), order
+
+    bb2 = bb.reshape(-1, 2)
+    h["FrStart"], h["FrIdx"] = csr(bb2[:, 0], 1300)
+    h["ToStart"], h["ToIdx"] = csr(bb2[:, 1], 1300)
+    h["GenStart"], h["GenIdx"] = csr(gb, 1300)
+    h["gen_bus"] = gb
+    world = 8
+    cut_bfs = sum(dm.Partition(h, world, r).n_cut for r in range(world))
+    cut_raw = sum(dm.Partition(h, world, r, reorder=False).n_cut for r in range(world))
+    cut_band = sum(dm.Partition(g, world, r, reorder=False).n_cut for r in range(world))   # the generator's own (banded) numbering
+    assert cut_raw > 0.8 * 2000 * (1 - 1 / world)       # shuffled labels cut into ranges: nearly every branch is cut
+    assert cut_bfs <= 0.12 * 2000, (cut_bfs, cut_raw, cut_band)
+    assert cut_bfs <= 3 * max(cut_band, 1)
+    # every branch is native on exactly one rank, every cut branch is a ghost on exactly one other
+    parts = [dm.Partition(h, world, r) for r in range(world)]
+    assert sum(p.n_native for p in parts) == 2000 and sum(p.n_ghost for p in parts) == cut_bfs

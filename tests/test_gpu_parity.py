@@ -555,3 +555,51 @@ def test_checkpoint_and_resume_through_the_abi(pkg, syn):
     for n in names:
         assert np.array_equal(a.download(n), b.download(n)), n
     assert np.array_equal(a.membuf, b.membuf)
+
+
+class _OneRank:
+    """stand-in for torch.distributed with a single rank (no process group needed)"""
+
+    @staticmethod
+    def get_world_size():
+        return 1
+
+    @staticmethod
+    def get_rank():
+        return 0
+
+    @staticmethod
+    def get_backend():
+        return "nccl"
+
+
+def test_native_distributed_loop_at_one_rank_matches_fused_solve(pkg, syn):
+    """csrc/dist_native.h: the distributed inner loop inside the library (RCCL bound at run time; with one rank
+    there is no communicator) must reproduce the fused single-GPU solve: same iteration counts, u / v to 1e-10."""
+    dm = exaadmm_loader.load_submodule("distributed")
+    g = syn.sized_like("case1354pegase", seed=2)
+    rho = (1e1, 1e3)
+    part = dm.Partition(g, 1, 0)
+    st = dm.init_state(g, *rho)
+    be = dm.HipBackend(pkg, part, rho[0], rho[1], device_index=0)
+    par = dict(dm.DEFAULT_PAR)
+    par.update(outer_iterlim=3, inner_iterlim=200)
+    model = dm.DistributedAcopf(part, be, _OneRank, st, par)
+    be.attach_native(_OneRank)
+    info = model.solve()
+    env, mod = pkg.solve_acopf("syn", grid=g, rho_pq=rho[0], rho_va=rho[1], outer_iterlim=3, inner_iterlim=200, verbose=0)
+    assert (info["outer"], info["cumul"]) == (mod.info.outer, mod.info.cumul)
+    assert abs(info["mismatch"] - mod.info.mismatch) <= 1e-10 * mod.info.mismatch
+    for name in ("u_curr", "v_curr", "z_curr"):
+        a, b = be.download(name), getattr(mod.solution, name)
+        assert np.abs(a - b).max() <= 1e-10 * max(1.0, np.abs(b).max()), name
+    # fixed-count mode (benchmark path) advances the same trajectory as the single-GPU fixed-count loop
+    be2 = dm.HipBackend(pkg, part, rho[0], rho[1], device_index=0)
+    for name in ("v_curr", "rho"):
+        be2.upload(name, part.slice_global(st[name]))
+    be2.attach_native(_OneRank)
+    res, ms = be2.run_fixed_native(12, 1, 1e3)
+    env3 = pkg.AdmmEnv("syn", rho[0], rho[1], verbose=0, grid=g)
+    m3 = pkg.ModelAcopf(env3)
+    n3, _, _ = m3.run_fixed(12, first_major_iter=1, beta=1e3)
+    assert np.allclose(res, n3, rtol=1e-10) and ms > 0

@@ -97,6 +97,11 @@ def library():
         raise ExaAdmmError("%s was not built through csrc/Makefile (version string %r lacks -sgpr-regalloc=basic): "
                            "its branch kernel cannot be trusted" % (LIB_PATH, ver))
     L.exaadmm_last_error.restype = C.c_char_p
+    L.exaadmm_dist_rccl_path.restype = C.c_char_p
+    # start the library's own HIP runtime NOW (it is not PyTorch's: torch bundles a private copy).  Starting torch's
+    # runtime between this library's load and its first HIP call leaves this one without a device.
+    L.exaadmm_device_count.restype = C.c_int
+    L.exaadmm_device_count()
     L.exaadmm_io_error.restype = C.c_char_p
     L.exaadmm_default_params.argtypes = [C.POINTER(Parameters)]
     L.exaadmm_default_params.restype = None
@@ -148,6 +153,7 @@ def library():
     L.exaadmm_dist_unique_id.argtypes = [C.c_char_p, C.c_int64]
     L.exaadmm_dist_attach.argtypes = [H, C.c_int, C.c_int, C.c_char_p, C.c_int64, C.c_int64, c_i64_p]
     L.exaadmm_dist_detach.argtypes = [H]
+    L.exaadmm_dist_selftest.argtypes = [H, C.c_int64, c_double_p]
     L.exaadmm_dist_run_inner.argtypes = [H, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int), c_double_p]
     L.exaadmm_dist_run_fixed.argtypes = [H, C.c_int, C.c_int, C.c_double, c_double_p, c_double_p]
     L.exaadmm_dist_norm_z.argtypes = [H, c_double_p]

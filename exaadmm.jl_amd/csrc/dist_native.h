@@ -14,8 +14,11 @@
 // 0.55x of the fused loop at one rank).  Here an iteration is nine kernel launches and at most three RCCL calls from
 // C++, enqueued in batches of eight with ONE host round trip per batch, as exaadmm_run_inner does on one GPU.
 //
-// RCCL is bound at run time (dlopen) so that the library keeps loading on hosts without it; a copy that is already
-// in the process (PyTorch ships one) is preferred, so that there is one RCCL per process.
+// RCCL is bound at run time (dlopen) so that the library keeps loading on hosts without it.  It must be the RCCL that
+// sits on THE SAME HIP runtime as this library, because the handle's stream is handed to it: a Python process that
+// also imports PyTorch holds a second, private HIP runtime and RCCL (torch/lib/), whose stream handles mean nothing to
+// this one.  The copy next to the libamdhip64 this library is bound to (normally /opt/rocm/lib) is therefore loaded by
+// path; torch.distributed is only used by the caller to hand the 128-byte id around.
 #pragma once
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -40,20 +43,37 @@ struct exaadmm_dist {
 };
 
 static exaadmm_dist g_rccl_binding;   // function table only (comm stays per handle)
+static std::string g_rccl_path;
+
+// which RCCL the library bound (empty before the first exaadmm_dist_unique_id / multi-rank exaadmm_dist_attach)
+extern "C" const char* exaadmm_dist_rccl_path(void) { return g_rccl_path.c_str(); }
 
 static int rccl_bind(exaadmm_dist* d)
 {
     if (d->lib) return 0;
     if (!g_rccl_binding.lib) {
-        const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        std::vector<std::string> names;
+        if (const char* e = getenv("EXAADMM_RCCL_LIB")) names.push_back(e);
+        Dl_info info;
+        if (dladdr((void*)&hipGetDeviceCount, &info) && info.dli_fname) {   // directory of the HIP runtime in use
+            std::string dir(info.dli_fname);
+            const size_t slash = dir.rfind('/');
+            if (slash != std::string::npos) {
+                dir.resize(slash + 1);
+                names.push_back(dir + "librccl.so.1");
+                names.push_back(dir + "librccl.so");
+            }
+        }
+        names.push_back("/opt/rocm/lib/librccl.so.1");
+        names.push_back("librccl.so.1");
         void* lib = nullptr;
-        for (const char* n : names)   // a copy already mapped into the process (e.g. torch's) wins
-            if ((lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL))) break;
-        if (!lib)
-            for (const char* n : names)
-                if ((lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+        for (const std::string& n : names)
+            if ((lib = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL))) {
+                g_rccl_path = n;
+                break;
+            }
         if (!lib) {
-            set_err("RCCL not found (librccl.so): %s", dlerror());
+            set_err("RCCL not found next to the HIP runtime (set EXAADMM_RCCL_LIB): %s", dlerror());
             return EXAADMM_ERR_INVALID;
         }
         exaadmm_dist& b = g_rccl_binding;
@@ -150,7 +170,7 @@ extern "C" int exaadmm_dist_attach(exaadmm_handle* h, int nranks, int rank, cons
         REQUIRE(tot == h->halo[s].count, "halo counts do not add up to the index list of the slot (exaadmm_set_halo_index)");
         if (tot > 0) HIPCHK(hipMalloc((void**)&d->buf[s], (size_t)tot * sizeof(double)));
     }
-    if (nranks > 1) {
+    if (nranks > 1 || unique_id != nullptr) {   // (a one-rank communicator is legal: used by the self test)
         REQUIRE(unique_id && id_bytes == (int64_t)sizeof(ncclUniqueId), "unique id must be the 128 bytes of exaadmm_dist_unique_id");
         if ((rc = rccl_bind(d))) return rc;
         ncclUniqueId id;
@@ -187,8 +207,44 @@ static int dist_exchange(exaadmm_handle* h, int send_slot, int recv_slot)
 static int dist_allreduce_sums(exaadmm_handle* h)
 {
     exaadmm_dist* d = h->dist;
-    if (d->nranks > 1) NCCLCHK(d, d->AllReduce(h->d_sums, h->d_sums, 4, ncclDouble, ncclSum, d->comm, h->stream));
+    if (d->comm) NCCLCHK(d, d->AllReduce(h->d_sums, h->d_sums, 4, ncclDouble, ncclSum, d->comm, h->stream));
     return 0;
+}
+
+// Exercises every RCCL entry point the loop uses, on the handle's stream, with whatever communicator is attached
+// (one rank is enough: a rank may send to itself inside a group): all-reduce of 4 doubles, grouped send + receive of
+// n doubles.  *max_err = largest deviation from the expected values.  Proves that the bound RCCL and this library
+// share one HIP runtime (a stream handle of a foreign runtime would fail here).
+extern "C" int exaadmm_dist_selftest(exaadmm_handle* h, int64_t n, double* max_err)
+{
+    REQUIRE(h && h->dist && h->dist->comm && n >= 1 && max_err, "needs an attached communicator");
+    exaadmm_dist* d = h->dist;
+    HIPCHK(hipSetDevice(h->device));
+    std::vector<double> a((size_t)n), b((size_t)n, -1.0);
+    for (int64_t i = 0; i < n; i++) a[(size_t)i] = 0.5 * (double)i + d->rank;
+    double *da = nullptr, *db = nullptr;
+    HIPCHK(hipMalloc((void**)&da, (size_t)n * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&db, (size_t)n * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(da, a.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    const double four[4] = {1.0, 2.0, 3.0, 4.0};
+    HIPCHK(hipMemcpyAsync(h->d_sums, four, sizeof(four), hipMemcpyHostToDevice, h->stream));
+    NCCLCHK(d, d->AllReduce(h->d_sums, h->d_sums, 4, ncclDouble, ncclSum, d->comm, h->stream));
+    const int next = (d->rank + 1) % d->nranks, prev = (d->rank + d->nranks - 1) % d->nranks;
+    NCCLCHK(d, d->GroupStart());
+    NCCLCHK(d, d->Send(da, (size_t)n, ncclDouble, next, d->comm, h->stream));
+    NCCLCHK(d, d->Recv(db, (size_t)n, ncclDouble, prev, d->comm, h->stream));
+    NCCLCHK(d, d->GroupEnd());
+    double got[4];
+    HIPCHK(hipMemcpyAsync(got, h->d_sums, sizeof(got), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(b.data(), db, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    (void)hipFree(da);
+    (void)hipFree(db);
+    double e = 0.0;
+    for (int j = 0; j < 4; j++) e = fmax(e, fabs(got[j] - d->nranks * four[j]));
+    for (int64_t i = 0; i < n; i++) e = fmax(e, fabs(b[(size_t)i] - (0.5 * (double)i + prev)));
+    *max_err = e;
+    return EXAADMM_OK;
 }
 
 // one inner iteration, enqueue only.  c != nullptr: armed device loop control (major_iter and beta come from it)

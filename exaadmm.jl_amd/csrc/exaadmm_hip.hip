@@ -108,6 +108,9 @@ struct exaadmm_handle {
     bool spec_on = false;
     double *u_alt = nullptr, *ls1_alt = nullptr, *ls2_alt = nullptr, *mu_alt = nullptr;
     int *st_alt[3] = {nullptr, nullptr, nullptr};   // per-branch counters of the alternate set (auglag, minor, ticks)
+    // fused z/l variant (kernels.h, k_branch_t<MP, true>): alternate v, per-block partial sums of the branch launch
+    bool zl_on = false;
+    double *v_alt = nullptr, *partials_br = nullptr;
     Dev dspec[2];
     Dev* d_dspec[2] = {nullptr, nullptr};
     int* h_base = nullptr;
@@ -195,6 +198,20 @@ static double* vec_ptr(exaadmm_handle* h, int which)
 // compiled correctly with -mllvm -sgpr-regalloc=basic (DESIGN.md "compiler note"); loaders check for it
 extern "C" const char* exaadmm_version(void) { return "exaadmm-hip 0.2 (gfx950) [" EXA_BUILD_FLAGS "]"; }
 extern "C" const char* exaadmm_last_error(void) { return g_err.c_str(); }
+
+// Number of visible HIP devices (0 when there is none or the runtime cannot start).  Also the library's way of
+// starting ITS HIP runtime at a defined moment: a process that holds a second HIP runtime (PyTorch bundles one)
+// must not start that one between this library's load and its first HIP call (observed: this runtime then reports
+// no device); the Python loader therefore calls this right after loading the library.
+extern "C" int exaadmm_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
 
 extern "C" void exaadmm_default_params(exaadmm_params* p)
 {
@@ -372,6 +389,11 @@ extern "C" int exaadmm_create(const exaadmm_grid* g, const exaadmm_params* p, in
         h->bus_lane_kernel = (e != nullptr && strcmp(e, "lane") == 0);
         h->use_graph = (getenv("EXAADMM_NO_GRAPH") == nullptr);
         h->spec_on = (getenv("EXAADMM_NO_SPEC") == nullptr);   // speculative branch launch (A/B switch)
+#if defined(EXA_HAVE_ZL)
+        // z/l pass fused into the branch launch's prologue (A/B switch; needs the lane-group bus kernel, which carries
+        // the reduction block)
+        h->zl_on = h->spec_on && !h->bus_lane_kernel && (getenv("EXAADMM_NO_ZLFUSE") == nullptr);
+#endif
     }
     TRY(upload_mupow_table());
 
@@ -943,7 +965,7 @@ static void launch_bus(exaadmm_handle* h, const Ctrl* c)
     if (h->bus_lane_kernel)  // A/B switch (EXAADMM_BUS_KERNEL=lane): one lane per bus
         hipLaunchKernelGGL(k_bus, grid_for(h->d.Ba, 64), dim3(64), 0, h->stream, h->d, h->baseMVA, c);
     else
-        hipLaunchKernelGGL(k_bus_group, grid_for(h->d.Ba, BUS_BLOCK / BUS_W), dim3(BUS_BLOCK), 0, h->stream, h->d, h->baseMVA, c);
+        hipLaunchKernelGGL(k_bus_group, grid_for(h->d.Ba, BUS_BLOCK / BUS_W), dim3(BUS_BLOCK), 0, h->stream, h->d, h->baseMVA, c, (Ctrl*)nullptr);
 }
 static void launch_fused_zl(exaadmm_handle* h, double beta, const Ctrl* c)
 {
@@ -1247,6 +1269,12 @@ static int spec_prepare(exaadmm_handle* h)
             if ((rc = dev_alloc(h, &q, (size_t)h->Lp))) return rc;
             HIPCHK(hipMemsetAsync(q, 0, (size_t)h->Lp * sizeof(int), h->stream));
         }
+        if ((rc = dev_alloc(h, &h->v_alt, (size_t)h->N))) return rc;
+        {
+            const int nblk = (int)grid_for(h->d.La, BR_BLOCK).x + ((h->G > 0) ? (int)grid_for(h->G, BR_BLOCK).x : 0);
+            if ((rc = dev_alloc(h, &h->partials_br, (size_t)nblk * 4))) return rc;
+        }
+        HIPCHK(hipMemcpyAsync(h->v_alt, h->d.v, (size_t)h->N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         if ((rc = dev_alloc(h, &h->d_dspec[0], 1))) return rc;
         if ((rc = dev_alloc(h, &h->d_dspec[1], 1))) return rc;
         if (hipHostMalloc((void**)&h->h_base, sizeof(int), hipHostMallocDefault) != hipSuccess) {
@@ -1270,6 +1298,17 @@ static int spec_prepare(exaadmm_handle* h)
     a.st_auglag = h->st_alt[0];  a.st_minor = h->st_alt[1];  a.st_ticks = h->st_alt[2];
     b.u_in = h->u_alt;    b.ls1_in = h->ls1_alt;  b.ls2_in = h->ls2_alt;  b.mu_in = h->mu_alt;
     a.npartials = b.npartials = h->ew_blocks;
+    // (only while the branch launch is latency-bound: with more than ~2 waves queued per SIMD the prologue's memory
+    //  latency, at one resident wave per SIMD, costs more than the streaming kernel it replaces -- measured at 1M
+    //  branches: k_branch 0.43 -> 0.61 ms against 0.10 ms for k_fused_zl; +3 % at 20 467 and 88 207 branches)
+    if (h->zl_on && h->d.lane_order == nullptr && grid_for(h->d.La, BR_BLOCK).x <= 2048) {
+        // v follows the same parity as u: the bus launch of an odd iteration writes the alternate v, which the next
+        // (even) iteration's branch launch reads
+        a.v_in = h->d.v;   a.v = h->v_alt;
+        b.v_in = h->v_alt; // b.v stays the primary buffer
+        a.partials_br = b.partials_br = h->partials_br;
+        a.npartials_br = b.npartials_br = (int)grid_for(h->d.La, BR_BLOCK).x + ((h->G > 0) ? (int)grid_for(h->G, BR_BLOCK).x : 0);
+    }
     if (memcmp(&a, &h->dspec[0], sizeof(Dev)) != 0 || memcmp(&b, &h->dspec[1], sizeof(Dev)) != 0) {
         invalidate_graph(h);
         h->dspec[0] = a;
@@ -1290,6 +1329,21 @@ static void enqueue_iteration_spec(exaadmm_handle* h, Ctrl* c, int j, bool sampl
     const int ng = (h->G > 0) ? (int)grid_for(h->G, BR_BLOCK).x : 0;
     if (sample) (void)hipEventRecord(h->tev[0], h->stream);
     if (bev) (void)hipEventRecord(bev[0], h->stream);
+#if defined(EXA_HAVE_ZL)
+    if (dv.partials_br != nullptr) {
+        // two launches per iteration: [z/l of the previous iteration + x-update] -> [bus update + reduction block]
+        hipLaunchKernelGGL((k_branch_t<false, true>), dim3(nb + ng), dim3(BR_BLOCK), 0, h->stream, h->d_dspec[par], h->bo, h->par.scale, 0, c,
+                           ng, h->baseMVA, j);
+        if (bev) (void)hipEventRecord(bev[1], h->stream);
+        if (sample) (void)hipEventRecord(h->tev[1], h->stream);
+        hipLaunchKernelGGL(k_bus_group, dim3(grid_for(h->d.Ba, BUS_BLOCK / BUS_W).x + 1), dim3(BUS_BLOCK), 0, h->stream, dv, h->baseMVA, c, c);
+        if (sample) {
+            (void)hipEventRecord(h->tev[2], h->stream);
+            (void)hipEventRecord(h->tev[3], h->stream);
+        }
+        return;
+    }
+#endif
     hipLaunchKernelGGL((k_branch_t<false>), dim3(nb + ng + 1), dim3(BR_BLOCK), 0, h->stream, h->d_dspec[par], h->bo, h->par.scale, 0, c,
                        ng, h->baseMVA, j);
     if (bev) (void)hipEventRecord(bev[1], h->stream);
@@ -1297,7 +1351,7 @@ static void enqueue_iteration_spec(exaadmm_handle* h, Ctrl* c, int j, bool sampl
     if (h->bus_lane_kernel)
         hipLaunchKernelGGL(k_bus, grid_for(h->d.Ba, 64), dim3(64), 0, h->stream, dv, h->baseMVA, c);
     else
-        hipLaunchKernelGGL(k_bus_group, grid_for(h->d.Ba, BUS_BLOCK / BUS_W), dim3(BUS_BLOCK), 0, h->stream, dv, h->baseMVA, c);
+        hipLaunchKernelGGL(k_bus_group, grid_for(h->d.Ba, BUS_BLOCK / BUS_W), dim3(BUS_BLOCK), 0, h->stream, dv, h->baseMVA, c, (Ctrl*)nullptr);
     if (sample) (void)hipEventRecord(h->tev[2], h->stream);
     hipLaunchKernelGGL(k_fused_zl, dim3(h->ew_blocks), dim3(EW_BLOCK), 0, h->stream, dv, 0.0, c, &c->pending);
     if (sample) (void)hipEventRecord(h->tev[3], h->stream);
@@ -1309,6 +1363,8 @@ static int spec_finish(exaadmm_handle* h, int iters)
 {
     if (iters & 1) {
         HIPCHK(hipMemcpyAsync(h->d.u, h->u_alt, (size_t)h->N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        if (h->dspec[0].partials_br != nullptr)   // fused z/l variant: v was ping-ponged as well
+            HIPCHK(hipMemcpyAsync(h->d.v, h->v_alt, (size_t)h->N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(h->d.ls1, h->ls1_alt, (size_t)h->Lp * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(h->d.ls2, h->ls2_alt, (size_t)h->Lp * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(h->d.mu, h->mu_alt, (size_t)h->Lp * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
@@ -1317,6 +1373,17 @@ static int spec_finish(exaadmm_handle* h, int iters)
             HIPCHK(hipMemcpyAsync(prim[q], h->st_alt[q], (size_t)h->Lp * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
     }
     return 0;
+}
+
+// The last enqueued iteration has no successor: nothing would reduce its residual sums (plain speculative loop) or
+// even run its z/l pass (fused variant).  Both kernels return at once when the loop has already stopped.
+static void spec_complete_last(exaadmm_handle* h, int enqueued)
+{
+    if (h->dspec[0].partials_br != nullptr && enqueued > 0) {
+        const Dev& dv = h->dspec[(enqueued - 1) & 1];   // the buffers the last enqueued iteration wrote
+        hipLaunchKernelGGL(k_fused_zl, dim3(h->ew_blocks), dim3(EW_BLOCK), 0, h->stream, dv, 0.0, h->d_ctrl, &h->d_ctrl->pending);
+    }
+    hipLaunchKernelGGL(k_final_reduce, dim3(1), dim3(EW_BLOCK), 0, h->stream, h->d.partials, h->ew_blocks, h->d_sums, h->d_ctrl, 1);
 }
 
 static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
@@ -1359,8 +1426,7 @@ static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
         }
         if (hc->done) break;
     }
-    // the last enqueued iteration has no successor whose branch launch would reduce its sums
-    hipLaunchKernelGGL(k_final_reduce, dim3(1), dim3(EW_BLOCK), 0, h->stream, h->d.partials, h->ew_blocks, h->d_sums, h->d_ctrl, 1);
+    spec_complete_last(h, enq);
     HIPCHK(hipMemcpyAsync(hc, h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
     if ((rc = sync_check(h, true))) return rc;
     if ((rc = spec_finish(h, hc->inner))) return rc;
@@ -1391,6 +1457,7 @@ extern "C" int exaadmm_run_inner(exaadmm_handle* h, int outer, int max_inner, do
     hc->check_every = std::max(1, (int)h->par.check_every);
     hc->eps_pri = sqrt((double)h->nvar_ctrl) / (2500.0 * outer);  // admm_two_level.jl:45
     hc->beta = beta;
+    hc->first_iter = 1;
     HIPCHK(hipMemcpyAsync(h->d_ctrl, hc, sizeof(Ctrl), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));  // hc is reused as the download target below
     h->residual_vectors_valid = false;
@@ -1537,11 +1604,12 @@ extern "C" int exaadmm_run_fixed(exaadmm_handle* h, int iters, int first_major_i
         hc->eps_pri = -1.0;
         hc->beta = beta;
         hc->base = first_major_iter - 1;
+        hc->first_iter = first_major_iter;
         HIPCHK(hipMemcpyAsync(h->d_ctrl, hc, sizeof(Ctrl), hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         HIPCHK(hipEventRecord(h->ev[0], h->stream));
         for (int i = 0; i < iters; i++) enqueue_iteration_spec(h, h->d_ctrl, i, false, time_branch ? &h->ev[2 + 2 * i] : nullptr);
-        hipLaunchKernelGGL(k_final_reduce, dim3(1), dim3(EW_BLOCK), 0, h->stream, h->d.partials, h->ew_blocks, h->d_sums, h->d_ctrl, 1);
+        spec_complete_last(h, iters);
         HIPCHK(hipEventRecord(h->ev[1], h->stream));
         if ((rc = spec_finish(h, iters))) return rc;
         double s[4];

@@ -27,6 +27,9 @@ struct Ctrl {
     // speculative branch launch (exaadmm_run_inner / run_fixed on one GPU): iterations enqueued before the
     // current batch, and "the z/l pass of an iteration has run but its sums are not reduced yet"
     int base, pending;
+    // z/l update fused into the branch launch (k_branch_t<MP, true>): major_iter of the launch that has NO pending
+    // z/l update in front of it (the first iteration of the loop)
+    int first_iter;
 };
 
 struct Dev {
@@ -53,6 +56,11 @@ struct Dev {
     // it writes), and the number of partial-sum blocks its extra block reduces
     const double *u_in, *ls1_in, *ls2_in, *mu_in;
     int npartials;
+    // fused z/l variant: v the branch launch reads (the bus launch of the same parity writes d.v), per-block partial
+    // sums of the branch launch's z/l prologue
+    const double* v_in;
+    double* partials_br;
+    int npartials_br;
     // multi-period model (ModelMpacopf): T periods stored period-major inside every
     // plane (generator t*g1+i, branch t*l1+j, bus t*b1+k); T = 1 for the single-period model.
     // Ramp block (SolutionRamping of period t >= 1) at [t*g1 + i]; block 0 is unused.
@@ -71,15 +79,39 @@ __device__ __forceinline__ bool loop_done(const Ctrl* c) { return c != nullptr &
 
 // ---------------------------------------------------------------- generator
 // generator_kernel_two_level (acopf_generator_kernel_gpu.jl:1-22), one lane per generator
-__device__ __forceinline__ void generator_update(const Dev& d, double baseMVA, int i)
+__device__ __forceinline__ void generator_update(const Dev& d, double baseMVA, int i, const double* vsrc = nullptr)
 {
     if (i >= d.G) return;
+    const double* const v = vsrc ? vsrc : d.v;
     const int pg = i, qg = d.Gp + i;
     const double M = baseMVA;
-    double t = (-(d.c1[i] * M + d.l[pg] + d.rho[pg] * (-d.v[pg] + d.z[pg]))) / (2 * d.c2[i] * (M * M) + d.rho[pg]);
+    double t = (-(d.c1[i] * M + d.l[pg] + d.rho[pg] * (-v[pg] + d.z[pg]))) / (2 * d.c2[i] * (M * M) + d.rho[pg]);
     d.u[pg] = fmax(d.pgmin[i], fmin(d.pgmax[i], t));
-    t = (-(d.l[qg] + d.rho[qg] * (-d.v[qg] + d.z[qg]))) / d.rho[qg];
+    t = (-(d.l[qg] + d.rho[qg] * (-v[qg] + d.z[qg]))) / d.rho[qg];
     d.u[qg] = fmax(d.qgmin[i], fmin(d.qgmax[i], t));
+}
+
+// z_prev <- z ; z-update ; l-update ; residual terms of ONE element, the arithmetic of k_fused_zl
+// (admm_inner_prestep + admm_update_z + admm_update_l + admm_update_residual) -- used by the branch launch's
+// prologue when the z/l pass rides in it.  Returns the new l and z of the element.
+__device__ __forceinline__ void zl_element(const Dev& d, int e, double u, double v, double rho, double beta, double (&s)[4],
+                                           double& l_new, double& z_new)
+{
+    const double lz = d.lz[e];
+    const double zold = d.z[e];
+    const double z = (-(lz + d.l[e] + rho * (u - v))) / (beta + rho);
+    const double rp = u - v + z;
+    const double rd = z - zold;
+    const double ax = rp - z;
+    d.zp[e] = zold;
+    d.z[e] = z;
+    l_new = -(lz + beta * z);
+    d.l[e] = l_new;
+    z_new = z;
+    s[0] += rp * rp;
+    s[1] += rd * rd;
+    s[2] += z * z;
+    s[3] += ax * ax;
 }
 
 __global__ void k_generator(Dev d, double baseMVA, const Ctrl* ctrl)
@@ -152,6 +184,9 @@ __global__ void __launch_bounds__(64) k_gen_ramp(Dev d, BranchOptions o, double 
 #if !defined(EXA_CONST_IN_LDS) && !defined(EXA_A_IN_LDS) && !defined(EXA_L_IN_LDS) && !defined(EXA_CONST_IN_REGS)
 #define EXA_CONST_IN_REGS 1
 #endif
+#if defined(EXA_CONST_IN_REGS) && !defined(EXA_A_IN_LDS) && !defined(EXA_L_IN_LDS)
+#define EXA_HAVE_ZL 1   // the fused z/l prologue (k_branch_t<MP, true>) exists in this build
+#endif
 constexpr int BR_LDS_CONST = 32, BR_LDS_MAT = 21;
 #if defined(EXA_A_IN_LDS) && defined(EXA_L_IN_LDS)
 constexpr int BR_LDS_DOUBLES = BR_LDS_CONST + 2 * BR_LDS_MAT;
@@ -175,7 +210,14 @@ constexpr int BR_LDS_DOUBLES = BR_LDS_CONST;
 #if !defined(EXA_BR_WAVES)
 #define EXA_BR_WAVES 1   // minimum waves per SIMD the register allocation must allow (2 -> at most 256 VGPR + AGPR)
 #endif
-template <bool MP>
+// ZL = true (speculative loop on one GPU, single-period model): the z / l / residual pass of the PREVIOUS iteration rides
+// in this launch's prologue -- every lane already loads u, v, z, l, rho of its own 8 (generator lanes: 2) elements, so
+// the pass costs 8 more loads (lz) and its arithmetic instead of a kernel of its own (6 reads + 3 writes per element
+// and a launch); per-block partial sums of the four residual norms go to partials_br, the bus launch that follows
+// reduces them and advances the loop control (k_bus_group, `red`).  The launch is still speculative: it reads the
+// previous iterate (u_in, v_in, ls*_in) and writes the other buffer set, so a stop detected one launch later leaves
+// the iterate of the stopping iteration -- including the z, l this prologue has just completed for it -- intact.
+template <bool MP, bool ZL = false>
 __global__ void __launch_bounds__(BR_BLOCK, EXA_BR_WAVES) k_branch_t(const Dev* __restrict__ dp, BranchOptions o, double scale, int major_iter, Ctrl* ctrl,
                                                        int gen_blocks, double baseMVA, int spec_j)
 {
@@ -186,7 +228,15 @@ __global__ void __launch_bounds__(BR_BLOCK, EXA_BR_WAVES) k_branch_t(const Dev* 
 #endif
     const Dev& d = *dp;
     int extra = 0;
-    if (spec_j >= 0) {
+    bool do_zl = false;
+    double zl_beta = 0.0;
+    if (ZL) {
+        if (ctrl->done) return;
+        major_iter = ctrl->base + spec_j + 1;
+        do_zl = (major_iter != ctrl->first_iter);
+        zl_beta = ctrl->beta;
+        if (do_zl && blockIdx.x == 0 && threadIdx.x == 0) ctrl->pending = 1;   // read by the NEXT launch only (bus, `red`)
+    } else if (spec_j >= 0) {
         extra = 1;
         if ((int)blockIdx.x == (int)gridDim.x - 1) {   // the reduction block
             if (ctrl->done || !ctrl->pending) return;
@@ -223,26 +273,49 @@ __global__ void __launch_bounds__(BR_BLOCK, EXA_BR_WAVES) k_branch_t(const Dev* 
     // blocks past the branch range do the generator update (independent of the branches; one
     // launch and one inter-kernel gap less per iteration).  gen_blocks = 0: branches only.
     const int nbr_blocks = gridDim.x - gen_blocks - extra;
+    double zs[4] = {0.0, 0.0, 0.0, 0.0};   // ZL: this lane's residual terms
     if ((int)blockIdx.x >= nbr_blocks) {
         const int gi = ((int)blockIdx.x - nbr_blocks) * BR_BLOCK + threadIdx.x;
         if (MP)   // multi-period model: ramp subproblems run beside the branch solves, same launch
             gen_ramp_lane(d, o, baseMVA, major_iter, gi);
-        else
+        else if (ZL) {
+            const double* const uin = d.u_in ? d.u_in : d.u;
+            const double* const vin = d.v_in ? d.v_in : d.v;
+            if (do_zl && gi < d.G) {
+                double ln, zn;
+                zl_element(d, gi, uin[gi], vin[gi], d.rho[gi], zl_beta, zs, ln, zn);
+                zl_element(d, d.Gp + gi, uin[d.Gp + gi], vin[d.Gp + gi], d.rho[d.Gp + gi], zl_beta, zs, ln, zn);
+            }
+            generator_update(d, baseMVA, gi, vin);
+            if (do_zl) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) zs[j] += __shfl_down(zs[j], off, 64);
+                }
+                if (threadIdx.x == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) d.partials_br[blockIdx.x * 4 + j] = zs[j];
+                }
+            }
+        } else
             generator_update(d, baseMVA, gi);
         return;
     }
     const int slot = blockIdx.x * BR_BLOCK + threadIdx.x;
-    if (slot >= d.La) return;
+    if (!ZL && slot >= d.La) return;
+    const bool lane_on = slot < d.La;
 #if defined(EXA_PROFILE_PHASES)
     const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
 #endif
     // which lane solves a branch does not change any result; lane_order exists for experiments
     // (regrouping lanes by work does not pay in either regime)
-    const int b = d.lane_order ? d.lane_order[slot] : slot;
+    const int b = (!ZL && d.lane_order) ? d.lane_order[slot] : (lane_on ? slot : 0);   // (ZL: lanes past the range read branch 0, write nothing)
     const int Lp = d.Lp;
     const int base = 2 * d.Gp + b;
     double* my = lds + threadIdx.x;
     const double* const uin = d.u_in ? d.u_in : d.u;
+    const double* const vin = (ZL && d.v_in) ? d.v_in : d.v;
 
     double ub[8], bnd[8];
 #if defined(EXA_CONST_IN_REGS)
@@ -251,14 +324,21 @@ __global__ void __launch_bounds__(BR_BLOCK, EXA_BR_WAVES) k_branch_t(const Dev* 
     for (int k = 0; k < 8; k++) {
         const int e = base + k * Lp;
         ub[k] = uin[e];
-        bd.lam_[k] = d.l[e];
         bd.rho_[k] = d.rho[e];
-        bd.xt_[k] = d.v[e] - d.z[e];
+        if (ZL && do_zl && lane_on) {
+            double zn;
+            zl_element(d, e, ub[k], vin[e], bd.rho_[k], zl_beta, zs, bd.lam_[k], zn);
+            bd.xt_[k] = vin[e] - zn;
+        } else {
+            bd.lam_[k] = d.l[e];
+            bd.xt_[k] = vin[e] - d.z[e];
+        }
         bd.Y_[k] = d.Y[b + k * Lp];
         bnd[k] = d.bnd[b + k * Lp];
     }
     (void)my;
 #else
+    static_assert(!ZL, "the fused z/l prologue is only built for the register-resident constants layout");
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         const int e = base + k * Lp;
@@ -272,6 +352,20 @@ __global__ void __launch_bounds__(BR_BLOCK, EXA_BR_WAVES) k_branch_t(const Dev* 
     BranchDataRef<BR_BLOCK> bd;
     bd.p = my;
 #endif
+    if (ZL) {
+        if (do_zl) {   // per-block partial sums of the four residual norms (fixed topology: wave shuffle, one wave per block)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) zs[j] += __shfl_down(zs[j], off, 64);
+            }
+            if (threadIdx.x == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) d.partials_br[blockIdx.x * 4 + j] = zs[j];
+            }
+        }
+        if (!lane_on) return;
+    }
     bd.ls1 = (d.ls1_in ? d.ls1_in : d.ls1)[b];
     bd.ls2 = (d.ls2_in ? d.ls2_in : d.ls2)[b];
     bd.mu = (major_iter == 1) ? 10.0 : (d.mu_in ? d.mu_in : d.mu)[b];
@@ -494,7 +588,12 @@ __device__ __forceinline__ void bus_load_end(const Dev& d, int code, double (&r)
     }
 }
 
-__global__ void __launch_bounds__(BUS_BLOCK) k_bus_group(Dev d, double baseMVA, const Ctrl* ctrl)
+__device__ __forceinline__ void block_reduce4(double (&s)[4]);   // (defined with the elementwise kernels below)
+
+// red != nullptr (fused z/l variant of the speculative loop): the launch carries one extra block that sums the
+// per-block residual terms the preceding branch launch's prologue left in partials_br and advances the loop control
+// (what k_final_reduce does), while the other blocks update their buses.
+__global__ void __launch_bounds__(BUS_BLOCK) k_bus_group(Dev d, double baseMVA, const Ctrl* ctrl, Ctrl* red)
 {
     // per component the lane computes the TERMS the reference adds up (each term is evaluated
     // exactly as written there: l + rho*(u+z), 1/rho, (u+z) + l/rho); the leader only adds them
@@ -503,6 +602,28 @@ __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group(Dev d, double baseMVA, 
     __shared__ double term[BUS_BLOCK / BUS_W][NTERM][BUS_W];
     __shared__ int kinds[BUS_BLOCK / BUS_W][BUS_W];
     __shared__ double res[BUS_BLOCK / BUS_W][4];
+    if (red != nullptr && blockIdx.x == gridDim.x - 1) {   // the reduction block (whole block takes this path)
+        if (red->done || !red->pending) return;
+        double s4[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int bq = threadIdx.x; bq < d.npartials_br; bq += BUS_BLOCK) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) s4[j] += d.partials_br[bq * 4 + j];
+        }
+        block_reduce4(s4);
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                red->sums[j] = s4[j];
+                red->res[j] = sqrt(s4[j]);
+            }
+            const int inner = red->inner + 1;
+            red->inner = inner;
+            red->pending = 0;
+            const bool test = (red->check_every <= 1) || (inner % red->check_every == 0);
+            if ((test && red->res[0] <= red->eps_pri) || inner >= red->max_inner) red->done = 1;
+        }
+        return;
+    }
     if (loop_done(ctrl)) return;
     const int grp = threadIdx.x / BUS_W, lane = threadIdx.x % BUS_W;
     const int I = blockIdx.x * (BUS_BLOCK / BUS_W) + grp;

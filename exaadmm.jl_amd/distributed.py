@@ -245,6 +245,10 @@ class HipBackend:
         pkg, lib, h, p = self.pkg, self.lib, self.mod.handle, self.part
         world, rank = dist.get_world_size(), dist.get_rank()
         ident = [None]
+        if world == 1 and os.environ.get("EXAADMM_DIST_ONE_RANK_COMM"):   # tests: a real one-rank communicator
+            buf = C.create_string_buffer(128)
+            pkg._check(lib.exaadmm_dist_unique_id(buf, 128), "exaadmm_dist_unique_id")
+            ident[0] = buf.raw
         if world > 1:
             if rank == 0:
                 buf = C.create_string_buffer(128)

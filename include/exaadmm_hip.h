@@ -101,6 +101,7 @@ typedef enum {
 
 const char *exaadmm_version(void);
 const char *exaadmm_last_error(void);
+int exaadmm_device_count(void); /* visible HIP devices (0 = none); starts the library's HIP runtime */
 const char *exaadmm_io_error(void); /* message of the last failed exaadmm_load_matpower */
 void exaadmm_default_params(exaadmm_params *p);
 
@@ -218,6 +219,10 @@ int exaadmm_dist_unique_id(void *out128, int64_t nbytes);
 int exaadmm_dist_attach(exaadmm_handle *h, int nranks, int rank, const void *unique_id, int64_t id_bytes,
                         int64_t nvar_global, const int64_t *counts);
 int exaadmm_dist_detach(exaadmm_handle *h);
+/* all-reduce + grouped send/receive of n doubles round the ranks on the handle's stream (one rank: to itself);
+ * max_err = deviation from the expected values.  Checks that RCCL and the library share one HIP runtime. */
+int exaadmm_dist_selftest(exaadmm_handle *h, int64_t n, double *max_err);
+const char *exaadmm_dist_rccl_path(void); /* the RCCL the library bound (next to its own HIP runtime), "" before */
 /* inner while-loop of admm_two_level.jl:34-63 over all partitions: eps_pri from the GLOBAL nvar, identical
  * break decision on every rank (all ranks see the same all-reduced sums) */
 int exaadmm_dist_run_inner(exaadmm_handle *h, int outer, int max_inner, double beta, int *inner_done, double out[4]);

@@ -593,6 +593,22 @@ def test_native_distributed_loop_at_one_rank_matches_fused_solve(pkg, syn):
     for name in ("u_curr", "v_curr", "z_curr"):
         a, b = be.download(name), getattr(mod.solution, name)
         assert np.abs(a - b).max() <= 1e-10 * max(1.0, np.abs(b).max()), name
+    # the same loop through a REAL (one-rank) RCCL communicator: all-reduce of the residual sums on the handle's
+    # stream, plus the self test that sends / receives through a group -- proves RCCL and the library share a runtime
+    os.environ["EXAADMM_DIST_ONE_RANK_COMM"] = "1"
+    try:
+        be1 = dm.HipBackend(pkg, part, rho[0], rho[1], device_index=0)
+        m1 = dm.DistributedAcopf(part, be1, _OneRank, st, par)
+        be1.attach_native(_OneRank)
+    finally:
+        del os.environ["EXAADMM_DIST_ONE_RANK_COMM"]
+    assert b"rccl" in pkg.library().exaadmm_dist_rccl_path()
+    import ctypes as C
+    err = C.c_double(1.0)
+    pkg._check(pkg.library().exaadmm_dist_selftest(be1.mod.handle, 4096, C.byref(err)), "exaadmm_dist_selftest")
+    assert err.value == 0.0
+    info1 = m1.solve()
+    assert (info1["outer"], info1["cumul"]) == (info["outer"], info["cumul"]) and info1["mismatch"] == info["mismatch"]
     # fixed-count mode (benchmark path) advances the same trajectory as the single-GPU fixed-count loop
     be2 = dm.HipBackend(pkg, part, rho[0], rho[1], device_index=0)
     for name in ("v_curr", "rho"):

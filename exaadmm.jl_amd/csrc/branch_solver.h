@@ -35,6 +35,30 @@ struct BranchData {
     EXA_HD double rho(int k) const { return rho_[k]; }
     EXA_HD double xt(int k) const { return xt_[k]; }
     EXA_HD double Y(int k) const { return Y_[k]; }
+    EXA_HD void fence() const {}
+};
+
+// The same 32 constants left where they already are -- the planes of l, rho, v, z and Y in global memory (L2 / Infinity
+// Cache resident between the evaluations of one solve) -- and fetched again by every objective / derivative evaluation.
+// Costs no registers outside the evaluations: the throughput variant of the branch kernel (k_branch_tp, two waves per
+// SIMD) uses it.  fence() is a compiler-level barrier at the start of an evaluation: without it the loads are
+// loop-invariant and would be hoisted back into registers for the whole solve.
+struct BranchDataGlobal {
+    // plane 0 of the branch part of each array: UNIFORM pointers (scalar registers; plane k is Lp further), and the
+    // lane's branch index as the only per-lane address register (global_load with scalar base + 32-bit lane offset)
+    const double *pl, *prho, *pv, *pz, *pY;
+    int Lp;
+    unsigned b;
+    double ls1, ls2, mu, scale;
+    EXA_HD double lam(int k) const { return (pl + k * Lp)[b]; }
+    EXA_HD double rho(int k) const { return (prho + k * Lp)[b]; }
+    EXA_HD double xt(int k) const { return (pv + k * Lp)[b] - (pz + k * Lp)[b]; }
+    EXA_HD double Y(int k) const { return (pY + k * Lp)[b]; }
+#if defined(__HIP_DEVICE_COMPILE__)
+    EXA_HD void fence() const { asm volatile("" ::: "memory"); }
+#else
+    EXA_HD void fence() const {}
+#endif
 };
 
 template <int STRIDE>
@@ -45,6 +69,7 @@ struct BranchDataRef {
     EXA_HD double rho(int k) const { return p[(8 + k) * STRIDE]; }
     EXA_HD double xt(int k) const { return p[(16 + k) * STRIDE]; }
     EXA_HD double Y(int k) const { return p[(24 + k) * STRIDE]; }
+    EXA_HD void fence() const {}
 };
 
 // Run-time parameters of the augmented-Lagrangian loop, and the TRON driver constants.  The driver
@@ -131,6 +156,7 @@ EXA_HD void flows_from_trig(const D& d, const FlowTrig& t, double (&phi)[4])
 template <class D>
 EXA_HD void branch_flows(const D& d, const double (&x)[6], double (&phi)[4], double (&sc)[2])
 {
+    d.fence();
     FlowTrig t;
     angle_sincos(x, sc[0], sc[1]);
     flow_trig(d, x, sc[0], sc[1], t);
@@ -162,6 +188,7 @@ EXA_HD double objective_from_flows(const D& d, const double (&x)[6], const FlowT
 template <class D>
 EXA_BIG double branch_f(const D& d, const double (&x)[6], double (&phi)[4], double (&sc)[2])
 {
+    d.fence();
     FlowTrig t;
     angle_sincos(x, sc[0], sc[1]);
     flow_trig(d, x, sc[0], sc[1], t);
@@ -174,6 +201,7 @@ EXA_BIG double branch_f(const D& d, const double (&x)[6], double (&phi)[4], doub
 template <class D>
 EXA_HD double branch_f_known(const D& d, const double (&x)[6], const double (&phi)[4], const double (&sc)[2])
 {
+    d.fence();
     FlowTrig t;
     flow_trig(d, x, sc[0], sc[1], t);
     return objective_from_flows(d, x, t, phi);
@@ -284,6 +312,7 @@ template <class D>
 EXA_BIG void branch_g(const D& d, const double (&x)[6], const double (&phi)[4], const double (&scs)[2],
                       double (&g)[6], GradParts& q)
 {
+    d.fence();
 #if defined(EXA_EXACT_ORACLE_ARITH)
     (void)phi;
     (void)scs;
@@ -490,12 +519,9 @@ EXA_HD void branch_solve(D& d, const BranchOptions& o, const MuPowTable& pw, dou
                 st.nfev = 1;
                 st.minor_iter = 1;
                 restart = false;
-            } else {
-                // task GH then NEWX  (tron_linelimit_kernel.jl:86-135)
-                st.minor_iter++;
-                if (gpnorm<6>(x, xl, xu, g) <= o.gtol) fin = TRON_CONV;
-                if (st.minor_iter >= o.max_minor) fin = TRON_MAXMINOR;
             }
+            // (task GH of a continuing solve: its NEWX test was already made, with the same g, at the end of the tick
+            //  that accepted the point -- see below; this refresh adds the Hessian)
             need_gh = false;
         }
         unsigned long long t1 = EXA_TICK();
@@ -528,10 +554,23 @@ EXA_HD void branch_solve(D& d, const BranchOptions& o, const MuPowTable& pw, dou
             } else {
                 int task;
                 moved = tron_evaluate<6>(st, ftrial, x, g, o.frtol, o.fatol, o.fmin, task);
-                if (task != TRON_RUN)
+                if (task != TRON_RUN) {
                     fin = task;
-                else
-                    need_gh = moved;
+                } else if (moved) {
+                    // task GH then NEWX (tron_linelimit_kernel.jl:86-135), made HERE instead of in a tick of its own:
+                    // the gradient at the accepted point from the flows / sin / cos its objective evaluation has just
+                    // produced (same operations on the same inputs as the evaluation at the top of the loop, hence
+                    // the same bits), then the projected-gradient test.  Nine solves in ten end on this test; they
+                    // used to spend a whole extra trip on it -- gradient AND Hessian, 4.7 k clocks -- and every
+                    // augmented-Lagrangian iteration of a straggler did too.  Only a solve that goes on pays for the
+                    // gradient twice (the next trip assembles g and H together).
+                    GradParts gq;
+                    branch_g(d, x, phit, scst, g, gq);
+                    st.minor_iter++;
+                    if (gpnorm<6>(x, xl, xu, g) <= o.gtol) fin = TRON_CONV;
+                    if (st.minor_iter >= o.max_minor) fin = TRON_MAXMINOR;
+                    need_gh = (fin == TRON_RUN);
+                }
             }
             if (moved) {
                 EXA_UNROLL

@@ -111,6 +111,10 @@ struct exaadmm_handle {
     // fused z/l variant (kernels.h, k_branch_t<MP, true>): alternate v, per-block partial sums of the branch launch
     bool zl_on = false;
     double *v_alt = nullptr, *partials_br = nullptr;
+    // branch launches with at least this many wavefronts use k_branch_tp (two waves per SIMD).  0 = never, the default:
+    // the variant measures 3-4.6x SLOWER (profiles/r02_two_waves_per_simd_experiments.txt); EXAADMM_TP_MIN_BLOCKS=1025
+    // reproduces the measurement
+    int tp_min_blocks = 0;
     Dev dspec[2];
     Dev* d_dspec[2] = {nullptr, nullptr};
     int* h_base = nullptr;
@@ -389,6 +393,7 @@ extern "C" int exaadmm_create(const exaadmm_grid* g, const exaadmm_params* p, in
         h->bus_lane_kernel = (e != nullptr && strcmp(e, "lane") == 0);
         h->use_graph = (getenv("EXAADMM_NO_GRAPH") == nullptr);
         h->spec_on = (getenv("EXAADMM_NO_SPEC") == nullptr);   // speculative branch launch (A/B switch)
+        if (const char* e = getenv("EXAADMM_TP_MIN_BLOCKS")) h->tp_min_blocks = atoi(e);   // 0 = never
 #if defined(EXA_HAVE_ZL)
         // z/l pass fused into the branch launch's prologue (A/B switch; needs the lane-group bus kernel, which carries
         // the reduction block)
@@ -947,6 +952,13 @@ static void launch_mp_elem(exaadmm_handle* h, double beta, const Ctrl* c)
     hipLaunchKernelGGL((k_mp_elem<MODE>), dim3(h->mp_nbx, h->T, MP_PLANES), dim3(EW_BLOCK), 0, h->stream, h->d, beta,
                        h->par.MAX_MULTIPLIER, c);
 }
+// throughput variant of the branch kernel (kernels.h, k_branch_tp): single-period model, identity lane order, and a
+// launch with more wavefronts than the chip has SIMDs
+static bool use_tp(const exaadmm_handle* h)
+{
+    return h->T == 1 && h->d.lane_order == nullptr && h->tp_min_blocks > 0 && (int)((h->d.La + BR_BLOCK - 1) / BR_BLOCK) >= h->tp_min_blocks;
+}
+
 static void launch_branch(exaadmm_handle* h, int major_iter, const Ctrl* c, bool with_generators = false)
 {
     if (h->dev_dirty) {  // rare: after create / set_active / set_owned_mask / lane order
@@ -957,6 +969,8 @@ static void launch_branch(exaadmm_handle* h, int major_iter, const Ctrl* c, bool
     const int ng = (with_generators && h->G > 0) ? (int)grid_for(h->G, BR_BLOCK).x : 0;
     if (h->T > 1)
         hipLaunchKernelGGL((k_branch_t<true>), dim3(nb + ng), dim3(BR_BLOCK), 0, h->stream, h->d_dev, h->bo, h->par.scale, major_iter, const_cast<Ctrl*>(c), ng, h->baseMVA, -1);
+    else if (use_tp(h))
+        hipLaunchKernelGGL(k_branch_tp, dim3(nb + ng), dim3(BR_BLOCK), 0, h->stream, h->d_dev, h->bo, h->par.scale, major_iter, const_cast<Ctrl*>(c), ng, h->baseMVA, -1);
     else
         hipLaunchKernelGGL((k_branch_t<false>), dim3(nb + ng), dim3(BR_BLOCK), 0, h->stream, h->d_dev, h->bo, h->par.scale, major_iter, const_cast<Ctrl*>(c), ng, h->baseMVA, -1);
 }
@@ -1197,6 +1211,8 @@ extern "C" int exaadmm_branch_kernel_occupancy(exaadmm_handle* h, int* waves_per
     int blocks = 0;
     if (h->T > 1)
         HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_branch_t<true>, BR_BLOCK, 0));
+    else if (use_tp(h))
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_branch_tp, BR_BLOCK, 0));
     else
         HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_branch_t<false>, BR_BLOCK, 0));
     *waves_per_simd = blocks / 4;
@@ -1301,7 +1317,7 @@ static int spec_prepare(exaadmm_handle* h)
     // (only while the branch launch is latency-bound: with more than ~2 waves queued per SIMD the prologue's memory
     //  latency, at one resident wave per SIMD, costs more than the streaming kernel it replaces -- measured at 1M
     //  branches: k_branch 0.43 -> 0.61 ms against 0.10 ms for k_fused_zl; +3 % at 20 467 and 88 207 branches)
-    if (h->zl_on && h->d.lane_order == nullptr && grid_for(h->d.La, BR_BLOCK).x <= 2048) {
+    if (h->zl_on && h->d.lane_order == nullptr && grid_for(h->d.La, BR_BLOCK).x <= 2048 && !use_tp(h)) {
         // v follows the same parity as u: the bus launch of an odd iteration writes the alternate v, which the next
         // (even) iteration's branch launch reads
         a.v_in = h->d.v;   a.v = h->v_alt;
@@ -1344,8 +1360,11 @@ static void enqueue_iteration_spec(exaadmm_handle* h, Ctrl* c, int j, bool sampl
         return;
     }
 #endif
-    hipLaunchKernelGGL((k_branch_t<false>), dim3(nb + ng + 1), dim3(BR_BLOCK), 0, h->stream, h->d_dspec[par], h->bo, h->par.scale, 0, c,
-                       ng, h->baseMVA, j);
+    if (use_tp(h))
+        hipLaunchKernelGGL(k_branch_tp, dim3(nb + ng + 1), dim3(BR_BLOCK), 0, h->stream, h->d_dspec[par], h->bo, h->par.scale, 0, c, ng, h->baseMVA, j);
+    else
+        hipLaunchKernelGGL((k_branch_t<false>), dim3(nb + ng + 1), dim3(BR_BLOCK), 0, h->stream, h->d_dspec[par], h->bo, h->par.scale, 0, c,
+                           ng, h->baseMVA, j);
     if (bev) (void)hipEventRecord(bev[1], h->stream);
     if (sample) (void)hipEventRecord(h->tev[1], h->stream);
     if (h->bus_lane_kernel)

@@ -87,12 +87,8 @@ EXA_HD void genramp_solve(GenRampData& d, const BranchOptions& o, const MuPowTab
                 st.nfev = 1;
                 st.minor_iter = 1;
                 restart = false;
-            } else {
-                st.minor_iter++;
-                if (gpnorm<3>(x, xl, xu, g) <= o.gtol) fin = TRON_CONV;
-                if (st.minor_iter >= o.max_minor) fin = TRON_MAXMINOR;
             }
-            need_gh = false;
+            need_gh = false;   // (a continuing solve made its NEWX test in the tick that accepted the point, see below)
         }
         if (fin == TRON_RUN) {
             tron_compute<3>(st, x, xl, xu, A, L, g, o.cgtol, 3);
@@ -108,10 +104,17 @@ EXA_HD void genramp_solve(GenRampData& d, const BranchOptions& o, const MuPowTab
             } else {
                 int task;
                 const bool moved = tron_evaluate<3>(st, ftrial, x, g, o.frtol, o.fatol, o.fmin, task);
-                if (task != TRON_RUN)
+                if (task != TRON_RUN) {
                     fin = task;
-                else
-                    need_gh = moved;
+                } else if (moved) {
+                    // NEWX test in the accepting tick (as in branch_solve): gradient at the accepted point, same bits as
+                    // the evaluation at the top of the loop; a solve that ends here saves a whole trip
+                    genramp_g(d, x, g);
+                    st.minor_iter++;
+                    if (gpnorm<3>(x, xl, xu, g) <= o.gtol) fin = TRON_CONV;
+                    if (st.minor_iter >= o.max_minor) fin = TRON_MAXMINOR;
+                    need_gh = (fin == TRON_RUN);
+                }
             }
         }
         if (fin != TRON_RUN) {

@@ -422,6 +422,115 @@ __global__ void __launch_bounds__(BR_BLOCK, EXA_BR_WAVES) k_branch_t(const Dev* 
 #endif
 }
 
+// ---------------------------------------------------------------- branch, throughput variant
+// Same solver, same arithmetic, laid out for TWO resident waves per SIMD (<= 256 VGPR + AGPR): used when the launch has
+// more wavefronts than the chip has SIMDs (1024), i.e. when waves queue behind each other and a second resident wave
+// fills the issue slots a single FP64 dependency chain leaves empty (one wave alone issues a VALU instruction every
+// ~8 cycles, PMC: VALU busy 0.54 at 1M branches).  What leaves the register file:
+//   * Hessian and Cholesky factor live in LDS as [entry][lane] planes (2 x 21 doubles x 64 lanes = 21.5 KB per wave,
+//     conflict-free, 7 waves per CU);
+//   * the 32 read-only problem constants are not held at all: every objective / derivative evaluation fetches them
+//     again from the planes of l, rho, v, z, Y (BranchDataGlobal) -- cache-resident, and the other wave computes meanwhile.
+// Single-period model; the generator blocks and the speculative reduction block are those of k_branch_t.
+// MEASURED AND REJECTED (round 2; off unless EXAADMM_TP_MIN_BLOCKS is set): with A, L and the constants out of the
+// register file the compiler still needs 256 VGPRs + 1292 B of scratch per lane (372 spilled registers: the peak is
+// the Hessian assembly -- 43 gradient intermediates + the 32 constants being consumed + the solver's persistent vectors),
+// and the scratch traffic makes the launch 3.2x (88 207 branches) to 4.6x (1M branches) slower than one wave per SIMD.
+// The plain register cap without LDS (-DEXA_BR_WAVES=2: 760 B scratch) is 2.3x slower, with the constants in LDS 1.8x.
+constexpr int TP_LDS_DOUBLES = 2 * 21;
+__global__ void __launch_bounds__(BR_BLOCK, 2) k_branch_tp(const Dev* __restrict__ dp, BranchOptions o, double scale, int major_iter, Ctrl* ctrl,
+                                                           int gen_blocks, double baseMVA, int spec_j)
+{
+    __shared__ double lds[TP_LDS_DOUBLES * BR_BLOCK];
+    const Dev& d = *dp;
+    int extra = 0;
+    if (spec_j >= 0) {
+        extra = 1;
+        if ((int)blockIdx.x == (int)gridDim.x - 1) {   // the reduction block (see k_branch_t)
+            if (ctrl->done || !ctrl->pending) return;
+            double s4[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int bq = threadIdx.x; bq < d.npartials; bq += BR_BLOCK) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) s4[j] += d.partials[bq * 4 + j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) s4[j] += __shfl_down(s4[j], off, 64);
+            }
+            if (threadIdx.x == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    ctrl->sums[j] = s4[j];
+                    ctrl->res[j] = sqrt(s4[j]);
+                }
+                const int inner = ctrl->inner + 1;
+                ctrl->inner = inner;
+                ctrl->pending = 0;
+                const bool test = (ctrl->check_every <= 1) || (inner % ctrl->check_every == 0);
+                if ((test && ctrl->res[0] <= ctrl->eps_pri) || inner >= ctrl->max_inner) ctrl->done = 1;
+            }
+            return;
+        }
+        if (ctrl->done) return;
+        major_iter = ctrl->base + spec_j + 1;
+    } else if (ctrl != nullptr) {
+        if (ctrl->done) return;
+        major_iter = ctrl->inner + 1;
+    }
+    const int nbr_blocks = gridDim.x - gen_blocks - extra;
+    if ((int)blockIdx.x >= nbr_blocks) {
+        generator_update(d, baseMVA, ((int)blockIdx.x - nbr_blocks) * BR_BLOCK + threadIdx.x);
+        return;
+    }
+    const int b = blockIdx.x * BR_BLOCK + threadIdx.x;
+    if (b >= d.La) return;
+    const int Lp = d.Lp;
+    const int base = 2 * d.Gp + b;
+    const double* const uin = d.u_in ? d.u_in : d.u;
+    double x[6], xl[6], xu[6], phi[4];
+    {
+        double ub[8], bnd[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            ub[k] = uin[base + k * Lp];
+            bnd[k] = d.bnd[b + k * Lp];
+        }
+        branch_start(ub, bnd, d.rateA[b], x, xl, xu);
+    }
+    BranchDataGlobal bd;
+    bd.pl = d.l + 2 * d.Gp;
+    bd.prho = d.rho + 2 * d.Gp;
+    bd.pv = d.v + 2 * d.Gp;
+    bd.pz = d.z + 2 * d.Gp;
+    bd.pY = d.Y;
+    bd.Lp = Lp;
+    bd.b = (unsigned)b;
+    bd.ls1 = (d.ls1_in ? d.ls1_in : d.ls1)[b];
+    bd.ls2 = (d.ls2_in ? d.ls2_in : d.ls2)[b];
+    bd.mu = (major_iter == 1) ? 10.0 : (d.mu_in ? d.mu_in : d.mu)[b];
+    bd.scale = scale;
+    SymRef<6, BR_BLOCK> A{lds + threadIdx.x};
+    SymRef<6, BR_BLOCK> L{lds + 21 * BR_BLOCK + threadIdx.x};
+    BranchStats st;
+    st.tl = nullptr;
+    branch_solve(bd, o, c_mupow, x, xl, xu, A, L, phi, st);
+    d.u[base] = phi[0];
+    d.u[base + Lp] = phi[1];
+    d.u[base + 2 * Lp] = phi[2];
+    d.u[base + 3 * Lp] = phi[3];
+    d.u[base + 4 * Lp] = x[0] * x[0];
+    d.u[base + 5 * Lp] = x[1] * x[1];
+    d.u[base + 6 * Lp] = x[2];
+    d.u[base + 7 * Lp] = x[3];
+    d.ls1[b] = bd.ls1;
+    d.ls2[b] = bd.ls2;
+    d.mu[b] = bd.mu;
+    d.st_auglag[b] = st.auglag_it;
+    d.st_minor[b] = st.minor_it;
+    d.st_ticks[b] = st.ticks;
+}
+
 // Multi-period model: the real power of a generator of period t < T-1 is also tied to the copy
 // phat kept by period t+1 (ramp block index pg + g1); the last period has no such partner.
 __device__ __forceinline__ bool bus_gen_has_ramp(const Dev& d, int pg) { return d.T > 1 && pg < (d.T - 1) * d.g1; }

@@ -171,11 +171,10 @@ EXA_HD void gpstep(const double (&x)[N], const double (&xl)[N], const double (&x
     }
 }
 
-// q(s) = 1/2 s'As + g's and g's
+// q(s) = 1/2 s'As + g's and g's; wa receives A s
 template <int N, class MA>
-EXA_HD void quad_model(const MA& A, const double (&g)[N], const double (&s)[N], double& q, double& gts)
+EXA_HD void quad_model(const MA& A, const double (&g)[N], const double (&s)[N], double& q, double& gts, double (&wa)[N])
 {
-    double wa[N];
     symv<N>(A, s, wa);
     gts = dot<N>(g, s);
     q = EXA_FMA(0.5, dot<N>(s, wa), gts);
@@ -185,19 +184,22 @@ EXA_HD void quad_model(const MA& A, const double (&g)[N], const double (&s)[N], 
 // The break points are only needed by the extrapolation branch and are computed there.  (||s|| must be
 // compared with delta as a norm, not as squares: delta is often exactly the norm of the previous step,
 // so ties are structural and a squared comparison flips them.)
+// as: A s of the RETURNED step when the last model evaluation of the search was made at exactly that step (the
+// interpolation branch ends that way), as_valid says so: dspcg starts with the same product and need not repeat it.
 template <int N, class MA>
 EXA_BIG void cauchy(const double (&x)[N], const double (&xl)[N], const double (&xu)[N], const MA& A,
-                   const double (&g)[N], double delta, double& alpha, double (&s)[N])
+                   const double (&g)[N], double delta, double& alpha, double (&s)[N], double (&as)[N], bool& as_valid)
 {
     const double mu0 = 0.01, interpf = 0.1, extrapf = 10.0;
 
     bool interp;
+    as_valid = false;
     gpstep<N>(x, xl, xu, -alpha, g, s);
     if (nrm2<N>(s) > delta) {
         interp = true;
     } else {
         double q, gts;
-        quad_model<N>(A, g, s, q, gts);
+        quad_model<N>(A, g, s, q, gts, as);
         interp = (q >= mu0 * gts);
     }
 
@@ -207,9 +209,11 @@ EXA_BIG void cauchy(const double (&x)[N], const double (&xl)[N], const double (&
         for (int guard = 0; search && guard < 400; guard++) {
             alpha = interpf * alpha;
             gpstep<N>(x, xl, xu, -alpha, g, s);
+            as_valid = false;
             if (nrm2<N>(s) <= delta) {
                 double q, gts;
-                quad_model<N>(A, g, s, q, gts);
+                quad_model<N>(A, g, s, q, gts, as);
+                as_valid = true;
                 search = (q > mu0 * gts);
             }
         }
@@ -226,7 +230,7 @@ EXA_BIG void cauchy(const double (&x)[N], const double (&xl)[N], const double (&
             gpstep<N>(x, xl, xu, -alpha, g, s);
             if (nrm2<N>(s) <= delta) {
                 double q, gts;
-                quad_model<N>(A, g, s, q, gts);
+                quad_model<N>(A, g, s, q, gts, as);
                 if (q < mu0 * gts) alphas = alpha;
             } else {
                 search = false;
@@ -568,13 +572,15 @@ EXA_BIG void prsrch_masked(unsigned fr, double (&x)[N], const double (&xl)[N], c
 
 // Subspace-projected CG from the Cauchy point (TRON dspcg).  On entry s = Cauchy step;
 // on exit x is the trial point and s = x - x0.
+// w: on entry A s of the Cauchy step if w_valid (else it is computed here); on exit A s of the final step -- every
+// return path leaves it current -- which dtron's predicted reduction needs next.
 template <int N, class MA, class ML>
 EXA_BIG void spcg(double (&x)[N], const double (&xl)[N], const double (&xu)[N], const MA& A, ML& L,
-                 const double (&g)[N], double delta, double rtol, double (&s)[N], int itermax,
+                 const double (&g)[N], double delta, double rtol, double (&s)[N], int itermax, double (&w)[N], bool w_valid,
                  unsigned long long* pc = nullptr)  // pc: diagnostic cycle counters (icfs, trpcg, prsrch, faces, cg its)
 {
-    double w[N], gf[N], id[N];
-    symv<N>(A, s, w);
+    double gf[N], id[N];
+    if (!w_valid) symv<N>(A, s, w);
     EXA_UNROLL
     for (int i = 0; i < N; i++) {
         double xi = x[i] + s[i];
@@ -643,7 +649,7 @@ EXA_BIG void spcg(double (&x)[N], const double (&xl)[N], const double (&xu)[N], 
 // Per-lane state of one trust-region Newton solve (isave/dsave of dtron + driver counters).
 template <int N>
 struct TronState {
-    double f, fc, delta, alphac, prered;
+    double f, fc, delta, alphac, prered, gts;   // gts = g's of the last model step (the ratio test needs it again)
     double xc[N], s[N];
     int iter, minor_iter, nfev;
 #if defined(EXA_PROFILE_PHASES)
@@ -659,20 +665,21 @@ EXA_HD void tron_compute(TronState<N>& st, double (&x)[N], const double (&xl)[N]
     st.fc = st.f;
     EXA_UNROLL
     for (int i = 0; i < N; i++) st.xc[i] = x[i];
+    double wa[N];   // A s: from the Cauchy search into dspcg, from dspcg into the predicted reduction (same products,
+    bool wa_valid;  // same bits as recomputing them: two of a model step's ~ten matrix-vector products less)
 #if defined(EXA_PROFILE_PHASES)
     unsigned long long c0 = EXA_CLK();
-    cauchy<N>(x, xl, xu, A, g, st.delta, st.alphac, st.s);
+    cauchy<N>(x, xl, xu, A, g, st.delta, st.alphac, st.s, wa, wa_valid);
     unsigned long long c1 = EXA_CLK();
-    spcg<N>(x, xl, xu, A, L, g, st.delta, cgtol, st.s, cg_itermax, st.pc);
+    spcg<N>(x, xl, xu, A, L, g, st.delta, cgtol, st.s, cg_itermax, wa, wa_valid, st.pc);
     st.pc[5] += c1 - c0;
     st.pc[6] += EXA_CLK() - c1;
 #else
-    cauchy<N>(x, xl, xu, A, g, st.delta, st.alphac, st.s);
-    spcg<N>(x, xl, xu, A, L, g, st.delta, cgtol, st.s, cg_itermax);
+    cauchy<N>(x, xl, xu, A, g, st.delta, st.alphac, st.s, wa, wa_valid);
+    spcg<N>(x, xl, xu, A, L, g, st.delta, cgtol, st.s, cg_itermax, wa, wa_valid);
 #endif
-    double wa[N];
-    symv<N>(A, st.s, wa);
-    st.prered = -(dot<N>(st.s, g) + 0.5 * dot<N>(st.s, wa));
+    st.gts = dot<N>(st.s, g);
+    st.prered = -(st.gts + 0.5 * dot<N>(st.s, wa));
 }
 
 // dtron, work = EVALUATE: ratio test with ftrial = f(x).  Returns true when the step is
@@ -691,7 +698,7 @@ EXA_HD bool tron_evaluate(TronState<N>& st, double ftrial, double (&x)[N], const
     const double snorm = nrm2<N>(st.s);
     if (st.iter == 1) delta = fmin(delta, snorm);
 
-    const double g0 = dot<N>(g, st.s);
+    const double g0 = st.gts;   // = dot(g, s): the products commute, the sum runs in the same order
     double alpha;
     if (f - fc - g0 <= 0.0)
         alpha = sigma3;

@@ -1,0 +1,14 @@
+O=gpurun_out/r02_b7
+mkdir -p $O
+timeout 1500 python -m pytest tests -m gpu -q -x > $O/pytest.log 2>&1; tail -4 $O/pytest.log
+python bench.py > $O/bench_default.log 2>&1
+for c in case_ACTIVSg70k synthetic1M case1354pegase; do
+  python bench.py --case $c --steps 100 --warmup 20 --no-cpu-baseline > $O/bench_$c.log 2>&1
+done
+python bench.py --periods 4 --steps 100 --warmup 20 --no-cpu-baseline > $O/bench_mp4.log 2>&1
+for f in $O/bench_*.log; do echo "$f: $(python -c "
+import json
+for l in open('$f'):
+    if l.startswith('{'):
+        d=json.loads(l); fs=d.get('full_solve',{}); print('%.1f it/s  k_branch %.4f ms | full solve %s' % (d['value'], d['roofline']['kernel_ms'], (fs.get('status'), fs.get('outer'), fs.get('cumul'), fs.get('iterations_per_s'))))
+")"; done

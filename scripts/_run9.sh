@@ -1,0 +1,13 @@
+O=gpurun_out/r02_b9
+mkdir -p $O
+timeout 1500 python -m pytest tests -m gpu -q -x > $O/pytest.log 2>&1; grep -E "passed|failed" $O/pytest.log | tail -1
+python bench.py > $O/bench_default.log 2>&1
+for c in case_ACTIVSg70k synthetic1M; do
+  python bench.py --case $c --steps 100 --warmup 20 --no-cpu-baseline > $O/bench_$c.log 2>&1
+done
+for f in $O/bench_*.log; do echo "$f: $(python -c "
+import json
+for l in open('$f'):
+    if l.startswith('{'):
+        d=json.loads(l); fs=d.get('full_solve',{}); print('%.1f it/s  k_branch %.4f ms | full solve %s' % (d['value'], d['roofline']['kernel_ms'], (fs.get('status'), fs.get('outer'), fs.get('cumul'), fs.get('iterations_per_s'))))
+")"; done

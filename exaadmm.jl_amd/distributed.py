@@ -252,9 +252,14 @@ class HipBackend:
         if world > 1:
             if rank == 0:
                 buf = C.create_string_buffer(128)
-                pkg._check(lib.exaadmm_dist_unique_id(buf, 128), "exaadmm_dist_unique_id")
-                ident[0] = buf.raw
+                try:
+                    pkg._check(lib.exaadmm_dist_unique_id(buf, 128), "exaadmm_dist_unique_id")
+                    ident[0] = buf.raw
+                except pkg.ExaAdmmError as e:      # no usable RCCL next to the HIP runtime: every rank falls back together
+                    sys.stderr.write("exaadmm: library-side RCCL unavailable (%s); using the Python-driven loop\n" % e)
             dist.broadcast_object_list(ident, src=0)
+            if ident[0] is None:
+                return False
         counts = np.asarray([p.plan_send_uzl[2], p.plan_recv_uzl[2], p.plan_send_v[2], p.plan_recv_v[2]], dtype=np.int64)
         assert counts.shape == (4, world)
         self.torch.cuda.synchronize(self.dev)
@@ -263,6 +268,7 @@ class HipBackend:
         pkg._check(lib.exaadmm_dist_attach(h, world, rank, ident[0], 128 if ident[0] else 0, p.nvar_global,
                                            counts.ctypes.data_as(pkg.c_i64_p)), "exaadmm_dist_attach")
         self.native = True
+        return True
 
     def run_inner_native(self, outer, max_inner, beta):
         done = C.c_int()
@@ -522,7 +528,7 @@ def bench_main(args, rank, world, local_rank):
     model = DistributedAcopf(part, be, dist, st, dict(DEFAULT_PAR))
     native = os.environ.get("EXAADMM_DIST_PYTHON_LOOP") is None
     if native:
-        be.attach_native(dist)
+        native = bool(be.attach_native(dist))
     beta = DEFAULT_PAR["initial_beta"]
 
     def run(n, first):

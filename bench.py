@@ -239,6 +239,12 @@ def main():
         pass
     occ = mod.branch_kernel_occupancy() if hasattr(mod, "branch_kernel_occupancy") else None
     branch_bytes = BYTES_PER_BRANCH_SOLVE * L
+    fused_zl = T == 1 and (L + 63) // 64 <= 2048 and not os.environ.get("EXAADMM_NO_ZLFUSE") and not os.environ.get("EXAADMM_NO_SPEC")
+    if fused_zl:
+        # the launch also carries the generator update (128 B per generator) and the z / l / residual pass of the previous
+        # iteration; of the latter only what the branch loads do not already bring counts: lz read + z, z_prev, l writes
+        # = 32 B per vector element (64 B minimal + 8 B z_prev, minus the 40 B of shared reads)
+        branch_bytes = 824.0 * L + 192.0 * G
     achieved = branch_bytes / (ms_branch * 1e-3) / 1e9
     out = {
         "metric": "ADMM inner iterations/sec", "value": its, "unit": "iterations/s",
@@ -248,7 +254,7 @@ def main():
                    "rho_va": params["rho_va"], "scale": params["scale"], "tight_factor": 0.99,
                    "mode": "fixed-count inner iterations, no early break", "parallelism": "1 GPU",
                    "state": "ADMM state after %d untimed preparation iterations from init_solution! (outer 1, beta %.0f)" % (args.prep, beta)},
-        "roofline": {"bound": "hbm", "kernel": "k_branch", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"bound": "hbm", "kernel": "k_branch" + (" (with the fused z/l prologue)" if fused_zl else ""), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": branch_bytes, "kernel_ms": ms_branch,
                      "kernel_ms_measured_over": "HIP events around each k_branch launch of the %d steps following the timed region" % args.steps,

@@ -171,7 +171,13 @@ def synthetic_grid(ngen, nline, nbus, seed=0, tight_factor=0.99, locality=64, fe
         Qd = qg_bus - needq
         flowS = np.maximum(np.abs(Sf), np.abs(St)) * M
         rate = np.where(unlimited, 0.0, np.maximum(1.5 * flowS, 40.0) * rng.uniform(1.0, 1.5, nline))
+        share = Pmax / np.maximum(cap[gbus], 1e-300)          # the units at a bus share its dispatch in proportion to their size
+        feasible_point = {"Vm": Vm, "Va": theta, "pg": pg_bus[gbus] * share / M, "qg": qg_bus[gbus] * share / M}
+    else:
+        feasible_point = None
     g = {"ngen": ngen, "nline": nline, "nbus": nbus, "baseMVA": M, "bus_ref": 0}
+    if feasible_point is not None:
+        g["feasible_point"] = feasible_point   # (tests: the operating point the instance was built round; not read by any solver)
     g["pgmin"] = np.zeros(ngen)
     g["pgmax"] = Pmax / M
     g["qgmin"] = -0.5 * Pmax / M

@@ -195,3 +195,39 @@ def test_c_driver_builds_as_plain_c_and_fails_loudly_without_gpu(pkg):
     if not torch.cuda.is_available():
         r = subprocess.run([exe, CASE9, "--quiet"], capture_output=True, text=True)
         assert r.returncode == 2 and "no CPU fallback" in r.stderr
+
+
+@pytest.mark.parametrize("case,kw", [("case118", {}), ("case1354pegase", {}), ("case13659pegase", {}), ("case1354pegase", {"cost": "market"})])
+def test_synthetic_instances_have_a_strictly_feasible_operating_point(case, kw):
+    """The benchmark instances (synthetic.py, recipe "acflow", seed 0) are built round an AC operating point; check,
+    with the reference's own equations (branch flows opfdata.jl:428-447 / acopf_eval_linelimit_kernel_cpu.jl:11-16, bus
+    balance acopf_bus_kernel_cpu.jl), that this point satisfies every constraint of the ACOPF with margin: power balance
+    at every bus, voltage / angle / generator boxes, thermal limits.  That is what makes the reference's two-level solve
+    converge on them (round 1's DC-only instance diverged)."""
+    syn = exaadmm_loader.load_submodule("synthetic")
+    g = syn.sized_like(case, seed=0, **kw)
+    fp = g["feasible_point"]
+    Vm, Va, pg, qg = fp["Vm"], fp["Va"], fp["pg"], fp["qg"]
+    L, B, M = g["nline"], g["nbus"], g["baseMVA"]
+    bb = np.asarray(g["brBusIdx"]).reshape(L, 2)
+    fr, to = bb[:, 0], bb[:, 1]
+    vi, vj, th = Vm[fr], Vm[to], Va[fr] - Va[to]
+    cs, sn = np.cos(th), np.sin(th)
+    pij = g["YffR"] * vi ** 2 + g["YftR"] * vi * vj * cs + g["YftI"] * vi * vj * sn
+    qij = -g["YffI"] * vi ** 2 - g["YftI"] * vi * vj * cs + g["YftR"] * vi * vj * sn
+    pji = g["YttR"] * vj ** 2 + g["YtfR"] * vi * vj * cs - g["YtfI"] * vi * vj * sn
+    qji = -g["YttI"] * vj ** 2 - g["YtfI"] * vi * vj * cs - g["YtfR"] * vi * vj * sn
+    gb = np.asarray(g["gen_bus"])
+    pbal = np.bincount(gb, weights=pg, minlength=B) - g["Pd"] / M - np.bincount(fr, weights=pij, minlength=B) \
+        - np.bincount(to, weights=pji, minlength=B) - g["YshR"] * Vm ** 2
+    qbal = np.bincount(gb, weights=qg, minlength=B) - g["Qd"] / M - np.bincount(fr, weights=qij, minlength=B) \
+        - np.bincount(to, weights=qji, minlength=B) + g["YshI"] * Vm ** 2
+    scale = max(1.0, np.abs(pij).max())
+    assert np.abs(pbal).max() <= 1e-9 * scale and np.abs(qbal).max() <= 1e-9 * scale
+    assert (Vm > g["Vmin"] + 0.05).all() and (Vm < g["Vmax"] - 0.05).all()
+    assert np.abs(Va).max() < np.pi                    # angle boxes are +-2 pi; the reference bus sits at 0
+    assert Va[0] == 0.0
+    assert (pg >= g["pgmin"] + 0.05 * g["pgmax"]).all() and (pg <= 0.75 * g["pgmax"]).all()
+    assert (qg >= 0.8 * g["qgmin"]).all() and (qg <= 0.8 * g["qgmax"]).all()
+    lim = np.asarray(g["rateA"])
+    assert ((pij ** 2 + qij ** 2) <= 0.5 * lim).all() and ((pji ** 2 + qji ** 2) <= 0.5 * lim).all()   # flows <= 1/1.5 of the rating

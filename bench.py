@@ -9,11 +9,13 @@ whole grid resident in HBM.  Workload at N=1: BASELINE.json configs[2], case1365
 and ./data; when absent (no network in this environment) a seeded size-matched synthetic grid
 (ngen 4092 / nline 20467 / nbus 13659) is used and the JSON says so.
 
-Benchmark state: the synthetic input includes the ADMM state, defined as the state after PREP (default 100)
+Benchmark state: the synthetic input includes the ADMM state, defined as the state after PREP (default 300)
 untimed inner iterations of outer iteration 1 from the reference's cold start (init_solution!); the W warm-up
-steps and the K timed steps follow.  (The cost of an iteration decays over the first ~80 iterations of a cold start, from 5x to 1x the thousands
-that follow in a solve; without a defined state the figure would depend on W.)  --prep 0 times from the cold
-start.  The CPU baseline is timed from the same state.
+steps and the K timed steps follow.  (The cost of an iteration decays from 0.26 ms over the first 20 iterations of a cold
+start to a flat 0.085 ms from iteration ~300 on -- profiles/r02_iteration_cost_vs_iteration_index_case13659.txt; without
+a defined state on the flat part the figure would depend on W and K.)  --prep 0 times from the cold start.  The CPU
+baseline is timed from the same state.  What a whole solve sees -- mostly the heavy first iterations of every inner
+loop -- is the `full_solve` block.
 
 For N>1 (launched by torch.distributed.run) the grid is N areas of that size joined by tie
 lines, one area per GPU (weak scaling); see exaadmm.jl_amd/distributed.py and DESIGN.md.
@@ -134,7 +136,7 @@ def main():
     ap.add_argument("--no-full-solve", action="store_true",
                     help="skip the whole-solve leg (cumul / time_overall of solve_acopf, outer 20 x inner 1000, early breaks on)")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU code path even with one rank")
-    ap.add_argument("--prep", type=int, default=100,
+    ap.add_argument("--prep", type=int, default=300,
                     help="untimed preparation iterations that define the benchmark state (the ADMM state after PREP inner "
                          "iterations from init_solution!): the first iterations of a cold start are several times heavier "
                          "than the thousands that follow in a solve; 0 = time from the cold start")

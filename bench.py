@@ -135,6 +135,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-solve", action="store_true",
                     help="skip the whole-solve leg (cumul / time_overall of solve_acopf, outer 20 x inner 1000, early breaks on)")
+    ap.add_argument("--cpu-solve-budget", type=float, default=30.0,
+                    help="seconds the CPU port may spend on the whole solve of the full_solve leg (cut off = bounded sample)")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU code path even with one rank")
     ap.add_argument("--prep", type=int, default=300,
                     help="untimed preparation iterations that define the benchmark state (the ADMM state after PREP inner "
@@ -291,7 +293,7 @@ def main():
         fs["definition"] = "cumul / time_overall of solve_acopf(outer_iterlim=20, inner_iterlim=1000), second of two solves"
         out["full_solve"] = fs
         if not args.no_cpu_baseline:
-            cf = cpu_full_solve(grid, params, budget_s=30.0)
+            cf = cpu_full_solve(grid, params, budget_s=args.cpu_solve_budget)
             fs["cpu_port"] = cf
             fs["speedup_vs_cpu_port"] = fs["iterations_per_s"] / cf["iterations_per_s"]
             if cf["finished"]:   # same solve on both sides: the counts and the objective must agree

@@ -80,11 +80,36 @@ VECTORS = {"u_curr": 0, "v_curr": 1, "l_curr": 2, "rho": 3, "rd": 4, "rp": 5, "z
 _LIB = None
 
 
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch wheels for ROCm carry a PRIVATE libamdhip64 / libhsa-runtime64 / librccl
+    (torch/lib); libexaadmm_hip.so is linked against the system one (/opt/rocm/lib).  A process that loads both ends up
+    with two HIP runtimes, and starting the second one fails now and then ("no HIP device visible" / "No HIP GPUs are
+    available", observed in both orders on MI355X boxes).  If PyTorch is installed, its runtime is therefore mapped
+    FIRST and globally, without importing torch: the library's hip* symbols then bind to it, `import torch` later finds
+    it already loaded, and RCCL (dist_native.h) is taken from the same directory.  Hosts without PyTorch (a Julia or
+    plain-C driver) use the system runtime.  EXAADMM_NO_TORCH_RUNTIME=1 disables the preload."""
+    if os.environ.get("EXAADMM_NO_TORCH_RUNTIME"):
+        return None
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return None
+        path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if not os.path.exists(path):
+            return None
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+        return path
+    except Exception:
+        return None
+
+
 def library():
     """Load libexaadmm_hip.so.  Raises if it has not been built: no fallback."""
     global _LIB
     if _LIB is not None:
         return _LIB
+    _preload_torch_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise ExaAdmmError("HIP extension %s is missing; run __graft_entry__.build() "
                            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)

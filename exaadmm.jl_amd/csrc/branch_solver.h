@@ -562,14 +562,16 @@ EXA_HD void branch_solve(D& d, const BranchOptions& o, const MuPowTable& pw, dou
                     // produced (same operations on the same inputs as the evaluation at the top of the loop, hence
                     // the same bits), then the projected-gradient test.  Nine solves in ten end on this test; they
                     // used to spend a whole extra trip on it -- gradient AND Hessian, 4.7 k clocks -- and every
-                    // augmented-Lagrangian iteration of a straggler did too.  Only a solve that goes on pays for the
-                    // gradient twice (the next trip assembles g and H together).
+                    // augmented-Lagrangian iteration of a straggler did too.  A solve that goes on assembles its
+                    // Hessian here as well (below); a solve that ends does not.
                     GradParts gq;
                     branch_g(d, x, phit, scst, g, gq);
                     st.minor_iter++;
                     if (gpnorm<6>(x, xl, xu, g) <= o.gtol) fin = TRON_CONV;
                     if (st.minor_iter >= o.max_minor) fin = TRON_MAXMINOR;
-                    need_gh = (fin == TRON_RUN);
+                    // the solve goes on: its Hessian now, from the same intermediates -- the next trip starts at the model
+                    // step with g and A current (the evaluation at the top of the loop is left to new subproblems)
+                    if (fin == TRON_RUN) branch_h(d, x, gq, A);
                 }
             }
             if (moved) {

@@ -113,7 +113,8 @@ EXA_HD void genramp_solve(GenRampData& d, const BranchOptions& o, const MuPowTab
                     st.minor_iter++;
                     if (gpnorm<3>(x, xl, xu, g) <= o.gtol) fin = TRON_CONV;
                     if (st.minor_iter >= o.max_minor) fin = TRON_MAXMINOR;
-                    need_gh = (fin == TRON_RUN);
+                    // (the Hessian of the ramp subproblem does not depend on x: A stays current, the next trip starts
+                    //  at the model step)
                 }
             }
         }

@@ -203,41 +203,41 @@ EXA_BIG void cauchy(const double (&x)[N], const double (&xl)[N], const double (&
         interp = (q >= mu0 * gts);
     }
 
-    if (interp) {
-        bool search = true;
-        // alpha shrinks 10x per trip; 400 trips take any finite alpha to 0 (guard against NaN spins)
-        for (int guard = 0; search && guard < 400; guard++) {
-            alpha = interpf * alpha;
-            gpstep<N>(x, xl, xu, -alpha, g, s);
-            as_valid = false;
-            if (nrm2<N>(s) <= delta) {
-                double q, gts;
-                quad_model<N>(A, g, s, q, gts, as);
-                as_valid = true;
-                search = (q > mu0 * gts);
-            }
-        }
-    } else {
+    // ONE search loop for both kinds of lanes (a wavefront that holds interpolating and extrapolating lanes used to run
+    // the two loops one after the other): per lane the operations and their order are those of dcauchy's two loops.
+    //   interpolation : alpha shrinks 10x per trip until the step is inside the region with sufficient decrease
+    //   extrapolation : alpha grows 10x per trip while the step stays inside the region (up to the largest break
+    //                   point); the last alpha that gave sufficient decrease is kept
+    double brptmax = 0.0;
+    if (!interp) {
         double mg[N];
         EXA_UNROLL
         for (int i = 0; i < N; i++) mg[i] = -g[i];
-        double brptmin, brptmax;
+        double brptmin;
         breakpt<N>(x, xl, xu, mg, brptmin, brptmax);
-        bool search = true;
-        double alphas = alpha;
-        for (int guard = 0; search && alpha <= brptmax && guard < 400; guard++) {
-            alpha = extrapf * alpha;
-            gpstep<N>(x, xl, xu, -alpha, g, s);
-            if (nrm2<N>(s) <= delta) {
-                double q, gts;
-                quad_model<N>(A, g, s, q, gts, as);
-                if (q < mu0 * gts) alphas = alpha;
-            } else {
-                search = false;
-            }
+    }
+    double alphas = alpha;
+    bool search = true;
+    // 400 trips take any finite alpha to 0 / past every break point (guard against NaN spins)
+    for (int guard = 0; search && (interp || alpha <= brptmax) && guard < 400; guard++) {
+        alpha = (interp ? interpf : extrapf) * alpha;
+        gpstep<N>(x, xl, xu, -alpha, g, s);
+        const bool inside = (nrm2<N>(s) <= delta);
+        double q = 0.0, gts = 0.0;
+        if (inside) quad_model<N>(A, g, s, q, gts, as);
+        if (interp) {
+            as_valid = inside;
+            if (inside) search = (q > mu0 * gts);
+        } else if (inside) {
+            if (q < mu0 * gts) alphas = alpha;
+        } else {
+            search = false;
         }
+    }
+    if (!interp) {
         alpha = alphas;
         gpstep<N>(x, xl, xu, -alpha, g, s);
+        as_valid = false;
     }
 }
 

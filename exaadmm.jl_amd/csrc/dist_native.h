@@ -22,6 +22,7 @@
 #pragma once
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <mutex>
 
 struct exaadmm_dist {
     void* lib = nullptr;
@@ -48,9 +49,12 @@ static std::string g_rccl_path;
 // which RCCL the library bound (empty before the first exaadmm_dist_unique_id / multi-rank exaadmm_dist_attach)
 extern "C" const char* exaadmm_dist_rccl_path(void) { return g_rccl_path.c_str(); }
 
+static std::mutex g_rccl_mutex;   // handles may be attached from different host threads
+
 static int rccl_bind(exaadmm_dist* d)
 {
     if (d->lib) return 0;
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
     if (!g_rccl_binding.lib) {
         std::vector<std::string> names;
         if (const char* e = getenv("EXAADMM_RCCL_LIB")) names.push_back(e);
@@ -145,8 +149,23 @@ extern "C" int exaadmm_dist_detach(exaadmm_handle* h)
 // counts: 4 x nranks, row-major: [send u/z/l per peer | recv u/z/l per peer | send v per peer | recv v per peer],
 // in doubles, the per-peer block order of the halo index lists in slots 0..3 (exaadmm_set_halo_index).
 // nranks == 1 needs no communicator: id may be NULL.
+static int dist_attach_impl(exaadmm_handle* h, int nranks, int rank, const void* unique_id, int64_t id_bytes, int64_t nvar_global,
+                            const int64_t* counts);
+
 extern "C" int exaadmm_dist_attach(exaadmm_handle* h, int nranks, int rank, const void* unique_id, int64_t id_bytes,
                                    int64_t nvar_global, const int64_t* counts)
+{
+    const int rc = dist_attach_impl(h, nranks, rank, unique_id, id_bytes, nvar_global, counts);
+    if (rc != EXAADMM_OK && h != nullptr && h->dist != nullptr) {   // no half-attached handle survives a failure
+        const std::string keep = g_err;
+        (void)exaadmm_dist_detach(h);
+        g_err = keep;
+    }
+    return rc;
+}
+
+static int dist_attach_impl(exaadmm_handle* h, int nranks, int rank, const void* unique_id, int64_t id_bytes, int64_t nvar_global,
+                            const int64_t* counts)
 {
     REQUIRE(h && nranks >= 1 && rank >= 0 && rank < nranks && nvar_global >= 1 && counts, "bad argument");
     REQUIRE(h->T == 1, "partition helpers are not available on a multi-period handle");
@@ -188,6 +207,7 @@ static int dist_exchange(exaadmm_handle* h, int send_slot, int recv_slot)
     if (ss.count > 0)
         hipLaunchKernelGGL(k_gather, grid_for(ss.count, 256), dim3(256), 0, h->stream, vec_table(h), ss.d_which, ss.d_idx, ss.count, d->buf[send_slot]);
     if (d->nranks > 1 && (ss.count > 0 || rs.count > 0)) {
+        REQUIRE(d->comm != nullptr, "partition has peers but no communicator (exaadmm_dist_attach failed?)");
         NCCLCHK(d, d->GroupStart());
         int64_t so = 0, ro = 0;
         for (int p = 0; p < d->nranks; p++) {
@@ -223,6 +243,10 @@ extern "C" int exaadmm_dist_selftest(exaadmm_handle* h, int64_t n, double* max_e
     std::vector<double> a((size_t)n), b((size_t)n, -1.0);
     for (int64_t i = 0; i < n; i++) a[(size_t)i] = 0.5 * (double)i + d->rank;
     double *da = nullptr, *db = nullptr;
+    struct Free {
+        double *&a, *&b;
+        ~Free() { if (a) (void)hipFree(a); if (b) (void)hipFree(b); }
+    } free_on_exit{da, db};
     HIPCHK(hipMalloc((void**)&da, (size_t)n * sizeof(double)));
     HIPCHK(hipMalloc((void**)&db, (size_t)n * sizeof(double)));
     HIPCHK(hipMemcpyAsync(da, a.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -238,8 +262,6 @@ extern "C" int exaadmm_dist_selftest(exaadmm_handle* h, int64_t n, double* max_e
     HIPCHK(hipMemcpyAsync(got, h->d_sums, sizeof(got), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(b.data(), db, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    (void)hipFree(da);
-    (void)hipFree(db);
     double e = 0.0;
     for (int j = 0; j < 4; j++) e = fmax(e, fabs(got[j] - d->nranks * four[j]));
     for (int64_t i = 0; i < n; i++) e = fmax(e, fabs(b[(size_t)i] - (0.5 * (double)i + prev)));

@@ -504,6 +504,19 @@ extern "C" int exaadmm_create(const exaadmm_grid* g, const exaadmm_params* p, in
             TRY(upload_vec(h, dec, ec));
             d.EndStart = des;
             d.EndCode = dec;
+            // slot layout of the first chunk of every bus (k_bus_group)
+            std::vector<int> slot((size_t)h->B * BUS_W, 0), cnt(h->B, 0);
+            for (int I = 0; I < h->B; I++) {
+                cnt[I] = es[I + 1] - es[I];
+                for (int k = 0; k < std::min(cnt[I], BUS_W); k++) slot[(size_t)I * BUS_W + k] = ec[(size_t)es[I] + k];
+            }
+            int *dsl, *dcn;
+            TRY(dev_alloc(h, &dsl, slot.size()));
+            TRY(dev_alloc(h, &dcn, cnt.size()));
+            TRY(upload_vec(h, dsl, slot));
+            TRY(upload_vec(h, dcn, cnt));
+            d.SlotCode = dsl;
+            d.EndCount = dcn;
         }
     }
     // reduction scratch + loop control

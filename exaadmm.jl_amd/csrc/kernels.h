@@ -46,6 +46,10 @@ struct Dev {
     const double *Pd, *Qd, *YshR, *YshI;
     const int *FrStart, *FrIdx, *ToStart, *ToIdx, *GenStart, *GenIdx;
     const int *EndStart, *EndCode;  // per bus: generators, from-branches, to-branches (kind << 28 | index)
+    // the same list laid out for the lane-group bus kernel: SlotCode[8 * bus + lane] = component of the bus's first chunk
+    // served by that lane, EndCount[bus] = number of components -- one round of independent, coalesced loads instead of
+    // the dependent pair EndStart -> EndCode (buses with more than 8 components use EndStart / EndCode for the rest)
+    const int *SlotCode, *EndCount;
     const unsigned char* owned;  // SoA order; nullptr = all owned
     const int* lane_order;       // k_branch: lane i solves branch lane_order[i] (nullptr = identity)
     int *st_auglag, *st_minor, *st_ticks;
@@ -740,7 +744,9 @@ __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group(Dev d, double baseMVA, 
     unsigned long long tb0 = __builtin_amdgcn_s_memtime(), tb1 = 0, tb2 = 0, tb3 = 0, tb4 = 0;
 #endif
     if (I >= d.Ba) return;   // whole groups leave together
-    const int e0 = d.EndStart[I], n = d.EndStart[I + 1] - e0;
+    const int n = d.EndCount[I];
+    const int code0 = d.SlotCode[I * BUS_W + lane];
+    const int e0 = (n > BUS_W) ? d.EndStart[I] : 0;   // (only the rare large buses need the CSR offset)
 #if defined(EXA_PROFILE_PHASES)
     asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb1) : "v"(n) : "memory");
 #endif
@@ -756,7 +762,7 @@ __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group(Dev d, double baseMVA, 
     for (int c0 = 0; c0 < n; c0 += BUS_W) {
         const int m = min(BUS_W, n - c0);
         if (lane < m) {
-            const int code = d.EndCode[e0 + c0 + lane];
+            const int code = (c0 == 0) ? code0 : d.EndCode[e0 + c0 + lane];
             kind = code >> 28;
             bus_load_end(d, code, r, idx);
 #if defined(EXA_PROFILE_PHASES)
@@ -840,7 +846,7 @@ __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group(Dev d, double baseMVA, 
         const int m = min(BUS_W, n - c0);
         if (lane < m) {
             if (n > BUS_W) {  // registers only hold the last chunk: fetch this one again
-                const int code = d.EndCode[e0 + c0 + lane];
+                const int code = (c0 == 0) ? code0 : d.EndCode[e0 + c0 + lane];
                 kind = code >> 28;
                 bus_load_end(d, code, r, idx);
             }

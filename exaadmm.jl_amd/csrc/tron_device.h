@@ -548,20 +548,26 @@ EXA_BIG void prsrch_masked(unsigned fr, double (&x)[N], const double (&xl)[N], c
     breakpt<N>(x, xl, xu, w, brptmin, brptmax);
 
     bool search = true;
+    bool wa1_current = false;   // wa1 = P[x + alpha w] - x for the CURRENT alpha (the accepted trial's step need not be projected twice)
     for (int guard = 0; search && alpha > brptmin && guard < 1100; guard++) {
         gpstep<N>(x, xl, xu, alpha, w, wa1);
         symv<N>(A, wa1, wa2);
         mask_vec<N>(fr, wa2);
         double gts = dot<N>(gf, wa1);
         double q = EXA_FMA(0.5, dot<N>(wa1, wa2), gts);
-        if (q <= mu0 * gts)
+        if (q <= mu0 * gts) {
             search = false;
-        else
+            wa1_current = true;
+        } else {
             alpha = interpf * alpha;
+        }
     }
-    if (alpha < 1.0 && alpha < brptmin) alpha = brptmin;
+    if (alpha < 1.0 && alpha < brptmin) {
+        alpha = brptmin;
+        wa1_current = false;
+    }
 
-    gpstep<N>(x, xl, xu, alpha, w, wa1);
+    if (!wa1_current) gpstep<N>(x, xl, xu, alpha, w, wa1);
     EXA_UNROLL
     for (int i = 0; i < N; i++) {
         double xi = x[i] + alpha * w[i];

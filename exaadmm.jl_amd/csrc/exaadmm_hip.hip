@@ -126,6 +126,8 @@ struct exaadmm_handle {
     double acc_ms[3] = {0.0, 0.0, 0.0};                          // x-update, xbar-update, z/l/residual
     InitData init;
 };
+static int branch_lpb(const exaadmm_handle* h);   // branches per wavefront of the branch launch (below)
+
 
 static int attach_init_data(exaadmm_handle* h, const exaadmm_grid* g);
 static void launch_gen(exaadmm_handle* h, const Ctrl* c, int major_iter = 0);
@@ -378,6 +380,7 @@ extern "C" int exaadmm_create(const exaadmm_grid* g, const exaadmm_params* p, in
     d.G = h->G; d.L = h->L; d.B = h->B; d.Gp = h->Gp; d.Lp = h->Lp; d.N = h->N;
     d.La = g->nline_active > 0 ? (int)g->nline_active : h->L;
     d.Ba = g->nbus_active > 0 ? (int)g->nbus_active : h->B;
+    d.lpb = BR_BLOCK;   // set for good once the handle is complete (branch_lpb)
     d.T = 1; d.g1 = h->G; d.l1 = h->L; d.b1 = h->B;
     const int base = g->index_base;
     int rc = 0;
@@ -534,6 +537,7 @@ extern "C" int exaadmm_create(const exaadmm_grid* g, const exaadmm_params* p, in
     memset(h->h_ctrl, 0, sizeof(Ctrl));
     TRY(attach_init_data(h, g));
 #undef TRY
+    h->d.lpb = branch_lpb(h);
     *out = h;
     return EXAADMM_OK;
 }
@@ -965,6 +969,23 @@ static void launch_mp_elem(exaadmm_handle* h, double beta, const Ctrl* c)
     hipLaunchKernelGGL((k_mp_elem<MODE>), dim3(h->mp_nbx, h->T, MP_PLANES), dim3(EW_BLOCK), 0, h->stream, h->d, beta,
                        h->par.MAX_MULTIPLIER, c);
 }
+// Branches per wavefront of the branch launch.  64 (full waves) is the measured optimum at every size: spreading a small
+// grid over more, emptier waves shortens no wave's serial chain by much and costs more than it saves (13659-bus grid:
+// 64 -> 0.0685 ms, 32 -> 0.0704, 23 -> 0.0768, 16 -> 0.0838; profiles/r02_lanes_per_wave.txt).
+// EXAADMM_LANES_PER_WAVE is kept as the A/B switch of that measurement.
+static int branch_lpb(const exaadmm_handle* h)
+{
+    (void)h;
+#if !defined(EXA_PROFILE_PHASES)   // (the diagnostic build indexes its per-wave timeline by 64-branch waves)
+    if (const char* e = getenv("EXAADMM_LANES_PER_WAVE")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= BR_BLOCK) return v;
+    }
+#endif
+    return BR_BLOCK;
+}
+static int branch_blocks(const exaadmm_handle* h) { return (std::max(h->d.La, 1) + h->d.lpb - 1) / h->d.lpb; }
+
 // throughput variant of the branch kernel (kernels.h, k_branch_tp): single-period model, identity lane order, and a
 // launch with more wavefronts than the chip has SIMDs
 static bool use_tp(const exaadmm_handle* h)
@@ -978,7 +999,7 @@ static void launch_branch(exaadmm_handle* h, int major_iter, const Ctrl* c, bool
         (void)hipMemcpyAsync(h->d_dev, &h->d, sizeof(Dev), hipMemcpyHostToDevice, h->stream);
         h->dev_dirty = false;
     }
-    const int nb = (int)grid_for(h->d.La, BR_BLOCK).x;
+    const int nb = use_tp(h) ? (int)grid_for(h->d.La, BR_BLOCK).x : branch_blocks(h);
     const int ng = (with_generators && h->G > 0) ? (int)grid_for(h->G, BR_BLOCK).x : 0;
     if (h->T > 1)
         hipLaunchKernelGGL((k_branch_t<true>), dim3(nb + ng), dim3(BR_BLOCK), 0, h->stream, h->d_dev, h->bo, h->par.scale, major_iter, const_cast<Ctrl*>(c), ng, h->baseMVA, -1);
@@ -1300,7 +1321,8 @@ static int spec_prepare(exaadmm_handle* h)
         }
         if ((rc = dev_alloc(h, &h->v_alt, (size_t)h->N))) return rc;
         {
-            const int nblk = (int)grid_for(h->d.La, BR_BLOCK).x + ((h->G > 0) ? (int)grid_for(h->G, BR_BLOCK).x : 0);
+            // room for any branches-per-wave setting the fused variant can run with (it is used below 2048 64-branch waves)
+            const int nblk = std::min(std::max(h->d.La, 1), BR_BLOCK * 2048) + ((h->G > 0) ? (int)grid_for(h->G, BR_BLOCK).x : 0);
             if ((rc = dev_alloc(h, &h->partials_br, (size_t)nblk * 4))) return rc;
         }
         HIPCHK(hipMemcpyAsync(h->v_alt, h->d.v, (size_t)h->N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
@@ -1330,13 +1352,13 @@ static int spec_prepare(exaadmm_handle* h)
     // (only while the branch launch is latency-bound: with more than ~2 waves queued per SIMD the prologue's memory
     //  latency, at one resident wave per SIMD, costs more than the streaming kernel it replaces -- measured at 1M
     //  branches: k_branch 0.43 -> 0.61 ms against 0.10 ms for k_fused_zl; +3 % at 20 467 and 88 207 branches)
-    if (h->zl_on && h->d.lane_order == nullptr && grid_for(h->d.La, BR_BLOCK).x <= 2048 && !use_tp(h)) {
+    if (h->zl_on && h->d.lane_order == nullptr && grid_for(h->d.La, BR_BLOCK).x <= 2048 && !use_tp(h)) {   // (size test in 64-branch waves)
         // v follows the same parity as u: the bus launch of an odd iteration writes the alternate v, which the next
         // (even) iteration's branch launch reads
         a.v_in = h->d.v;   a.v = h->v_alt;
         b.v_in = h->v_alt; // b.v stays the primary buffer
         a.partials_br = b.partials_br = h->partials_br;
-        a.npartials_br = b.npartials_br = (int)grid_for(h->d.La, BR_BLOCK).x + ((h->G > 0) ? (int)grid_for(h->G, BR_BLOCK).x : 0);
+        a.npartials_br = b.npartials_br = branch_blocks(h) + ((h->G > 0) ? (int)grid_for(h->G, BR_BLOCK).x : 0);
     }
     if (memcmp(&a, &h->dspec[0], sizeof(Dev)) != 0 || memcmp(&b, &h->dspec[1], sizeof(Dev)) != 0) {
         invalidate_graph(h);
@@ -1354,7 +1376,7 @@ static void enqueue_iteration_spec(exaadmm_handle* h, Ctrl* c, int j, bool sampl
 {
     const int par = j & 1;
     const Dev& dv = h->dspec[par];
-    const int nb = (int)grid_for(h->d.La, BR_BLOCK).x;
+    const int nb = use_tp(h) ? (int)grid_for(h->d.La, BR_BLOCK).x : branch_blocks(h);
     const int ng = (h->G > 0) ? (int)grid_for(h->G, BR_BLOCK).x : 0;
     if (sample) (void)hipEventRecord(h->tev[0], h->stream);
     if (bev) (void)hipEventRecord(bev[0], h->stream);
@@ -1751,6 +1773,7 @@ extern "C" int exaadmm_set_active(exaadmm_handle* h, int64_t nbranch, int64_t nb
             "active branch count must be given at create time (exaadmm_grid.nline_active): branches are stored bus-sorted");
     h->d.La = (int)nbranch;
     h->d.Ba = (int)nbus;
+    h->d.lpb = branch_lpb(h);
     h->dev_dirty = true;
     invalidate_graph(h);
     return EXAADMM_OK;

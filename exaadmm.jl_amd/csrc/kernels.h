@@ -35,6 +35,10 @@ struct Ctrl {
 struct Dev {
     int G, L, B, Gp, Lp, N;
     int La, Ba;  // active branches / buses (<= L, B): a partition's ghosts come after them
+    // branches per wavefront of the branch launch (1..64).  A trip of the solver loop costs a wavefront the MAXIMUM over
+    // its lanes of every data-dependent phase (faces, CG iterations, line-search trials), so while the chip has more
+    // SIMDs than the launch has wavefronts the branches are spread thinner than 64 per wave (exaadmm_hip.hip, branch_lpb)
+    int lpb;
     double *u, *v, *z, *zp, *l, *lz, *rho;
     double *rp, *rd, *ax;
     const double* Y;    // 8 planes x Lp
@@ -306,9 +310,9 @@ __global__ void __launch_bounds__(BR_BLOCK, EXA_BR_WAVES) k_branch_t(const Dev* 
             generator_update(d, baseMVA, gi);
         return;
     }
-    const int slot = blockIdx.x * BR_BLOCK + threadIdx.x;
-    if (!ZL && slot >= d.La) return;
-    const bool lane_on = slot < d.La;
+    const int slot = blockIdx.x * d.lpb + threadIdx.x;
+    const bool lane_on = (int)threadIdx.x < d.lpb && slot < d.La;
+    if (!ZL && !lane_on) return;
 #if defined(EXA_PROFILE_PHASES)
     const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
 #endif
@@ -389,7 +393,7 @@ __global__ void __launch_bounds__(BR_BLOCK, EXA_BR_WAVES) k_branch_t(const Dev* 
     branch_start(ub, bnd, d.rateA[b], x, xl, xu);
     BranchStats st;
 #if defined(EXA_PROFILE_PHASES)
-    st.tl = d.st_tl ? d.st_tl + (size_t)(slot / 64) * 128 : nullptr;
+    st.tl = d.st_tl ? d.st_tl + (size_t)blockIdx.x * 128 : nullptr;   // (the diagnostic build keeps 64 branches per wave)
     // force the loads to land before the stamp: consume one loaded value in the asm dependency
     unsigned long long t_loaded;
     asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_loaded) : "v"(x[0]) : "memory");

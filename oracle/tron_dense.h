@@ -15,9 +15,14 @@
  * (n <= TRON_NMAX); the reverse-communication driver mirrors
  * acopf_tron_linelimit_kernel.jl:44-144.
  *
- * PARITY STATUS: primitive-level parity is UNPINNED (no ExaTron sources or
- * unit vectors available); end-to-end parity is pinned by the reference's own
- * known answers (test/algorithms/acopf_update_cpu.jl:28-172), see tests/.
+ * PARITY STATUS: primitive-level parity with ExaTron itself is UNPINNED (no
+ * ExaTron sources or unit vectors available); end-to-end parity is pinned by
+ * the reference's own known answers (test/algorithms/acopf_update_cpu.jl:28-172),
+ * see tests/.  Each primitive is checked against an independent computation of
+ * what the published algorithm defines (numpy/scipy factorisations and Krylov
+ * solves, the Cauchy / projected-search inequalities, enumerated box-QP
+ * minimisers, scipy.optimize on the bounded Rosenbrock function) in
+ * tests/test_oracle_tron.py.
  */
 #ifndef EXAADMM_ORACLE_TRON_DENSE_H
 #define EXAADMM_ORACLE_TRON_DENSE_H

@@ -9,6 +9,7 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 CASE9 = os.path.join(GOLDEN, "case9.m")
+CASE118 = os.path.join(GOLDEN, "case118.m")
 
 
 def pytest_configure(config):

@@ -26,7 +26,7 @@ def main():
     cum = re.findall(r"mod\.info\.cumul == (\d+)", src)
     out["solve_case118"] = {"outer": 20, "cumul": int(cum[1]),
                             "objval": float(re.search(r"objval, ([\d.]+); rtol=1e-6", src).group(1)),
-                            "note": "case118.m is not available offline; recorded for completeness"}
+                            "note": "input: tests/golden/case118.m (IEEE 118-bus system written out in MATPOWER layout; the upstream ExaData copy is not available offline)"}
     json.dump(out, open(OUT, "w"), indent=1)
     print("wrote", OUT)
 

@@ -8,7 +8,7 @@ import re
 import numpy as np
 import pytest
 
-from conftest import CASE9, ROOT
+from conftest import CASE9, CASE118, ROOT
 import exaadmm_loader
 
 
@@ -29,9 +29,12 @@ def test_every_declared_symbol_is_exported(pkg):
     assert not missing, missing
 
 
-def test_native_matpower_loader_matches_oracle_loader(pkg, oracle):
-    a = pkg.opf_loaddata(CASE9)
-    b = oracle.grid_from_matpower(CASE9)
+@pytest.mark.parametrize("case", [CASE9, CASE118], ids=["case9", "case118"])
+def test_native_matpower_loader_matches_oracle_loader(pkg, oracle, case):
+    """(case118 adds what case9 lacks: transformers, bus shunts, parallel circuits, unlimited ratings,
+    buses without load, 54 generators on 118 buses)"""
+    a = pkg.opf_loaddata(case)
+    b = oracle.grid_from_matpower(case)
     assert (a["ngen"], a["nline"], a["nbus"]) == (b["ngen"], b["nline"], b["nbus"])
     for k in pkg.Grid._F64 + pkg.Grid._BUS:
         assert np.allclose(a[k], b[k], rtol=1e-15, atol=0), k

@@ -1,6 +1,7 @@
 """world_size-2 (and 3) gloo tests of the multi-GPU orchestration: partitioning, halo plans,
 all_to_all halo exchange, residual all-reduce and device-style loop control must reproduce the
 single-process solve of the global grid."""
+import json
 import os
 import socket
 
@@ -26,7 +27,7 @@ RHO = (4e2, 4e4)
 PAR = dict(outer_iterlim=2, inner_iterlim=25)
 
 
-def _worker(rank, world, port, outdir, check_every=1):
+def _worker(rank, world, port, outdir, check_every=1, case=None, par_over=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -34,12 +35,16 @@ def _worker(rank, world, port, outdir, check_every=1):
         dm = exaadmm_loader.load_submodule("distributed")
         syn = exaadmm_loader.load_submodule("synthetic")
         from dist_oracle_backend import OracleBackend
-        grid = syn.synthetic_grid(GRID["ngen"], GRID["nline"], GRID["nbus"], seed=GRID["seed"], locality=GRID["locality"])
+        if case is None:
+            grid = syn.synthetic_grid(GRID["ngen"], GRID["nline"], GRID["nbus"], seed=GRID["seed"], locality=GRID["locality"])
+        else:
+            from oracle import oracle as O
+            grid = O.grid_from_matpower(case)
         part = dm.Partition(grid, world, rank)
         st = dm.init_state(grid, *RHO)
         be = OracleBackend(part, *RHO)
         par = dict(dm.DEFAULT_PAR)
-        par.update(PAR)
+        par.update(PAR if par_over is None else par_over)
         model = dm.DistributedAcopf(part, be, dist, st, par, check_every=check_every)
         info = model.solve()
         u = model.gather_owned("u_curr")
@@ -68,6 +73,28 @@ def test_partitioned_solve_matches_single_process(world, tmp_path, oracle):
         assert np.abs(a - b).max() <= 1e-10 * max(1.0, np.abs(b).max()), name
     assert np.isclose(float(out["primres"]), ref.info.primres, rtol=1e-10)
     assert np.isclose(float(out["mismatch"]), ref.info.mismatch, rtol=1e-10)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_partitioned_solve_reproduces_the_case118_anchor(world, tmp_path):
+    """The reference's second anchor (test/algorithms/acopf_update_cpu.jl:174-179: 20 outer / 1232 inner iterations,
+    objective 129645.676) with the 118-bus system cut into 2 and 3 partitions: halo exchange, replicated break
+    decisions and the all-reduced residuals leave the trajectory where the single-process reference has it."""
+    from conftest import CASE118
+    from oracle import oracle as O
+    anchor = json.load(open(os.path.join(os.path.dirname(CASE118), "case9_iter1.json")))["solve_case118"]
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), 1, CASE118, dict(outer_iterlim=25, outer_eps=2e-5)),
+             nprocs=world, join=True)
+    out = np.load(os.path.join(str(tmp_path), "out.npz"))
+    assert out["cut"] > 0
+    assert int(out["cumul"]) == anchor["cumul"] and int(out["outer"]) == anchor["outer"]
+    grid = O.grid_from_matpower(CASE118)
+    pg = out["u"][0:2 * grid["ngen"]:2] * grid["baseMVA"]
+    # (admm_poststep, acopf_admm_prepoststep_cpu.jl:30-46: raw cost coefficients on MW)
+    raw = O.read_matpower(CASE118)["mpc.gencost"]
+    c2, c1, c0 = (np.array([r[k] for r in raw]) for k in (4, 5, 6))
+    objval = float(np.sum(c2 * pg ** 2 + c1 * pg + c0))
+    assert abs(objval - anchor["objval"]) <= 1e-6 * anchor["objval"]
 
 
 def test_partition_invariants():

@@ -28,8 +28,13 @@ syn = exaadmm_loader.load_submodule("synthetic")
 dm = exaadmm_loader.load_submodule("distributed")
 import ctypes as C
 world = %(world)d
-g = syn.sized_like("case1354pegase", seed=2)
-rho = (1e1, 1e3)
+case = %(case)r
+if case:
+    g = pkg.opf_loaddata(case)            # the reference's 118-bus anchor case, cut into `world` partitions
+    rho, par_over = (4e2, 4e4), dict(outer_iterlim=25, outer_eps=2e-5)
+else:
+    g = syn.sized_like("case1354pegase", seed=2)
+    rho, par_over = (1e1, 1e3), dict(outer_iterlim=3, inner_iterlim=200)
 st = dm.init_state(g, *rho)
 parts = [dm.Partition(g, world, r) for r in range(world)]
 assert sum(p.n_cut for p in parts) > 0
@@ -45,7 +50,7 @@ class Stub:
     def broadcast_object_list(self, lst, src=0): lst[0] = buf.raw
 
 bes = [dm.HipBackend(pkg, p, rho[0], rho[1], device_index=0) for p in parts]
-par = dict(dm.DEFAULT_PAR); par.update(outer_iterlim=3, inner_iterlim=200)
+par = dict(dm.DEFAULT_PAR); par.update(par_over)
 models = [dm.DistributedAcopf(p, be, Stub(r), st, par) for r, (p, be) in enumerate(zip(parts, bes))]
 infos, errs = [None] * world, [None] * world
 def run(r):
@@ -61,7 +66,7 @@ ths = [threading.Thread(target=run, args=(r,)) for r in range(world)]
 [t.start() for t in ths]; [t.join(180) for t in ths]
 assert not any(t.is_alive() for t in ths), "a rank hung"
 assert not any(errs), errs
-env, mod = pkg.solve_acopf("syn", grid=g, rho_pq=rho[0], rho_va=rho[1], outer_iterlim=3, inner_iterlim=200, verbose=0)
+env, mod = pkg.solve_acopf("syn", grid=g, rho_pq=rho[0], rho_va=rho[1], verbose=0, **par_over)
 out = {"cut": int(sum(p.n_cut for p in parts)), "cumul": [i["cumul"] for i in infos], "outer": [i["outer"] for i in infos],
        "mismatch": [i["mismatch"] for i in infos], "single": [mod.info.outer, mod.info.cumul, mod.info.mismatch], "err": {}}
 for name in ("u_curr", "v_curr", "z_curr", "l_curr"):
@@ -108,14 +113,30 @@ def _shim():
     return so
 
 
+def _run_worker(world, case):
+    env = dict(os.environ, EXAADMM_RCCL_LIB=_shim())
+    r = subprocess.run([sys.executable, "-c", WORKER % {"root": ROOT, "world": world, "case": case}], env=env,
+                       capture_output=True, text=True, timeout=480)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_library_distributed_loop_with_several_ranks_on_one_gpu(world):
-    env = dict(os.environ, EXAADMM_RCCL_LIB=_shim())
-    r = subprocess.run([sys.executable, "-c", WORKER % {"root": ROOT, "world": world}], env=env, capture_output=True, text=True, timeout=480)
-    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
-    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    out = _run_worker(world, "")
     assert out["cut"] > 0
     assert all(c == out["single"][1] for c in out["cumul"]) and all(o == out["single"][0] for o in out["outer"]), out
     assert all(abs(m - out["single"][2]) <= 1e-10 * out["single"][2] for m in out["mismatch"]), out
+    assert all(e <= 1e-10 for e in out["err"].values()), out
+    assert all(n == 0 for n in out["fixed_nonzero_differences"].values()), out
+
+
+def test_library_distributed_loop_reproduces_the_case118_anchor():
+    """The reference's 118-bus anchor (acopf_update_cpu.jl:174-179: 20 outer / 1232 inner iterations) from the
+    in-library distributed loop with the system cut into 3 partitions."""
+    out = _run_worker(3, os.path.join(ROOT, "tests", "golden", "case118.m"))
+    assert out["cut"] > 0
+    assert out["cumul"] == [1232] * 3 and out["outer"] == [20] * 3, out
+    assert out["single"][:2] == [20, 1232], out
     assert all(e <= 1e-10 for e in out["err"].values()), out
     assert all(n == 0 for n in out["fixed_nonzero_differences"].values()), out

@@ -63,6 +63,9 @@ for seed, noise in ((0, 0.0), (1, 0.02), (2, 0.2)):
                           "penalty_mismatches": int((mb_gpu[:, 26] != mult[:, 2]).sum()),
                           "max_auglag": int(a_ref.max())})
     mod.close()
+env, mod = pkg.solve_acopf(os.path.join(%(root)r, "tests", "golden", "case118.m"), outer_iterlim=25, rho_pq=4e2, rho_va=4e4,
+                           outer_eps=2e-5, verbose=0)
+out["case118"] = {"status": mod.info.status, "outer": mod.info.outer, "cumul": mod.info.cumul, "objval": mod.info.objval}
 print("RESULT " + json.dumps(out))
 '''
 
@@ -82,6 +85,10 @@ def test_exact_build_matches_oracle_and_bounds_the_fast_build():
     report = {"exact": exact, "fast": fast}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(report, open(os.path.join(ROOT, "gpurun_out", "exact_arith_report.json"), "w"), indent=1)
+    # the reference's 118-bus anchor (acopf_update_cpu.jl:174-179) holds for both arithmetics
+    for r in (exact, fast):
+        assert (r["case118"]["status"], r["case118"]["outer"], r["case118"]["cumul"]) == ("Solved", 20, 1232), r["case118"]
+        assert abs(r["case118"]["objval"] - 129645.676) <= 1e-6 * 129645.676
     n = sum(s["n"] for s in exact["states"])
     mis_exact = sum(s["count_mismatches"] for s in exact["states"])
     mis_fast = sum(s["count_mismatches"] for s in fast["states"])

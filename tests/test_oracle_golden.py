@@ -132,9 +132,28 @@ def _find_case(name):
     return None
 
 
-@pytest.mark.skipif(_find_case("case118.m") is None, reason="case118.m not available offline (ExaData artifact)")
+def test_case118_fixture_is_the_ieee_118_bus_system():
+    """Integrity of tests/golden/case118.m: the published totals of the IEEE 118-bus system."""
+    from oracle import oracle as O
+    raw = O.read_matpower(_find_case("case118.m"))
+    bus, gen, br, cost = (np.array(raw[k]) for k in ("mpc.bus", "mpc.gen", "mpc.branch", "mpc.gencost"))
+    assert bus.shape[0] == 118 and gen.shape[0] == 54 and br.shape[0] == 186 and cost.shape[0] == 54
+    assert bus[:, 2].sum() == 4242.0 and bus[:, 3].sum() == 1438.0          # MW, MVAr
+    assert abs(gen[:, 8].sum() - 9966.2) < 1e-9                                # installed capacity, MW
+    assert np.count_nonzero(bus[:, 5]) == 14                                   # bus shunts
+    assert np.count_nonzero(br[:, 8]) == 9                                     # transformers (off-nominal ratio)
+    assert int(bus[bus[:, 1] == 3, 0][0]) == 69                                # reference bus
+    assert np.array_equal(np.unique(bus[:, 0]), np.arange(1, 119))
+    zero = gen[:, 1] == 0
+    assert np.all(cost[zero, 4] == 0.01) and np.all(cost[zero, 5] == 40.0)
+    np.testing.assert_allclose(cost[~zero, 4], 10.0 / gen[~zero, 1], rtol=5e-6)
+    assert np.all(cost[~zero, 5] == 20.0)
+
+
 def test_case118_full_solve_anchor(oracle):
-    """second anchor of the reference test (acopf_update_cpu.jl:174-179); runs when the file is supplied"""
+    """Second anchor of the reference test (acopf_update_cpu.jl:174-179): 20 outer / 1232 inner iterations,
+    objective 129645.676 (rtol 1e-6) -- 186 branch subproblems through 1232 iterations with the same counts as the
+    reference pins the aug-Lagrangian / TRON dynamics far harder than the 9-bus trajectories do."""
     a = G["solve_case118"]
     m = oracle.solve_acopf(_find_case("case118.m"), outer_iterlim=25, rho_pq=4e2, rho_va=4e4, outer_eps=2e-5)
     assert m.info.status == 1 and m.info.outer == a["outer"] and m.info.cumul == a["cumul"]

@@ -49,11 +49,15 @@ CASE = "case13659pegase"
 CASE_PARAMS = {"case13659pegase": dict(rho_pq=5e1, rho_va=5e3, scale=1e-4),
                "case1354pegase": dict(rho_pq=1e1, rho_va=1e3, scale=1e-4),
                "case_ACTIVSg70k": dict(rho_pq=3e4, rho_va=3e5, scale=1e-5),
-               "synthetic1M": dict(rho_pq=5e1, rho_va=5e3, scale=1e-4)}
+               "synthetic1M": dict(rho_pq=5e1, rho_va=5e3, scale=1e-4),
+               # the reference's own test cases (real input files under tests/golden/), with the settings of its anchors
+               # (test/algorithms/acopf_update_cpu.jl:168-179: outer_iterlim=25, outer_eps=2e-5, no bound tightening)
+               "case9": dict(rho_pq=4e2, rho_va=4e4, scale=1e-4, tight_factor=1.0, outer_iterlim=25, outer_eps=2e-5),
+               "case118": dict(rho_pq=4e2, rho_va=4e4, scale=1e-4, tight_factor=1.0, outer_iterlim=25, outer_eps=2e-5)}
 
 
 def find_case_file(name):
-    for d in (os.environ.get("MATPOWER_DATA", ""), os.path.join(ROOT, "data")):
+    for d in (os.environ.get("MATPOWER_DATA", ""), os.path.join(ROOT, "data"), os.path.join(ROOT, "tests", "golden")):
         if d:
             p = os.path.join(d, name + ".m")
             if os.path.exists(p):
@@ -84,7 +88,7 @@ def cpu_baseline(grid, params, budget_s=15.0, nthreads=1, prep=100):
                       % (n_done, max(prep, 2), nthreads, t_used)}
 
 
-def cpu_full_solve(grid, params, budget_s=30.0, nthreads=1):
+def cpu_full_solve(grid, params, budget_s=30.0, nthreads=1, outer_lim=20, outer_eps=2e-4):
     """The reference's own metric (print_statistics.jl:12: cumul / time_overall of admm_two_level.jl:28-80) for the
     CPU port: the oracle runs THE SAME two-level solve (outer 20 x inner 1000, early breaks on) step by step until it
     finishes or the time budget is spent; a cut-off run is a bounded sample (the first iterations of the solve)."""
@@ -92,10 +96,11 @@ def cpu_full_solve(grid, params, budget_s=30.0, nthreads=1):
     from oracle import oracle as O
     m = O.OracleModel(grid, params["rho_pq"], params["rho_va"], scale=params["scale"], nthreads=nthreads)
     par = m.par
+    par.outer_eps = outer_eps
     sqrt_d = math.sqrt(m.nvar)
     beta, cumul, status, outer, finished = par.initial_beta, 0, "IterationLimit", 0, True
     t0 = time.perf_counter()
-    while outer < 20:
+    while outer < outer_lim:
         outer += 1
         m.info.outer = outer
         nzp = m.norm_z()
@@ -177,16 +182,18 @@ def main():
         raise SystemExit("bench.py needs an MI355X; the product has no CPU path")
 
     params = CASE_PARAMS[args.case]
+    tight = params.get("tight_factor", 0.99)
+    outer_lim, outer_eps = params.get("outer_iterlim", 20), params.get("outer_eps", 2e-4)
     path = find_case_file(args.case)
     if path:
-        grid = pkg.opf_loaddata(path, tight_factor=0.99)
+        grid = pkg.opf_loaddata(path, tight_factor=tight)
         workload, data = args.case, "real MATPOWER file"
     else:
         grid = syn.sized_like(args.case, seed=0)
         workload, data = "synthetic-%s-sized" % args.case, "synthetic"
     G, L, B = int(grid["ngen"]), int(grid["nline"]), int(grid["nbus"])
 
-    env = pkg.AdmmEnv(args.case, params["rho_pq"], params["rho_va"], tight_factor=0.99, gpu_no=0, verbose=0, grid=grid)
+    env = pkg.AdmmEnv(args.case, params["rho_pq"], params["rho_va"], tight_factor=tight, gpu_no=0, verbose=0, grid=grid)
     T = max(1, args.periods)
     if T > 1:
         import numpy as np
@@ -255,7 +262,7 @@ def main():
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": data,
         "config": {"workload": workload, "ngen": G, "nline": L, "nbus": B, "rho_pq": params["rho_pq"],
-                   "rho_va": params["rho_va"], "scale": params["scale"], "tight_factor": 0.99,
+                   "rho_va": params["rho_va"], "scale": params["scale"], "tight_factor": tight,
                    "mode": "fixed-count inner iterations, no early break", "parallelism": "1 GPU",
                    "state": "ADMM state after %d untimed preparation iterations from init_solution! (outer 1, beta %.0f)" % (args.prep, beta)},
         "roofline": {"bound": "hbm", "kernel": "k_branch" + (" (with the fused z/l prologue)" if fused_zl else ""), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -279,21 +286,28 @@ def main():
         # admm_two_level.jl:28-80).  Two solves: the first one also pays graph capture and first-touch costs.
         fs = None
         for rep in range(2):
+            tw0 = time.perf_counter()
             env2, mod2 = pkg.solve_acopf(args.case, grid=grid, rho_pq=params["rho_pq"], rho_va=params["rho_va"],
-                                         scale=params["scale"], tight_factor=0.99, outer_iterlim=20, inner_iterlim=1000, verbose=0)
+                                         scale=params["scale"], tight_factor=tight, outer_iterlim=outer_lim, outer_eps=outer_eps,
+                                         inner_iterlim=1000, verbose=0)
             i2 = mod2.info
+            host_u, host_v = mod2.solution.u_curr, mod2.solution.v_curr   # results back in host memory
+            tw1 = time.perf_counter()
             cur = {"status": i2.status, "outer": i2.outer, "cumul": i2.cumul, "time_overall_s": i2.time_overall,
                    "iterations_per_s": i2.cumul / i2.time_overall, "ms_per_iteration": 1e3 * i2.time_overall / max(i2.cumul, 1),
-                   "objval": i2.objval, "mismatch": i2.mismatch, "avg_auglag_it_last": i2.avg_auglag_it}
+                   "objval": i2.objval, "mismatch": i2.mismatch, "avg_auglag_it_last": i2.avg_auglag_it,
+                   # boundary-inclusive: host grid arrays in -> handle creation (PCIe upload, CSR / slot tables), initial
+                   # point, solve, u and v back in host memory (PCIe download).  Reported, never `value`.
+                   "host_to_host_s": tw1 - tw0, "iterations_per_s_host_to_host": i2.cumul / (tw1 - tw0)}
             if fs is None:
                 first = cur
             fs = cur
             mod2.close()
         fs["first_run_time_overall_s"] = first["time_overall_s"]
-        fs["definition"] = "cumul / time_overall of solve_acopf(outer_iterlim=20, inner_iterlim=1000), second of two solves"
+        fs["definition"] = "cumul / time_overall of solve_acopf(outer_iterlim=%d, outer_eps=%g, inner_iterlim=1000), second of two solves" % (outer_lim, outer_eps)
         out["full_solve"] = fs
         if not args.no_cpu_baseline:
-            cf = cpu_full_solve(grid, params, budget_s=args.cpu_solve_budget)
+            cf = cpu_full_solve(grid, params, budget_s=args.cpu_solve_budget, outer_lim=outer_lim, outer_eps=outer_eps)
             fs["cpu_port"] = cf
             fs["speedup_vs_cpu_port"] = fs["iterations_per_s"] / cf["iterations_per_s"]
             if cf["finished"]:   # same solve on both sides: the counts and the objective must agree

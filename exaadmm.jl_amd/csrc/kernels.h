@@ -102,24 +102,29 @@ __device__ __forceinline__ void generator_update(const Dev& d, double baseMVA, i
 // z_prev <- z ; z-update ; l-update ; residual terms of ONE element, the arithmetic of k_fused_zl
 // (admm_inner_prestep + admm_update_z + admm_update_l + admm_update_residual) -- used by the branch launch's
 // prologue when the z/l pass rides in it.  Returns the new l and z of the element.
-__device__ __forceinline__ void zl_element(const Dev& d, int e, double u, double v, double rho, double beta, double (&s)[4],
-                                           double& l_new, double& z_new)
+__device__ __forceinline__ void zl_values(double u, double v, double rho, double beta, double lz, double zold, double lold,
+                                          double (&s)[4], double& l_new, double& z_new)
 {
-    const double lz = d.lz[e];
-    const double zold = d.z[e];
-    const double z = (-(lz + d.l[e] + rho * (u - v))) / (beta + rho);
+    const double z = (-(lz + lold + rho * (u - v))) / (beta + rho);
     const double rp = u - v + z;
     const double rd = z - zold;
     const double ax = rp - z;
-    d.zp[e] = zold;
-    d.z[e] = z;
     l_new = -(lz + beta * z);
-    d.l[e] = l_new;
     z_new = z;
     s[0] += rp * rp;
     s[1] += rd * rd;
     s[2] += z * z;
     s[3] += ax * ax;
+}
+__device__ __forceinline__ void zl_element(const Dev& d, int e, double u, double v, double rho, double beta, double (&s)[4],
+                                           double& l_new, double& z_new)
+{
+    const double lz = d.lz[e];
+    const double zold = d.z[e];
+    zl_values(u, v, rho, beta, lz, zold, d.l[e], s, l_new, z_new);
+    d.zp[e] = zold;
+    d.z[e] = z_new;
+    d.l[e] = l_new;
 }
 
 __global__ void k_generator(Dev d, double baseMVA, const Ctrl* ctrl)
@@ -328,21 +333,55 @@ __global__ void __launch_bounds__(BR_BLOCK, EXA_BR_WAVES) k_branch_t(const Dev* 
     double ub[8], bnd[8];
 #if defined(EXA_CONST_IN_REGS)
     BranchData bd;
+    double ls1_0 = 0.0, ls2_0 = 0.0, mu_0 = 0.0, rate_0 = 0.0;
+    if (ZL) {
+        // Every load of the prologue first, every store after them.  As far as the compiler knows the planes may alias,
+        // so a store between two loads is a full memory round trip: with the z/l pass written element by element
+        // (load, compute, store, eight times, then the multipliers) a wave needed 10.6 k clocks from kernel entry to
+        // "loads landed" against 4.0 k for the launch without the pass (profiles/r02_wave_timeline_*).
+        double vv[8], zo[8], lo[8], lzv[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const int e = base + k * Lp;
-        ub[k] = uin[e];
-        bd.rho_[k] = d.rho[e];
-        if (ZL && do_zl && lane_on) {
-            double zn;
-            zl_element(d, e, ub[k], vin[e], bd.rho_[k], zl_beta, zs, bd.lam_[k], zn);
-            bd.xt_[k] = vin[e] - zn;
-        } else {
+        for (int k = 0; k < 8; k++) {
+            const int e = base + k * Lp;
+            ub[k] = uin[e];
+            bd.rho_[k] = d.rho[e];
+            vv[k] = vin[e];
+            zo[k] = d.z[e];
+            lo[k] = d.l[e];
+            lzv[k] = do_zl ? d.lz[e] : 0.0;
+            bd.Y_[k] = d.Y[b + k * Lp];
+            bnd[k] = d.bnd[b + k * Lp];
+        }
+        ls1_0 = (d.ls1_in ? d.ls1_in : d.ls1)[b];
+        ls2_0 = (d.ls2_in ? d.ls2_in : d.ls2)[b];
+        mu_0 = (d.mu_in ? d.mu_in : d.mu)[b];
+        rate_0 = d.rateA[b];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (do_zl && lane_on) {
+                const int e = base + k * Lp;
+                double zn;
+                zl_values(ub[k], vv[k], bd.rho_[k], zl_beta, lzv[k], zo[k], lo[k], zs, bd.lam_[k], zn);
+                d.zp[e] = zo[k];
+                d.z[e] = zn;
+                d.l[e] = bd.lam_[k];
+                bd.xt_[k] = vv[k] - zn;
+            } else {
+                bd.lam_[k] = lo[k];
+                bd.xt_[k] = vv[k] - zo[k];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int e = base + k * Lp;
+            ub[k] = uin[e];
+            bd.rho_[k] = d.rho[e];
             bd.lam_[k] = d.l[e];
             bd.xt_[k] = vin[e] - d.z[e];
+            bd.Y_[k] = d.Y[b + k * Lp];
+            bnd[k] = d.bnd[b + k * Lp];
         }
-        bd.Y_[k] = d.Y[b + k * Lp];
-        bnd[k] = d.bnd[b + k * Lp];
     }
     (void)my;
 #else
@@ -374,9 +413,18 @@ __global__ void __launch_bounds__(BR_BLOCK, EXA_BR_WAVES) k_branch_t(const Dev* 
         }
         if (!lane_on) return;
     }
-    bd.ls1 = (d.ls1_in ? d.ls1_in : d.ls1)[b];
-    bd.ls2 = (d.ls2_in ? d.ls2_in : d.ls2)[b];
-    bd.mu = (major_iter == 1) ? 10.0 : (d.mu_in ? d.mu_in : d.mu)[b];
+#if defined(EXA_CONST_IN_REGS)
+    if (ZL) {
+        bd.ls1 = ls1_0;
+        bd.ls2 = ls2_0;
+        bd.mu = (major_iter == 1) ? 10.0 : mu_0;
+    } else
+#endif
+    {
+        bd.ls1 = (d.ls1_in ? d.ls1_in : d.ls1)[b];
+        bd.ls2 = (d.ls2_in ? d.ls2_in : d.ls2)[b];
+        bd.mu = (major_iter == 1) ? 10.0 : (d.mu_in ? d.mu_in : d.mu)[b];
+    }
     bd.scale = scale;
 #if defined(EXA_A_IN_LDS)
     SymRef<6, BR_BLOCK> A{my + BR_LDS_CONST * BR_BLOCK};
@@ -390,7 +438,11 @@ __global__ void __launch_bounds__(BR_BLOCK, EXA_BR_WAVES) k_branch_t(const Dev* 
 #endif
 
     double x[6], xl[6], xu[6], phi[4];
+#if defined(EXA_CONST_IN_REGS)
+    branch_start(ub, bnd, ZL ? rate_0 : d.rateA[b], x, xl, xu);
+#else
     branch_start(ub, bnd, d.rateA[b], x, xl, xu);
+#endif
     BranchStats st;
 #if defined(EXA_PROFILE_PHASES)
     st.tl = d.st_tl ? d.st_tl + (size_t)blockIdx.x * 128 : nullptr;   // (the diagnostic build keeps 64 branches per wave)

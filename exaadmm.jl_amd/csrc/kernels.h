@@ -239,6 +239,9 @@ __global__ void __launch_bounds__(BR_BLOCK, EXA_BR_WAVES) k_branch_t(const Dev* 
 #else
     __shared__ double lds[(BR_LDS_DOUBLES > 0 ? BR_LDS_DOUBLES : 1) * BR_BLOCK];
 #endif
+#if defined(EXA_PROFILE_PHASES)
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();   // first instruction of the wave
+#endif
     const Dev& d = *dp;
     int extra = 0;
     bool do_zl = false;
@@ -474,6 +477,7 @@ __global__ void __launch_bounds__(BR_BLOCK, EXA_BR_WAVES) k_branch_t(const Dev* 
     if (st.tl) {   // per-wave prologue / epilogue stamps (entries 123..127 of the timeline)
         unsigned long long t_stored;
         asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_stored) : : "memory");
+        st.tl[122] = t_start;
         st.tl[123] = t_entry;
         st.tl[124] = t_loaded;
         st.tl[125] = t_solved;

@@ -73,6 +73,16 @@ enum { TRON_RUN = 0, TRON_CONV = 4, TRON_WARN = 10, TRON_MAXMINOR = 20, TRON_MAX
 // SymMat owns its storage (registers / local memory); SymRef<N,STRIDE> views storage with an
 // element stride -- the GPU kernel points it into LDS laid out [entry][lane] (STRIDE = 64),
 // so lane-local matrices cost no VGPRs and every LDS access of a wave is conflict-free.
+// Host-only loop counters for tests/tools/count_solver_loops.py (how many trips do the searches of a model step make?).
+#if defined(EXA_HOST_COUNTERS) && !defined(__HIP_DEVICE_COMPILE__)
+extern "C" long long exa_cnt[16];
+#define EXA_CNT(i) (exa_cnt[i]++)
+#else
+#define EXA_CNT(i) ((void)0)
+#endif
+enum { CNT_CAUCHY = 0, CNT_CAUCHY_INTERP, CNT_CAUCHY_TRIP_IN, CNT_CAUCHY_TRIP_OUT, CNT_PRSRCH, CNT_PRSRCH_TRIP, CNT_FACE, CNT_CG,
+       CNT_ICFS_SLOW, CNT_CAUCHY_FIRST_OUT };
+
 template <int N>
 struct SymMat {
     double a[N * (N + 1) / 2];
@@ -194,9 +204,11 @@ EXA_BIG void cauchy(const double (&x)[N], const double (&xl)[N], const double (&
 
     bool interp;
     as_valid = false;
+    EXA_CNT(CNT_CAUCHY);
     gpstep<N>(x, xl, xu, -alpha, g, s);
     if (nrm2<N>(s) > delta) {
         interp = true;
+        EXA_CNT(CNT_CAUCHY_FIRST_OUT);
     } else {
         double q, gts;
         quad_model<N>(A, g, s, q, gts, as);
@@ -209,6 +221,7 @@ EXA_BIG void cauchy(const double (&x)[N], const double (&xl)[N], const double (&
     //   extrapolation : alpha grows 10x per trip while the step stays inside the region (up to the largest break
     //                   point); the last alpha that gave sufficient decrease is kept
     double brptmax = 0.0;
+    if (interp) EXA_CNT(CNT_CAUCHY_INTERP);
     if (!interp) {
         double mg[N];
         EXA_UNROLL
@@ -225,6 +238,7 @@ EXA_BIG void cauchy(const double (&x)[N], const double (&xl)[N], const double (&
         const bool inside = (nrm2<N>(s) <= delta);
         double q = 0.0, gts = 0.0;
         if (inside) quad_model<N>(A, g, s, q, gts, as);
+        if (inside) EXA_CNT(CNT_CAUCHY_TRIP_IN); else EXA_CNT(CNT_CAUCHY_TRIP_OUT);
         if (interp) {
             as_valid = inside;
             if (inside) search = (q > mu0 * gts);
@@ -343,6 +357,7 @@ EXA_BIG void icfs_masked(unsigned fr, const MA& A, ML& L, double (&id)[N])
         }
         if (chol_inplace<N>(L, id)) return;
     }
+    EXA_CNT(CNT_ICFS_SLOW);
 
     double wa2[N], wi2[N], rdv[N];
     EXA_UNROLL
@@ -468,6 +483,7 @@ EXA_BIG int trpcg_masked(unsigned fr, const MA& A, const double (&gf)[N], double
     const double tol2 = tol * tol, stol2 = stol * stol;   // norms are only compared: use squares
 
     for (int iters = 1; iters <= itermax; iters++) {
+        EXA_CNT(CNT_CG);
         EXA_UNROLL
         for (int i = 0; i < N; i++) z[i] = p[i];
         trsol_t<N>(L, id, z);
@@ -546,10 +562,12 @@ EXA_BIG void prsrch_masked(unsigned fr, double (&x)[N], const double (&xl)[N], c
     double alpha = 1.0;
     double brptmin, brptmax;
     breakpt<N>(x, xl, xu, w, brptmin, brptmax);
+    EXA_CNT(CNT_PRSRCH);
 
     bool search = true;
     bool wa1_current = false;   // wa1 = P[x + alpha w] - x for the CURRENT alpha (the accepted trial's step need not be projected twice)
     for (int guard = 0; search && alpha > brptmin && guard < 1100; guard++) {
+        EXA_CNT(CNT_PRSRCH_TRIP);
         gpstep<N>(x, xl, xu, alpha, w, wa1);
         symv<N>(A, wa1, wa2);
         mask_vec<N>(fr, wa2);
@@ -602,6 +620,7 @@ EXA_BIG void spcg(double (&x)[N], const double (&xl)[N], const double (&xu)[N], 
         if (fr == 0u) return;
 
         unsigned long long c0 = EXA_CLK();
+        EXA_CNT(CNT_FACE);
         icfs_masked<N>(fr, A, L, id);
         unsigned long long c1 = EXA_CLK();
         if (pc) pc[0] += c1 - c0;

@@ -13,9 +13,10 @@ L.exaadmm_debug_phase_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_
 g = syn.sized_like("case13659pegase", seed=0)
 env = pkg.AdmmEnv("syn", 5e1, 5e3, verbose=0, grid=g)
 mod = pkg.ModelAcopf(env)
-mod.run_fixed(30, first_major_iter=1, beta=1e3)
+nwarm = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+mod.run_fixed(nwarm, first_major_iter=1, beta=1e3)
 for rep in range(2):
-    norms, ms, msb = mod.run_fixed(1, first_major_iter=40 + rep, beta=1e3, time_branch=True)
+    norms, ms, msb = mod.run_fixed(1, first_major_iter=nwarm + 1 + rep, beta=1e3, time_branch=True)
     a, m, t = mod.branch_counters()
     Lp = ((g["nline"] + 63) // 64) * 64
     buf = np.zeros(13 * Lp, dtype=np.uint64)
@@ -25,7 +26,10 @@ for rep in range(2):
     print("k_branch %.3f ms; ticks: median %d max %d; auglag max %d" % (msb, np.median(t), t.max(), a.max()))
     light = cyc[12] == 2
     heavy = cyc[12] >= 4
-    for nm, sel in (("2 lone ticks", light), (">=4 lone ticks", heavy)):
+    one = cyc[12] == 1
+    for nm, sel in (("1 lone tick", one), ("2 lone ticks", light), (">=4 lone ticks", heavy)):
+        if not sel.any():
+            continue
         tot = cyc[:5, sel].sum(axis=0).mean()
         print("  %-22s n=%5d ticks %.1f total cyc %.0f (%.1f us @2.4GHz)  per tick %.0f | " % (nm, sel.sum(), t[sel].mean(), tot, tot / 2400.0, tot / t[sel].mean())
               + ", ".join("%s %.0f" % (names[q], cyc[q, sel].mean()) for q in range(13)))

@@ -27,7 +27,8 @@ for rep in range(3):
     clk = (tl & np.uint64(0x00ffffffffffffff)).astype(np.int64)
     act = (tl >> np.uint64(56)).astype(np.int64)
     stamps = clk[:, 123:127].copy()
-    clk = clk.copy(); clk[:, 123:127] = 0; act = act.copy(); act[:, 123:127] = 0
+    t_start = clk[:, 122].copy()
+    clk = clk.copy(); clk[:, 122:127] = 0; act = act.copy(); act[:, 122:127] = 0
     nt = (clk > 0).sum(axis=1) - 1          # ticks of the wave
     dur = np.array([clk[w, nt[w]] - clk[w, 0] for w in range(nw)])
     t0 = clk[:, 0][clk[:, 0] > 0].min()
@@ -38,6 +39,9 @@ for rep in range(3):
         first_tick = clk[ok, 0] - stamps[ok, 1]
         epi = stamps[ok, 3] - stamps[ok, 2]
         total = stamps[ok, 3] - stamps[ok, 0]
+        pre = stamps[ok, 0] - t_start[ok]
+        print("  wave start (first instruction) -> entry (loop control + launch geometry read): median %.0f max %.0f clocks; first wave start -> last wave start %.0f clocks"
+              % (np.median(pre), pre.max(), t_start[ok].max() - t_start[ok].min()))
         print("  in-kernel stamps per wave (clocks): entry->loads landed median %.0f max %.0f | loads landed->first tick median %.0f | solve end->stores landed median %.0f max %.0f | entry->stores landed median %.0f max %.0f"
               % (np.median(pro_load), pro_load.max(), np.median(first_tick), np.median(epi), epi.max(), np.median(total), total.max()))
     span = float(end - t0)

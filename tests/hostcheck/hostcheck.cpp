@@ -24,6 +24,12 @@ static void fill(BranchData& d, const double* param, const double* Y, double sca
     d.scale = scale;
 }
 
+#if defined(EXA_HOST_COUNTERS)
+extern "C" {
+long long exa_cnt[16] = {0};   // loop counters of tron_device.h (tests/tools/count_solver_loops.py)
+}
+#endif
+
 extern "C" double hostcheck_fgh(const double* x_, const double* param, const double* Y, double scale,
                                 double* g_, double* Afull)
 {

@@ -250,7 +250,8 @@ def main():
         pass
     occ = mod.branch_kernel_occupancy() if hasattr(mod, "branch_kernel_occupancy") else None
     branch_bytes = BYTES_PER_BRANCH_SOLVE * L
-    fused_zl = T == 1 and (L + 63) // 64 <= 2048 and not os.environ.get("EXAADMM_NO_ZLFUSE") and not os.environ.get("EXAADMM_NO_SPEC")
+    fused_zl = (T == 1 and (L + 63) // 64 <= int(os.environ.get("EXAADMM_ZLFUSE_MAX_WAVES", 1 << 30))
+                and not os.environ.get("EXAADMM_NO_ZLFUSE") and not os.environ.get("EXAADMM_NO_SPEC"))
     if fused_zl:
         # the launch also carries the generator update (128 B per generator) and the z / l / residual pass of the previous
         # iteration; of the latter only what the branch loads do not already bring counts: lz read + z, z_prev, l writes

@@ -110,6 +110,7 @@ struct exaadmm_handle {
     int *st_alt[3] = {nullptr, nullptr, nullptr};   // per-branch counters of the alternate set (auglag, minor, ticks)
     // fused z/l variant (kernels.h, k_branch_t<MP, true>): alternate v, per-block partial sums of the branch launch
     bool zl_on = false;
+    int zl_max_waves = 1 << 30;   // the fused variant is used up to this many 64-branch wavefronts (EXAADMM_ZLFUSE_MAX_WAVES: A/B)
     double *v_alt = nullptr, *partials_br = nullptr;
     // branch launches with at least this many wavefronts use k_branch_tp (two waves per SIMD).  0 = never, the default:
     // the variant measures 3-4.6x SLOWER (profiles/r02_two_waves_per_simd_experiments.txt); EXAADMM_TP_MIN_BLOCKS=1025
@@ -401,6 +402,7 @@ extern "C" int exaadmm_create(const exaadmm_grid* g, const exaadmm_params* p, in
         // z/l pass fused into the branch launch's prologue (A/B switch; needs the lane-group bus kernel, which carries
         // the reduction block)
         h->zl_on = h->spec_on && !h->bus_lane_kernel && (getenv("EXAADMM_NO_ZLFUSE") == nullptr);
+        if (const char* e = getenv("EXAADMM_ZLFUSE_MAX_WAVES")) h->zl_max_waves = atoi(e);
 #endif
     }
     TRY(upload_mupow_table());
@@ -1321,8 +1323,9 @@ static int spec_prepare(exaadmm_handle* h)
         }
         if ((rc = dev_alloc(h, &h->v_alt, (size_t)h->N))) return rc;
         {
-            // room for any branches-per-wave setting the fused variant can run with (it is used below 2048 64-branch waves)
-            const int nblk = std::min(std::max(h->d.La, 1), BR_BLOCK * 2048) + ((h->G > 0) ? (int)grid_for(h->G, BR_BLOCK).x : 0);
+            // room for any branches-per-wave setting the fused variant can run with
+            const int nblk = std::max(std::min(std::max(h->d.La, 1), BR_BLOCK * 2048), (int)grid_for(h->d.La, BR_BLOCK).x) +
+                             ((h->G > 0) ? (int)grid_for(h->G, BR_BLOCK).x : 0);
             if ((rc = dev_alloc(h, &h->partials_br, (size_t)nblk * 4))) return rc;
         }
         HIPCHK(hipMemcpyAsync(h->v_alt, h->d.v, (size_t)h->N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
@@ -1349,10 +1352,12 @@ static int spec_prepare(exaadmm_handle* h)
     a.st_auglag = h->st_alt[0];  a.st_minor = h->st_alt[1];  a.st_ticks = h->st_alt[2];
     b.u_in = h->u_alt;    b.ls1_in = h->ls1_alt;  b.ls2_in = h->ls2_alt;  b.mu_in = h->mu_alt;
     a.npartials = b.npartials = h->ew_blocks;
-    // (only while the branch launch is latency-bound: with more than ~2 waves queued per SIMD the prologue's memory
-    //  latency, at one resident wave per SIMD, costs more than the streaming kernel it replaces -- measured at 1M
-    //  branches: k_branch 0.43 -> 0.61 ms against 0.10 ms for k_fused_zl; +3 % at 20 467 and 88 207 branches)
-    if (h->zl_on && h->d.lane_order == nullptr && grid_for(h->d.La, BR_BLOCK).x <= 2048 && !use_tp(h)) {   // (size test in 64-branch waves)
+    // (at every size.  With the prologue written element by element -- eight dependent memory round trips per wave -- the
+    //  fused variant lost above ~2 waves queued per SIMD: 1M branches, k_branch 0.43 -> 0.61 ms against 0.10 ms for the
+    //  k_fused_zl it replaces.  With all loads ahead of the stores it wins there too: 1M branches 1 478 -> 1 529 it/s,
+    //  300 k branches 0.237 -> 0.226 ms per iteration; EXAADMM_ZLFUSE_MAX_WAVES=2048 restores the old size gate.)
+    if (h->zl_on && h->d.lane_order == nullptr && (int)grid_for(h->d.La, BR_BLOCK).x <= h->zl_max_waves && !use_tp(h) &&
+        (branch_blocks(h) <= BR_BLOCK * 2048 / BR_BLOCK || h->d.lpb == BR_BLOCK)) {   // (size test in 64-branch waves)
         // v follows the same parity as u: the bus launch of an odd iteration writes the alternate v, which the next
         // (even) iteration's branch launch reads
         a.v_in = h->d.v;   a.v = h->v_alt;

@@ -718,7 +718,10 @@ __global__ void k_bus(Dev d, double baseMVA, const Ctrl* ctrl)
 //   * the leader publishes mu1, mu2, w, theta through LDS and every lane writes the v entries
 //     of its own component from the registers it already holds.
 // Buses with more than BUS_W incident components are processed in chunks.
-constexpr int BUS_W = 8;
+#if !defined(EXA_BUS_W)
+#define EXA_BUS_W 8   // measured at 13 659 buses (kernel-trace average): 8 -> 12.8, 16 -> 13.5, 32 -> 15.5 us
+#endif
+constexpr int BUS_W = EXA_BUS_W;
 constexpr int BUS_BLOCK = 256;   // measured at 13 659 buses: 64 -> 15.1, 128 -> 14.5, 256 -> 12.4, 512 -> 11.9, 1024 -> 13.2 us; 512 loses 5 % of the non-branch time at 1M branches
 constexpr int BUS_REC = 16;  // doubles per record: (u,z,l,rho) x (p,q,w,theta) or (u,z,l,rho) x (pg,qg)
 enum { END_GEN = 0, END_FROM = 1, END_TO = 2 };

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Split the rocprofv3 kernel trace of `bench.py --steps K --warmup W [--prep P]` by the phases of the run, so that the
+trace's average kernel durations can be compared with the HIP-event figure of the bench line (which covers the timed
+region only; the plain --stats average also covers the cold preparation iterations and the two whole solves).
+usage: kernel_trace_split.py <kernel_trace.csv> [K=200] [W=20] [P=300]  ->  JSON on stdout"""
+import csv
+import json
+import sys
+
+import numpy as np
+
+f = sys.argv[1]
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+W = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+P = int(sys.argv[4]) if len(sys.argv) > 4 else 300
+rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+out = {"trace": f, "phases": "preparation %d | warm-up %d | timed region %d | event-bracketed pass %d | whole solves (rest)" % (P, W, K, K)}
+for key, tag in (("k_branch", "k_branch"), ("k_bus", "k_bus_group")):
+    d = np.array([(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if key in r["Kernel_Name"]])
+    cuts = [0, P, P + W, P + W + K, P + W + 2 * K, len(d)]
+    names = ["preparation", "warm_up", "timed_region", "event_bracketed_pass", "whole_solves"]
+    out[tag] = {"launches": int(len(d)), "average_us_all": float(d.mean())}
+    for n, a, b in zip(names, cuts[:-1], cuts[1:]):
+        if b > a:
+            out[tag][n] = {"launches": int(b - a), "average_us": float(d[a:b].mean()), "min_us": float(d[a:b].min()), "max_us": float(d[a:b].max())}
+print(json.dumps(out, indent=1))

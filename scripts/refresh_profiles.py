@@ -21,7 +21,7 @@ def line(f):
 
 names = {"bench_default": "bench", "bench_driver_cmd": "bench_driver_command_steps20", "bench_case1354pegase": "bench_case1354pegase",
          "bench_case_ACTIVSg70k": "bench_case_ACTIVSg70k", "bench_synthetic1M": "bench_synthetic1M", "bench_dist1": "bench_force_dist_one_rank",
-         "bench_mp4": "bench_mp_4_periods"}
+         "bench_mp4": "bench_mp_4_periods", "bench_case118": "bench_case118_real_file", "bench_case9": "bench_case9_real_file"}
 for k, v in names.items():
     f = os.path.join(src, k + ".log")
     if os.path.exists(f):
@@ -39,7 +39,7 @@ for d, wl, steps, G, L in (("pmc_case13659pegase", "synthetic-case13659pegase-si
     if not os.path.isdir(p):
         continue
     out.update(json.loads(subprocess.check_output([sys.executable, os.path.join(ROOT, "scripts", "summarize_pmc.py"), p, wl, str(steps)])))
-    fused = (L + 63) // 64 <= 2048
+    fused = True   # the z/l pass rides in the branch launch at every size (since the load-first prologue)
     out[wl]["k_branch"]["algorithmic_bytes"] = int(824.0 * L + 192.0 * G) if fused else int(568.0 * L)
     out[wl]["k_branch"]["algorithmic_bytes_note"] = ("fused launch: 568 B per branch + 128 B per generator + the unshared part of the z/l pass (32 B per vector element) = 824 L + 192 G"
                                                      if fused else "568 B per branch")

@@ -176,6 +176,25 @@ def test_multi_period_fused_loop_matches_oracle(pkg, syn, oracle):
         assert np.abs(mod.models[t].solution.u_curr - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max())
 
 
+def test_multi_period_solve_on_the_118_bus_system_matches_oracle(pkg, oracle):
+    """Real data: tests/golden/case118.m over 3 load levels with generator ramp coupling, cold start, fused loop:
+    outer / cumulative iteration counts, objective and every period's u as the CPU oracle."""
+    from conftest import CASE118
+    grid = oracle.grid_from_matpower(CASE118)
+    T = 3
+    al = np.array([1.0, 1.006, 0.992])
+    pd = np.stack([grid["Pd"] * a for a in al], 1)
+    qd = np.stack([grid["Qd"] * a for a in al], 1)
+    kw = dict(outer_iterlim=4, inner_iterlim=400, rho_pq=4e2, rho_va=4e4, warm_start=False)
+    env2, mod = pkg.solve_mpacopf(CASE118, load=(pd, qd), end_period=T, **kw)
+    om = oracle.solve_mpacopf(grid, pd, qd, **kw)
+    assert (mod.info.outer, mod.info.cumul) == (om.info.outer, om.info.cumul)
+    assert abs(mod.info.objval - om.info.objval) <= 1e-6 * abs(om.info.objval)
+    for t in range(T):
+        ref = om.periods[t].sol["u_curr"]
+        assert np.abs(mod.models[t].solution.u_curr - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max())
+
+
 def test_single_period_multi_period_handle_equals_plain_handle(pkg, syn):
     """Edge: T = 1 has no ramp block and must reproduce the single-period model bit for bit."""
     grid = syn.sized_like("case118", seed=1)

@@ -480,6 +480,37 @@ def test_non_finite_input_does_not_stall_the_branch_kernel(pkg, syn):
     assert t[b] <= 2
 
 
+def test_rolling_horizon_on_the_118_bus_system_matches_oracle(pkg, oracle, tmp_path):
+    """solve_acopf_rolling (row f3) on real data: 3 periods of tests/golden/case118.m (first period = the reference's
+    anchor solve, 20 / 1232), ramp-limited generator bounds and warm starts with the persistent line multipliers --
+    per-period status, iteration counts and objective as the same procedure on the CPU oracle."""
+    case118 = os.path.join(GOLDEN, "case118.m")
+    g = oracle.grid_from_matpower(case118)
+    T = 3
+    fac = np.array([1.0, 1.004, 0.997])
+    pd = np.outer(g["Pd"], fac)
+    qd = np.outer(g["Qd"], fac)
+    np.savetxt(str(tmp_path / "load.Pd"), pd)
+    np.savetxt(str(tmp_path / "load.Qd"), qd)
+    kw = dict(rho_pq=4e2, rho_va=4e4, outer_iterlim=25, outer_eps=2e-5, tight_factor=1.0)
+    env, mod, res = pkg.solve_acopf_rolling(case118, load_prefix=str(tmp_path / "load"), start_period=1, end_period=T,
+                                            ramp_ratio=0.02, **kw)
+    assert (res[0]["status"], res[0]["outer"], res[0]["cumul"]) == ("Solved", 20, 1232)
+    ref = oracle.OracleModel(g, 4e2, 4e4, outer_iterlim=25, outer_eps=2e-5)
+    ramp = 0.02 * g["pgmax"]
+    for t in range(T):
+        ref.g["Pd"][:] = pd[:, t]
+        ref.g["Qd"][:] = qd[:, t]
+        info = ref.admm_two_level()
+        assert res[t]["status"] == ("Solved" if info.status == 1 else "IterationLimit")
+        assert (res[t]["outer"], res[t]["cumul"]) == (info.outer, info.cumul), (t, res[t], info.outer, info.cumul)
+        assert abs(res[t]["objval"] - info.objval) <= 1e-6 * abs(info.objval)
+        pg = ref.sol["u_curr"][0:2 * g["ngen"]:2]
+        ref.pgmin_curr[:] = np.maximum(g["pgmin"], pg - ramp)
+        ref.pgmax_curr[:] = np.minimum(g["pgmax"], pg + ramp)
+    assert np.abs(mod.solution.u_curr - ref.sol["u_curr"]).max() <= 1e-6 * max(1.0, np.abs(ref.sol["u_curr"]).max())
+
+
 @pytest.mark.parametrize("case,cumul,objval,tol", [("case9.m", 705, 5303.435, 1e-2), ("case118.m", 1232, 129645.676, 0.13)])
 def test_plain_c_driver_solves_the_reference_anchors(case, cumul, objval, tol):
     """tools/exaadmm_solve (C, no Python in the loop): native MATPOWER loader + C ABI + fused two-level

@@ -278,6 +278,10 @@ static int dist_enqueue_iteration(exaadmm_handle* h, Ctrl* c, int major_iter, do
     launch_bus(h, c);
     if ((rc = dist_exchange(h, 2, 3))) return rc;
     launch_fused_zl(h, beta, c);
+    if (h->dist->comm == nullptr) {
+        launch_final(h, c, h->d_sums);   // one partition, nothing to all-reduce: the reduction advances the loop control itself
+        return 0;
+    }
     launch_final(h, nullptr, h->d_sums);
     if ((rc = dist_allreduce_sums(h))) return rc;
     if (c) hipLaunchKernelGGL(k_ctrl_step, dim3(1), dim3(64), 0, h->stream, h->d_sums, c);

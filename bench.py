@@ -143,10 +143,17 @@ def main():
     ap.add_argument("--cpu-solve-budget", type=float, default=30.0,
                     help="seconds the CPU port may spend on the whole solve of the full_solve leg (cut off = bounded sample)")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU code path even with one rank")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="N > 1: weak = N areas of the case's size, one per GPU (default; --case case_ACTIVSg70k is north_star's "
+                         "target configuration); strong = ONE grid of the case's size sharded N ways")
     ap.add_argument("--prep", type=int, default=300,
                     help="untimed preparation iterations that define the benchmark state (the ADMM state after PREP inner "
                          "iterations from init_solution!): the first iterations of a cold start are several times heavier "
                          "than the thousands that follow in a solve; 0 = time from the cold start")
+    ap.add_argument("--repeats", type=int, default=0,
+                    help="how many times the K-step timed region is repeated (the median is reported); 0 = as many as fill "
+                         "--gpu-seconds of GPU time")
+    ap.add_argument("--gpu-seconds", type=float, default=1.0)
     ap.add_argument("--periods", type=int, default=1,
                     help="T > 1: multi-period ACOPF (SURVEY.md §8 f4) over T load levels of the same grid, one time-expanded device model")
     args = ap.parse_args()
@@ -216,15 +223,29 @@ def main():
     if args.warmup > 0:
         mod.run_fixed(args.warmup, first_major_iter=done + 1, beta=beta)
         done += args.warmup
-    # timed region: exactly K steps, nothing but the iteration's own kernels on the stream.  (Round 1 bracketed every
-    # branch launch of the timed region with a HIP event pair: the rocprofv3 trace shows 5.7 us of idle queue on either
-    # side of the kernel for them, i.e. +11 us on a 93 us iteration -- profiles/r02_kernel_gaps.txt.)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    norms, ms_total, _ = mod.run_fixed(args.steps, first_major_iter=done + 1, beta=beta, time_branch=False)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    # timed region: exactly K steps, nothing but the iteration's own kernels on the stream, bracketed by synchronisation on
+    # both sides.  (Round 1 bracketed every branch launch of the timed region with a HIP event pair: the rocprofv3 trace
+    # shows 5.7 us of idle queue on either side of the kernel for them -- profiles/r02_a_kernel_gaps_bench_with_events.txt.)
+    # The region is REPEATED (the loop simply goes on: consecutive K-step stretches of the same inner loop) until the GPU
+    # has been busy for about a second, and the MEDIAN region is reported: K = 20 steps last 1.6 ms, too short for the
+    # driver's smi sampling to see and at the mercy of one scheduling hiccup.
+    def region(first):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nrm, ms, _ = mod.run_fixed(args.steps, first_major_iter=first, beta=beta, time_branch=False)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, nrm, ms
+
+    regions = []
+    dt, norms, ms_total = region(done + 1)
     done += args.steps
+    regions.append(dt)
+    repeats = 1 if args.repeats == 1 else (args.repeats if args.repeats > 1 else max(1, min(4000, int(round(args.gpu_seconds / max(dt, 1e-6))))))
+    for _ in range(repeats - 1):
+        dt_i, norms, ms_total = region(done + 1)
+        done += args.steps
+        regions.append(dt_i)
+    dt = sorted(regions)[len(regions) // 2]
     # the dominant kernel's duration: HIP events around each of its launches on the launch stream, over the K steps
     # that FOLLOW the timed region (same steady state), so that the events do not sit inside the figure they explain
     torch.cuda.synchronize()
@@ -239,19 +260,26 @@ def main():
         G, L, B = G * T, L * T, B * T   # algorithmic bytes of the time-expanded model (ramp block: +88 B per generator and period)
     else:
         a_it, m_it = mod.branch_stats()
-    # HBM traffic of the dominant kernel from the PMC passes committed under profiles/ (collected
-    # with rocprofv3 on this same command; bench.py itself cannot collect counters)
-    traffic = valu_busy = pmc_build = None
+    # HBM traffic of the dominant kernel: rocprofv3 --pmc passes of THIS command (scripts/collect_pmc.sh; bench.py itself
+    # cannot collect counters), summarised per workload in profiles/r03_pmc_summary.json together with the version string
+    # of the library they were taken from.  An entry taken from other code than the library loaded now is refused.
+    traffic = valu_busy = None
+    lib_version = pkg.library().exaadmm_version().decode()
+    pmc_file = os.path.join("profiles", "r03_pmc_summary.json")
+    traffic_source = "none: %s has no entry for this workload" % pmc_file
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
+        pmc = json.load(open(os.path.join(ROOT, pmc_file)))
         kb = pmc.get(workload, {}).get("k_branch", {})
-        traffic, valu_busy, pmc_build = kb.get("traffic_bytes"), kb.get("valu_busy"), pmc.get("build")
-    except Exception:
-        pass
+        if kb and pmc.get("library_version") != lib_version:
+            traffic_source = "refused: %s was collected with %r, the loaded library is %r" % (pmc_file, pmc.get("library_version"), lib_version)
+        elif kb:
+            traffic, valu_busy = kb.get("traffic_bytes"), kb.get("valu_busy")
+            traffic_source = "%s (library %s, repository commit %s)" % (pmc_file, pmc.get("library_version"), pmc.get("commit"))
+    except Exception as e:
+        traffic_source = "none: %s unreadable (%s)" % (pmc_file, e)
     occ = mod.branch_kernel_occupancy() if hasattr(mod, "branch_kernel_occupancy") else None
     branch_bytes = BYTES_PER_BRANCH_SOLVE * L
-    fused_zl = (T == 1 and (L + 63) // 64 <= int(os.environ.get("EXAADMM_ZLFUSE_MAX_WAVES", 1 << 30))
-                and not os.environ.get("EXAADMM_NO_ZLFUSE") and not os.environ.get("EXAADMM_NO_SPEC"))
+    fused_zl = (T == 1 and not os.environ.get("EXAADMM_NO_SPEC") and os.environ.get("EXAADMM_BUS_KERNEL") != "lane")
     if fused_zl:
         # the launch also carries the generator update (128 B per generator) and the z / l / residual pass of the previous
         # iteration; of the latter only what the branch loads do not already bring counts: lz read + z, z_prev, l writes
@@ -262,6 +290,14 @@ def main():
         "metric": "ADMM inner iterations/sec", "value": its, "unit": "iterations/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": data,
+        "value_definition": "K / (median wall time of a K-step timed region): fixed-count inner iterations of outer iteration 1, "
+                            "no early break, from the ADMM state after --prep untimed iterations; `repeats` consecutive regions "
+                            "were timed.  The reference's own metric (cumul / time_overall of a whole solve_acopf, "
+                            "print_statistics.jl:12) is value_reference_metric / full_solve",
+        "repeats": len(regions),
+        "regions": {"first": args.steps / regions[0], "median": its, "last": args.steps / regions[-1],
+                    "min": args.steps / max(regions), "max": args.steps / min(regions), "unit": "iterations/s",
+                    "gpu_seconds": sum(regions)},
         "config": {"workload": workload, "ngen": G, "nline": L, "nbus": B, "rho_pq": params["rho_pq"],
                    "rho_va": params["rho_va"], "scale": params["scale"], "tight_factor": tight,
                    "mode": "fixed-count inner iterations, no early break", "parallelism": "1 GPU",
@@ -275,9 +311,9 @@ def main():
                      # HBM is the wrong roof at the named sizes (state is Infinity-Cache resident, the kernel is the FP64
                      # dependent-issue chain of its slowest lane): occupancy and VALU utilisation say how it is bound
                      "waves_per_simd": occ, "waves_launched_per_simd": ((L + 63) // 64) / 1024.0,
-                     "valu_busy": valu_busy, "pmc_build": pmc_build,
+                     "valu_busy": valu_busy, "traffic_source": traffic_source, "library_version": lib_version,
                      "note": "latency/FP64-issue bound: state is Infinity-Cache resident; traffic / valu_busy come from the "
-                             "rocprofv3 --pmc passes committed under profiles/ (r02_pmc_summary.json); see DESIGN.md"},
+                             "rocprofv3 --pmc passes of this command (traffic_source); see DESIGN.md"},
         "solver": {"avg_auglag_it": a_it, "avg_tron_minor_it": m_it, "primres": float(norms[0]),
                    "device_ms_total": ms_total, "ms_per_step_with_kernel_events": 1e3 * dt_with_events / args.steps},
     }
@@ -304,6 +340,7 @@ def main():
                 first = cur
             fs = cur
             mod2.close()
+        out["value_reference_metric"] = fs["iterations_per_s"]
         fs["first_run_time_overall_s"] = first["time_overall_s"]
         fs["definition"] = "cumul / time_overall of solve_acopf(outer_iterlim=%d, outer_eps=%g, inner_iterlim=1000), second of two solves" % (outer_lim, outer_eps)
         out["full_solve"] = fs

@@ -45,7 +45,7 @@ class Grid(C.Structure):
                  ("index_base", C.c_int32), ("baseMVA", C.c_double)] +
                 [(n, c_double_p) for n in _F64] + [("brBusIdx", c_i64_p)] +
                 [(n, c_double_p) for n in _BUS] + [(n, c_i64_p) for n in _IDX] +
-                [("nline_active", C.c_int64), ("nbus_active", C.c_int64)])
+                [("nline_owned", C.c_int64)])
 
 
 class Parameters(C.Structure):
@@ -104,6 +104,13 @@ def _preload_torch_hip_runtime():
         return None
 
 
+def bound_hip_runtime():
+    """path and version of the HIP runtime the loaded library is bound to, and the HIP version it was compiled against"""
+    buf = C.create_string_buffer(1024)
+    library().exaadmm_hip_runtime_info(buf, 1024)
+    return buf.value.decode()
+
+
 def library():
     """Load libexaadmm_hip.so.  Raises if it has not been built: no fallback."""
     global _LIB
@@ -123,10 +130,15 @@ def library():
                            "its branch kernel cannot be trusted" % (LIB_PATH, ver))
     L.exaadmm_last_error.restype = C.c_char_p
     L.exaadmm_dist_rccl_path.restype = C.c_char_p
-    # start the library's own HIP runtime NOW (it is not PyTorch's: torch bundles a private copy).  Starting torch's
-    # runtime between this library's load and its first HIP call leaves this one without a device.
+    # start the HIP runtime the library is bound to NOW, at a defined moment (with PyTorch installed that is torch's bundled
+    # runtime, mapped above; otherwise the system one), and check that it is a runtime the library's code can talk to
     L.exaadmm_device_count.restype = C.c_int
     L.exaadmm_device_count()
+    L.exaadmm_hip_runtime_info.argtypes = [C.c_char_p, C.c_int64]
+    buf = C.create_string_buffer(1024)
+    if L.exaadmm_hip_runtime_info(buf, 1024) != 0:
+        raise ExaAdmmError("HIP runtime / library mismatch: %s; set EXAADMM_NO_TORCH_RUNTIME=1 to use the system runtime"
+                           % buf.value.decode())
     L.exaadmm_io_error.restype = C.c_char_p
     L.exaadmm_default_params.argtypes = [C.POINTER(Parameters)]
     L.exaadmm_default_params.restype = None
@@ -157,15 +169,12 @@ def library():
     L.exaadmm_branch_stats.argtypes = [H, c_double_p, c_double_p]
     L.exaadmm_download_branch_counters.argtypes = [H, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                                    C.POINTER(C.c_int32), C.c_int64]
-    L.exaadmm_set_branch_lane_order.argtypes = [H, C.POINTER(C.c_int32), C.c_int64]
     L.exaadmm_branch_kernel_occupancy.argtypes = [H, C.POINTER(C.c_int)]
     L.exaadmm_run_inner.argtypes = [H, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int), c_double_p]
     L.exaadmm_solve_two_level.argtypes = [H, C.POINTER(Info)]
     L.exaadmm_run_fixed.argtypes = [H, C.c_int, C.c_int, C.c_double, c_double_p, c_double_p, c_double_p]
     L.exaadmm_set_stream.argtypes = [H, C.c_void_p]
     L.exaadmm_set_async.argtypes = [H, C.c_int]
-    L.exaadmm_set_active.argtypes = [H, C.c_int64, C.c_int64]
-    L.exaadmm_set_owned_mask.argtypes = [H, C.POINTER(C.c_uint8), C.c_int64]
     L.exaadmm_set_halo_index.argtypes = [H, C.c_int, C.POINTER(C.c_int32), c_i64_p, C.c_int64]
     L.exaadmm_halo_pack.argtypes = [H, C.c_int, C.c_void_p]
     L.exaadmm_halo_unpack.argtypes = [H, C.c_int, C.c_void_p]
@@ -176,12 +185,13 @@ def library():
     L.exaadmm_ctrl_read.argtypes = [H, C.POINTER(C.c_int), C.POINTER(C.c_int), c_double_p]
     L.exaadmm_ctrl_end.argtypes = [H]
     L.exaadmm_dist_unique_id.argtypes = [C.c_char_p, C.c_int64]
-    L.exaadmm_dist_attach.argtypes = [H, C.c_int, C.c_int, C.c_char_p, C.c_int64, C.c_int64, c_i64_p]
+    L.exaadmm_dist_prepare.argtypes = [H, C.c_int, C.c_int, C.c_int64, c_i64_p, c_i64_p]
+    L.exaadmm_dist_connect.argtypes = [H, C.c_char_p, C.c_int64]
+    L.exaadmm_dist_attach.argtypes = [H, C.c_int, C.c_int, C.c_char_p, C.c_int64, C.c_int64, c_i64_p, c_i64_p]
+    L.exaadmm_dist_exchange_count.argtypes = []
+    L.exaadmm_dist_exchange_count.restype = C.c_int64
     L.exaadmm_dist_detach.argtypes = [H]
     L.exaadmm_dist_selftest.argtypes = [H, C.c_int64, c_double_p]
-    L.exaadmm_dist_run_inner.argtypes = [H, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int), c_double_p]
-    L.exaadmm_dist_run_fixed.argtypes = [H, C.c_int, C.c_int, C.c_double, c_double_p, c_double_p]
-    L.exaadmm_dist_norm_z.argtypes = [H, c_double_p]
     L.exaadmm_mp_create.argtypes = [C.POINTER(Grid), C.POINTER(Parameters), C.c_int, c_double_p, c_double_p,
                                     C.c_double, C.c_int, C.POINTER(H)]
     L.exaadmm_mp_periods.argtypes = [H]
@@ -218,8 +228,7 @@ def _as_grid_arrays(g):
         out[k] = np.ascontiguousarray(g[k], dtype=np.int64)
     out["ngen"], out["nline"], out["nbus"] = int(g["ngen"]), int(g["nline"]), int(g["nbus"])
     out["baseMVA"] = float(g["baseMVA"])
-    out["nline_active"] = int(g.get("nline_active", 0))
-    out["nbus_active"] = int(g.get("nbus_active", 0))
+    out["nline_owned"] = int(g.get("nline_owned", 0))
     return out
 
 
@@ -307,7 +316,7 @@ class ModelAcopf:
         self.gen_start, self.line_start = 1, 2 * self.ngen + 1   # 1-based like the reference
         cg = Grid()
         cg.ngen, cg.nline, cg.nbus, cg.index_base, cg.baseMVA = self.ngen, self.nline, self.nbus, 0, g["baseMVA"]
-        cg.nline_active, cg.nbus_active = g.get("nline_active", 0), g.get("nbus_active", 0)
+        cg.nline_owned = g.get("nline_owned", 0)
         for k in Grid._F64 + Grid._BUS:
             setattr(cg, k, _dp(g[k]))
         for k in Grid._IDX + ("brBusIdx",):
@@ -388,13 +397,6 @@ class ModelAcopf:
         w = C.c_int()
         _check(library().exaadmm_branch_kernel_occupancy(self._h, C.byref(w)), "exaadmm_branch_kernel_occupancy")
         return w.value
-
-    def set_branch_lane_order(self, order):
-        if order is None:
-            _check(library().exaadmm_set_branch_lane_order(self._h, None, 0), "lane order")
-            return
-        o = np.ascontiguousarray(order, dtype=np.int32)
-        _check(library().exaadmm_set_branch_lane_order(self._h, o.ctypes.data_as(C.POINTER(C.c_int32)), o.size), "lane order")
 
     def run_fixed(self, iters, first_major_iter=2, beta=None, time_branch=False):
         """K inner iterations without convergence test; returns (norms, ms_total, ms_branch)."""

@@ -25,9 +25,8 @@ namespace exa {
 // Problem constants of one branch.  lam/rho/xt are rows 1-8 / 9-16 / 17-24 of the
 // reference's membuf, ls1/ls2/mu rows 25/26/27 (acopf_auglag_linelimit_kernel_gpu.jl:49-79).
 // Y = YffR YffI YftR YftI YttR YttI YtfR YtfI.
-// BranchData owns the 32 read-only constants; BranchDataRef<STRIDE> views them in storage with
-// an element stride (the kernel stages them in LDS as [k][lane], STRIDE = 64).  The three
-// values the augmented-Lagrangian loop updates stay in registers either way.
+// BranchData owns the 32 read-only constants and the three values the augmented-Lagrangian loop
+// updates; all of it lives in registers.
 struct BranchData {
     double lam_[8], rho_[8], xt_[8], Y_[8];
     double ls1, ls2, mu, scale;
@@ -35,41 +34,37 @@ struct BranchData {
     EXA_HD double rho(int k) const { return rho_[k]; }
     EXA_HD double xt(int k) const { return xt_[k]; }
     EXA_HD double Y(int k) const { return Y_[k]; }
-    EXA_HD void fence() const {}
-};
-
-// The same 32 constants left where they already are -- the planes of l, rho, v, z and Y in global memory (L2 / Infinity
-// Cache resident between the evaluations of one solve) -- and fetched again by every objective / derivative evaluation.
-// Costs no registers outside the evaluations: the throughput variant of the branch kernel (k_branch_tp, two waves per
-// SIMD) uses it.  fence() is a compiler-level barrier at the start of an evaluation: without it the loads are
-// loop-invariant and would be hoisted back into registers for the whole solve.
-struct BranchDataGlobal {
-    // plane 0 of the branch part of each array: UNIFORM pointers (scalar registers; plane k is Lp further), and the
-    // lane's branch index as the only per-lane address register (global_load with scalar base + 32-bit lane offset)
-    const double *pl, *prho, *pv, *pz, *pY;
-    int Lp;
-    unsigned b;
-    double ls1, ls2, mu, scale;
-    EXA_HD double lam(int k) const { return (pl + k * Lp)[b]; }
-    EXA_HD double rho(int k) const { return (prho + k * Lp)[b]; }
-    EXA_HD double xt(int k) const { return (pv + k * Lp)[b] - (pz + k * Lp)[b]; }
-    EXA_HD double Y(int k) const { return (pY + k * Lp)[b]; }
-#if defined(__HIP_DEVICE_COMPILE__)
-    EXA_HD void fence() const { asm volatile("" ::: "memory"); }
+#if defined(EXA_PARK_CONST) && defined(__HIP_DEVICE_COMPILE__)
+    // The 32 read-only constants are only consumed by the objective / derivative evaluations.  A copy is parked in LDS
+    // ([entry][lane], conflict-free) when the solve starts; before the model step (two thirds of a trip, which never looks
+    // at them) the register copies are dropped, after it they are fetched back: 64 registers less at the solver's
+    // pressure peak.
+    __device__ __forceinline__ void park(double* p) const
+    {
+        EXA_UNROLL
+        for (int k = 0; k < 8; k++) {
+            p[k * 64] = lam_[k];
+            p[(8 + k) * 64] = rho_[k];
+            p[(16 + k) * 64] = xt_[k];
+            p[(24 + k) * 64] = Y_[k];
+        }
+        asm volatile("" ::: "memory");
+    }
+    __device__ __forceinline__ void fetch(const double* p)
+    {
+        asm volatile("" ::: "memory");
+        EXA_UNROLL
+        for (int k = 0; k < 8; k++) {
+            lam_[k] = p[k * 64];
+            rho_[k] = p[(8 + k) * 64];
+            xt_[k] = p[(16 + k) * 64];
+            Y_[k] = p[(24 + k) * 64];
+        }
+    }
 #else
-    EXA_HD void fence() const {}
+    EXA_HD void park(double*) const {}
+    EXA_HD void fetch(const double*) {}
 #endif
-};
-
-template <int STRIDE>
-struct BranchDataRef {
-    const double* p;  // 32 entries: lam[8] rho[8] xt[8] Y[8]
-    double ls1, ls2, mu, scale;
-    EXA_HD double lam(int k) const { return p[k * STRIDE]; }
-    EXA_HD double rho(int k) const { return p[(8 + k) * STRIDE]; }
-    EXA_HD double xt(int k) const { return p[(16 + k) * STRIDE]; }
-    EXA_HD double Y(int k) const { return p[(24 + k) * STRIDE]; }
-    EXA_HD void fence() const {}
 };
 
 // Run-time parameters of the augmented-Lagrangian loop, and the TRON driver constants.  The driver
@@ -106,9 +101,9 @@ EXA_HD double mu_pow(const MuPowTable& t, double mu, bool nine)
 // Default (fast) device build: the compiler may fuse the multiply-add pairs of the objective / gradient / Hessian
 // evaluation (252 + 234 of the kernel's 1 930 separate multiplies / adds become 248 fused ones; +2.8 % iterations/s at
 // 13 659 buses).  Like the explicit fma() of the TRON algebra this rounds once where the CPU path rounds twice, so it is
-// off in the exact-arithmetic build (the parity instrument) and -DEXA_NO_CONTRACT_FGH switches it off for A/B runs.
+// off in the exact-arithmetic build (the parity instrument).
 // The rest of the library (bus update, z / l / residual pass, generators) stays at -ffp-contract=off.
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(EXA_EXACT_ORACLE_ARITH) && !defined(EXA_NO_CONTRACT_FGH)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(EXA_EXACT_ORACLE_ARITH)
 #define EXA_CONTRACT_FGH 1
 #pragma clang fp contract(fast)
 #endif
@@ -165,7 +160,6 @@ EXA_HD void flows_from_trig(const D& d, const FlowTrig& t, double (&phi)[4])
 template <class D>
 EXA_HD void branch_flows(const D& d, const double (&x)[6], double (&phi)[4], double (&sc)[2])
 {
-    d.fence();
     FlowTrig t;
     angle_sincos(x, sc[0], sc[1]);
     flow_trig(d, x, sc[0], sc[1], t);
@@ -197,7 +191,6 @@ EXA_HD double objective_from_flows(const D& d, const double (&x)[6], const FlowT
 template <class D>
 EXA_BIG double branch_f(const D& d, const double (&x)[6], double (&phi)[4], double (&sc)[2])
 {
-    d.fence();
     FlowTrig t;
     angle_sincos(x, sc[0], sc[1]);
     flow_trig(d, x, sc[0], sc[1], t);
@@ -210,7 +203,6 @@ EXA_BIG double branch_f(const D& d, const double (&x)[6], double (&phi)[4], doub
 template <class D>
 EXA_HD double branch_f_known(const D& d, const double (&x)[6], const double (&phi)[4], const double (&sc)[2])
 {
-    d.fence();
     FlowTrig t;
     flow_trig(d, x, sc[0], sc[1], t);
     return objective_from_flows(d, x, t, phi);
@@ -321,7 +313,6 @@ template <class D>
 EXA_BIG void branch_g(const D& d, const double (&x)[6], const double (&phi)[4], const double (&scs)[2],
                       double (&g)[6], GradParts& q)
 {
-    d.fence();
 #if defined(EXA_EXACT_ORACLE_ARITH)
     (void)phi;
     (void)scs;
@@ -474,8 +465,9 @@ struct BranchStats {
 // when the multipliers changed (new subproblem).
 template <class D, class MA, class ML>
 EXA_HD void branch_solve(D& d, const BranchOptions& o, const MuPowTable& pw, double (&x)[6], const double (&xl)[6],
-                         const double (&xu)[6], MA& A, ML& L, double (&phi)[4], BranchStats& stats)
+                         const double (&xu)[6], MA& A, ML& L, double (&phi)[4], BranchStats& stats, double* park = nullptr)
 {
+    d.park(park);
     TronState<6> st;
     double g[6];
     double scs[2];             // sin, cos of the angle difference at the accepted x
@@ -514,13 +506,9 @@ EXA_HD void branch_solve(D& d, const BranchOptions& o, const MuPowTable& pw, dou
             // ONE evaluation site for both cases (a second inlined copy would be executed one after
             // the other whenever a wavefront holds lanes of both kinds)
             branch_g(d, x, phi, scs, g, gp);
-#if !defined(EXA_LAZY_H)
-            // The Hessian is assembled with every gradient although the last evaluation of a TRON solve
-            // does not need it: deferring it behind the projected-gradient test keeps ~50 intermediates
-            // alive across the test (+90 registers at the kernel's pressure peak -> scratch spills) and
-            // measures 7 % SLOWER (-DEXA_LAZY_H).
+            // (the Hessian is assembled with every gradient of a new subproblem: deferring it behind the model step
+            //  kept ~50 intermediates alive, +90 registers at the pressure peak, and measured 7 % slower)
             branch_h(d, x, gp, A);
-#endif
             if (restart) {
                 // task START: f, g, H at x; delta0 = ||g||  (tron_linelimit_kernel.jl:66-106)
                 it++;
@@ -539,10 +527,8 @@ EXA_HD void branch_solve(D& d, const BranchOptions& o, const MuPowTable& pw, dou
         unsigned long long t1 = EXA_TICK();
         stats.cyc[0] += t1 - t0;
         if (fin == TRON_RUN) {
-#if defined(EXA_LAZY_H)
-            if (refresh) branch_h(d, x, gp, A);
-#endif
             tron_compute<6>(st, x, xl, xu, A, L, g, o.cgtol, 6);
+            d.fetch(park);
             unsigned long long t2 = EXA_TICK();
             stats.cyc[1] += t2 - t1;
             const double ftrial = branch_f(d, x, phit, scst);

@@ -6,6 +6,8 @@
 #include "exaadmm_hip.h"
 #include "kernels.h"
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -93,8 +95,11 @@ struct exaadmm_handle {
     // gathered from (from-bus for own branches, to-bus for ghosts) so that the bus kernel's
     // gathers of consecutive buses hit consecutive elements of the planes.
     std::vector<int> perm;
-    unsigned char* d_owned = nullptr;
-    int* d_lane_order = nullptr;
+    // per reference branch: 0 = both ends on this handle's buses, 1 = only the from-end, 2 = only the to-end (a partition's
+    // cut branches; the other end's bus update runs on a peer)
+    std::vector<char> cut_side;
+    double* d_busc = nullptr;   // rho-only constants of the bus update (k_bus_const); recomputed when rho changes
+    bool busc_dirty = true;
     // hipGraph of one batch of fused inner iterations (exaadmm_run_inner); rebuilt when anything
     // baked into its kernel arguments changes (parameters, active counts, masks, lane order)
     hipGraphExec_t batch_graph = nullptr;
@@ -103,19 +108,14 @@ struct exaadmm_handle {
     bool residual_vectors_valid = false;
     bool async_mode = false;
     bool bus_lane_kernel = false;
-    // speculative branch launch (kernels.h, k_branch_t): second set of the buffers the branch kernel writes,
-    // the two Dev variants (odd / even iteration) on host and device, a pinned word for the batch base
+    // speculative loop (kernels.h, k_branch_t<MP, true>): second set of the buffers the branch kernel writes,
+    // the two Dev variants (odd / even iteration) on host and device, a pinned word for the batch base.
+    // EXAADMM_NO_SPEC=1 (A/B switch) runs the plain four-launch loop instead.
     bool spec_on = false;
     double *u_alt = nullptr, *ls1_alt = nullptr, *ls2_alt = nullptr, *mu_alt = nullptr;
     int *st_alt[3] = {nullptr, nullptr, nullptr};   // per-branch counters of the alternate set (auglag, minor, ticks)
-    // fused z/l variant (kernels.h, k_branch_t<MP, true>): alternate v, per-block partial sums of the branch launch
-    bool zl_on = false;
-    int zl_max_waves = 1 << 30;   // the fused variant is used up to this many 64-branch wavefronts (EXAADMM_ZLFUSE_MAX_WAVES: A/B)
+    // (the z/l pass of an iteration rides in the NEXT branch launch's prologue: alternate v, per-block partial sums)
     double *v_alt = nullptr, *partials_br = nullptr;
-    // branch launches with at least this many wavefronts use k_branch_tp (two waves per SIMD).  0 = never, the default:
-    // the variant measures 3-4.6x SLOWER (profiles/r02_two_waves_per_simd_experiments.txt); EXAADMM_TP_MIN_BLOCKS=1025
-    // reproduces the measurement
-    int tp_min_blocks = 0;
     Dev dspec[2];
     Dev* d_dspec[2] = {nullptr, nullptr};
     int* h_base = nullptr;
@@ -127,7 +127,6 @@ struct exaadmm_handle {
     double acc_ms[3] = {0.0, 0.0, 0.0};                          // x-update, xbar-update, z/l/residual
     InitData init;
 };
-static int branch_lpb(const exaadmm_handle* h);   // branches per wavefront of the branch launch (below)
 
 
 static int attach_init_data(exaadmm_handle* h, const exaadmm_grid* g);
@@ -203,7 +202,10 @@ static double* vec_ptr(exaadmm_handle* h, int which)
 #endif
 // the flags the library was compiled with travel in the version string: k_branch is only known to be
 // compiled correctly with -mllvm -sgpr-regalloc=basic (DESIGN.md "compiler note"); loaders check for it
-extern "C" const char* exaadmm_version(void) { return "exaadmm-hip 0.2 (gfx950) [" EXA_BUILD_FLAGS "]"; }
+#ifndef EXA_SRC_HASH
+#define EXA_SRC_HASH "unknown"
+#endif
+extern "C" const char* exaadmm_version(void) { return "exaadmm-hip 0.3 (gfx950) [" EXA_BUILD_FLAGS "] src:" EXA_SRC_HASH; }
 extern "C" const char* exaadmm_last_error(void) { return g_err.c_str(); }
 
 // Number of visible HIP devices (0 when there is none or the runtime cannot start).  Also the library's way of
@@ -218,6 +220,25 @@ extern "C" int exaadmm_device_count(void)
         return 0;
     }
     return n;
+}
+
+// Which HIP runtime the library's hip* symbols are bound to in this process (a Python process that has PyTorch maps
+// torch's bundled runtime first, a C / Julia host gets the system one), its version, and the version of the headers the
+// library was compiled against.  Returns the runtime's major version minus the headers' (0 = compatible).
+extern "C" int exaadmm_hip_runtime_info(char* out, int64_t n)
+{
+    Dl_info info;
+    const char* path = "?";
+    if (dladdr((void*)&hipGetDeviceCount, &info) && info.dli_fname) path = info.dli_fname;
+    int rv = 0;
+    if (hipRuntimeGetVersion(&rv) != hipSuccess) {
+        (void)hipGetLastError();
+        rv = 0;
+    }
+    if (out && n > 0)
+        snprintf(out, (size_t)n, "%s (runtime version %d.%d.%d; library compiled against HIP %d.%d.%d)", path, rv / 10000000,
+                 (rv / 100000) % 100, rv % 100000, HIP_VERSION_MAJOR, HIP_VERSION_MINOR, HIP_VERSION_PATCH);
+    return rv / 10000000 - HIP_VERSION_MAJOR;
 }
 
 extern "C" void exaadmm_default_params(exaadmm_params* p)
@@ -335,11 +356,7 @@ extern "C" int exaadmm_create(const exaadmm_grid* g, const exaadmm_params* p, in
         return EXAADMM_ERR_NO_DEVICE;
     }
 
-    {
-        const int64_t la0 = g->nline_active > 0 ? g->nline_active : g->nline;
-        const int64_t ba0 = g->nbus_active > 0 ? g->nbus_active : g->nbus;
-        REQUIRE(la0 <= g->nline && ba0 <= g->nbus, "nline_active / nbus_active out of range");
-    }
+    REQUIRE(g->nline_owned >= 0 && g->nline_owned <= g->nline, "nline_owned out of range");
     exaadmm_handle* h = new exaadmm_handle();
     h->device = device_id;
     h->G = (int)g->ngen;
@@ -358,20 +375,16 @@ extern "C" int exaadmm_create(const exaadmm_grid* g, const exaadmm_params* p, in
         exaadmm_default_params(&h->par);
     fill_branch_options(h);
     {
-        const int64_t la = g->nline_active > 0 ? g->nline_active : g->nline;
-        const char* e = getenv("EXAADMM_BRANCH_ORDER");
-        const bool by_bus = !(e != nullptr && strcmp(e, "input") == 0);
+        const int64_t la = g->nline_owned > 0 ? g->nline_owned : g->nline;
         std::vector<int> order(h->L);
         for (int b = 0; b < h->L; b++) order[b] = b;
-        if (by_bus) {
-            std::vector<int64_t> key(h->L);
-            for (int b = 0; b < h->L; b++) {
-                const bool own = b < la;
-                const int64_t bus = g->brBusIdx[2 * (size_t)b + (own ? 0 : 1)] - g->index_base;
-                key[b] = (own ? 0 : ((int64_t)1 << 40)) + bus;
-            }
-            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key[a] < key[b]; });
+        std::vector<int64_t> key(h->L);
+        for (int b = 0; b < h->L; b++) {
+            const bool own = b < la;
+            const int64_t bus = g->brBusIdx[2 * (size_t)b + (own ? 0 : 1)] - g->index_base;
+            key[b] = (own ? 0 : ((int64_t)1 << 40)) + bus;
         }
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key[a] < key[b]; });
         h->perm.assign(h->L, 0);
         for (int pos = 0; pos < h->L; pos++) h->perm[order[pos]] = pos;
     }
@@ -379,9 +392,8 @@ extern "C" int exaadmm_create(const exaadmm_grid* g, const exaadmm_params* p, in
     memset(&h->d, 0, sizeof(h->d));
     Dev& d = h->d;
     d.G = h->G; d.L = h->L; d.B = h->B; d.Gp = h->Gp; d.Lp = h->Lp; d.N = h->N;
-    d.La = g->nline_active > 0 ? (int)g->nline_active : h->L;
-    d.Ba = g->nbus_active > 0 ? (int)g->nbus_active : h->B;
-    d.lpb = BR_BLOCK;   // set for good once the handle is complete (branch_lpb)
+    d.Lown = g->nline_owned > 0 ? (int)g->nline_owned : h->L;
+    d.nranks = 1;
     d.T = 1; d.g1 = h->G; d.l1 = h->L; d.b1 = h->B;
     const int base = g->index_base;
     int rc = 0;
@@ -396,14 +408,8 @@ extern "C" int exaadmm_create(const exaadmm_grid* g, const exaadmm_params* p, in
         const char* e = getenv("EXAADMM_BUS_KERNEL");
         h->bus_lane_kernel = (e != nullptr && strcmp(e, "lane") == 0);
         h->use_graph = (getenv("EXAADMM_NO_GRAPH") == nullptr);
-        h->spec_on = (getenv("EXAADMM_NO_SPEC") == nullptr);   // speculative branch launch (A/B switch)
-        if (const char* e = getenv("EXAADMM_TP_MIN_BLOCKS")) h->tp_min_blocks = atoi(e);   // 0 = never
-#if defined(EXA_HAVE_ZL)
-        // z/l pass fused into the branch launch's prologue (A/B switch; needs the lane-group bus kernel, which carries
-        // the reduction block)
-        h->zl_on = h->spec_on && !h->bus_lane_kernel && (getenv("EXAADMM_NO_ZLFUSE") == nullptr);
-        if (const char* e = getenv("EXAADMM_ZLFUSE_MAX_WAVES")) h->zl_max_waves = atoi(e);
-#endif
+        // speculative two-launch loop (A/B switch; needs the lane-group bus kernel, which carries the reduction block)
+        h->spec_on = (getenv("EXAADMM_NO_SPEC") == nullptr) && !h->bus_lane_kernel;
     }
     TRY(upload_mupow_table());
 
@@ -490,16 +496,27 @@ extern "C" int exaadmm_create(const exaadmm_grid* g, const exaadmm_params* p, in
         TRY(build_csr(h, g->GenStart, g->GenIdx, base, h->B, h->G, &d.GenStart, &d.GenIdx, std::max(h->G, 1)));
         // combined per-bus component list for the lane-group bus kernel: generators, from-ends, to-ends
         {
+            // a branch with only ONE end on a local bus is shared with a peer partition: the v entries of that end are what
+            // the peer is missing (END_CUT -> the bus kernel also drops them into the halo message, dist_native.h)
+            std::vector<char> seen_fr(h->L, 0), seen_to(h->L, 0);
+            for (int64_t k = 0; k < g->FrStart[h->B] - base; k++) seen_fr[(size_t)(g->FrIdx[k] - base)] = 1;
+            for (int64_t k = 0; k < g->ToStart[h->B] - base; k++) seen_to[(size_t)(g->ToIdx[k] - base)] = 1;
+            h->cut_side.assign(h->L, 0);
+            for (int b = 0; b < h->L; b++) h->cut_side[b] = (seen_fr[b] && !seen_to[b]) ? 1 : ((!seen_fr[b] && seen_to[b]) ? 2 : 0);
             std::vector<int> es(h->B + 1, 0), ec;
             ec.reserve((size_t)2 * h->L + h->G);
             for (int I = 0; I < h->B; I++) {
                 es[I] = (int)ec.size();
                 for (int64_t k = g->GenStart[I] - base; k < g->GenStart[I + 1] - base; k++)
                     ec.push_back((END_GEN << 28) | (int)(g->GenIdx[k] - base));
-                for (int64_t k = g->FrStart[I] - base; k < g->FrStart[I + 1] - base; k++)
-                    ec.push_back((END_FROM << 28) | h->perm[(size_t)(g->FrIdx[k] - base)]);
-                for (int64_t k = g->ToStart[I] - base; k < g->ToStart[I + 1] - base; k++)
-                    ec.push_back((END_TO << 28) | h->perm[(size_t)(g->ToIdx[k] - base)]);
+                for (int64_t k = g->FrStart[I] - base; k < g->FrStart[I + 1] - base; k++) {
+                    const size_t b = (size_t)(g->FrIdx[k] - base);
+                    ec.push_back((END_FROM << 28) | h->perm[b] | (seen_to[b] ? 0 : END_CUT));
+                }
+                for (int64_t k = g->ToStart[I] - base; k < g->ToStart[I + 1] - base; k++) {
+                    const size_t b = (size_t)(g->ToIdx[k] - base);
+                    ec.push_back((END_TO << 28) | h->perm[b] | (seen_fr[b] ? 0 : END_CUT));
+                }
             }
             es[h->B] = (int)ec.size();
             int *des, *dec;
@@ -537,9 +554,10 @@ extern "C" int exaadmm_create(const exaadmm_grid* g, const exaadmm_params* p, in
         return EXAADMM_ERR_HIP;
     }
     memset(h->h_ctrl, 0, sizeof(Ctrl));
+    TRY(dev_alloc(h, &h->d_busc, (size_t)BUSC_N * h->B));
+    d.busc = h->d_busc;
     TRY(attach_init_data(h, g));
 #undef TRY
-    h->d.lpb = branch_lpb(h);
     *out = h;
     return EXAADMM_OK;
 }
@@ -555,8 +573,6 @@ extern "C" int exaadmm_destroy(exaadmm_handle* h)
         if (s.d_idx) (void)hipFree(s.d_idx);
         if (s.d_which) (void)hipFree(s.d_which);
     }
-    if (h->d_owned) (void)hipFree(h->d_owned);
-    if (h->d_lane_order) (void)hipFree(h->d_lane_order);
     if (h->batch_graph) (void)hipGraphExecDestroy(h->batch_graph);
     if (h->spec_graph) (void)hipGraphExecDestroy(h->spec_graph);
     if (h->h_base) (void)hipHostFree(h->h_base);
@@ -606,6 +622,7 @@ extern "C" int exaadmm_upload_solution(exaadmm_handle* h, int which, const doubl
     ref_to_soa(h, host, h->stage.data(), which == EXAADMM_RHO ? 1.0 : 0.0);
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(dst, h->stage.data(), (size_t)h->N * sizeof(double), hipMemcpyHostToDevice));
+    if (which == EXAADMM_RHO) h->busc_dirty = true;
     return EXAADMM_OK;
 }
 
@@ -778,6 +795,7 @@ extern "C" int exaadmm_init_solution(exaadmm_handle* h, double rho_pq, double rh
         HIPCHK(hipMemcpy(h->d.r_u, ru.data(), n * sizeof(double), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d.r_s, rs.data(), n * sizeof(double), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d.r_rho, rr.data(), n * sizeof(double), hipMemcpyHostToDevice));
+        h->busc_dirty = true;
     }
     h->residual_vectors_valid = true;
     return EXAADMM_OK;
@@ -794,7 +812,7 @@ extern "C" int exaadmm_mp_create(const exaadmm_grid* g, const exaadmm_params* p,
 {
     REQUIRE(g && out && Pd && Qd, "null argument");
     REQUIRE(T >= 1, "need at least one period");
-    REQUIRE(g->nline_active == 0 && g->nbus_active == 0, "a multi-period model cannot be a partition");
+    REQUIRE(g->nline_owned == 0 || g->nline_owned == g->nline, "a multi-period model cannot be a partition");
     const int64_t G = g->ngen, L = g->nline, B = g->nbus;
     REQUIRE((2 * G + 8 * L) * (int64_t)T < (int64_t)2000000000, "time-expanded grid too large for 32-bit device indices");
     const int base = (int)g->index_base;
@@ -951,6 +969,7 @@ extern "C" int exaadmm_mp_upload_ramp(exaadmm_handle* h, int which, const double
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(dst, host, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    if (which == EXAADMM_RHO) h->busc_dirty = true;
     return EXAADMM_OK;
 }
 
@@ -971,51 +990,46 @@ static void launch_mp_elem(exaadmm_handle* h, double beta, const Ctrl* c)
     hipLaunchKernelGGL((k_mp_elem<MODE>), dim3(h->mp_nbx, h->T, MP_PLANES), dim3(EW_BLOCK), 0, h->stream, h->d, beta,
                        h->par.MAX_MULTIPLIER, c);
 }
-// Branches per wavefront of the branch launch.  64 (full waves) is the measured optimum at every size: spreading a small
-// grid over more, emptier waves shortens no wave's serial chain by much and costs more than it saves (13659-bus grid:
-// 64 -> 0.0685 ms, 32 -> 0.0704, 23 -> 0.0768, 16 -> 0.0838; profiles/r02_lanes_per_wave.txt).
-// EXAADMM_LANES_PER_WAVE is kept as the A/B switch of that measurement.
-static int branch_lpb(const exaadmm_handle* h)
-{
-    (void)h;
-#if !defined(EXA_PROFILE_PHASES)   // (the diagnostic build indexes its per-wave timeline by 64-branch waves)
-    if (const char* e = getenv("EXAADMM_LANES_PER_WAVE")) {
-        const int v = atoi(e);
-        if (v >= 1 && v <= BR_BLOCK) return v;
-    }
-#endif
-    return BR_BLOCK;
-}
-static int branch_blocks(const exaadmm_handle* h) { return (std::max(h->d.La, 1) + h->d.lpb - 1) / h->d.lpb; }
+// 64 branches per wavefront (full waves) is the measured optimum at every size: spreading a small grid over more, emptier
+// waves shortens no wave's serial chain by much and costs more than it saves (profiles/r02_lanes_per_wave.txt).
+static int branch_blocks(const exaadmm_handle* h) { return (int)grid_for(h->L, BR_BLOCK).x; }
+static int gen_blocks(const exaadmm_handle* h) { return (h->G > 0) ? (int)grid_for(h->G, BR_BLOCK).x : 0; }
 
-// throughput variant of the branch kernel (kernels.h, k_branch_tp): single-period model, identity lane order, and a
-// launch with more wavefronts than the chip has SIMDs
-static bool use_tp(const exaadmm_handle* h)
+// the Dev copy kernels read through a pointer (rare: after create / attach)
+static void flush_dev(exaadmm_handle* h)
 {
-    return h->T == 1 && h->d.lane_order == nullptr && h->tp_min_blocks > 0 && (int)((h->d.La + BR_BLOCK - 1) / BR_BLOCK) >= h->tp_min_blocks;
+    if (h->dev_dirty) {
+        (void)hipMemcpyAsync(h->d_dev, &h->d, sizeof(Dev), hipMemcpyHostToDevice, h->stream);
+        h->dev_dirty = false;
+    }
+}
+// rho-only constants of the bus update: recomputed after rho changed (never inside a stream capture: callers flush first)
+static void flush_bus_const(exaadmm_handle* h)
+{
+    if (h->busc_dirty) {
+        hipLaunchKernelGGL(k_bus_const, grid_for(h->B, 256), dim3(256), 0, h->stream, h->d, h->d_busc);
+        h->busc_dirty = false;
+    }
 }
 
 static void launch_branch(exaadmm_handle* h, int major_iter, const Ctrl* c, bool with_generators = false)
 {
-    if (h->dev_dirty) {  // rare: after create / set_active / set_owned_mask / lane order
-        (void)hipMemcpyAsync(h->d_dev, &h->d, sizeof(Dev), hipMemcpyHostToDevice, h->stream);
-        h->dev_dirty = false;
-    }
-    const int nb = use_tp(h) ? (int)grid_for(h->d.La, BR_BLOCK).x : branch_blocks(h);
-    const int ng = (with_generators && h->G > 0) ? (int)grid_for(h->G, BR_BLOCK).x : 0;
+    flush_dev(h);
+    const int nb = branch_blocks(h);
+    const int ng = with_generators ? gen_blocks(h) : 0;
     if (h->T > 1)
         hipLaunchKernelGGL((k_branch_t<true>), dim3(nb + ng), dim3(BR_BLOCK), 0, h->stream, h->d_dev, h->bo, h->par.scale, major_iter, const_cast<Ctrl*>(c), ng, h->baseMVA, -1);
-    else if (use_tp(h))
-        hipLaunchKernelGGL(k_branch_tp, dim3(nb + ng), dim3(BR_BLOCK), 0, h->stream, h->d_dev, h->bo, h->par.scale, major_iter, const_cast<Ctrl*>(c), ng, h->baseMVA, -1);
     else
         hipLaunchKernelGGL((k_branch_t<false>), dim3(nb + ng), dim3(BR_BLOCK), 0, h->stream, h->d_dev, h->bo, h->par.scale, major_iter, const_cast<Ctrl*>(c), ng, h->baseMVA, -1);
 }
 static void launch_bus(exaadmm_handle* h, const Ctrl* c)
 {
-    if (h->bus_lane_kernel)  // A/B switch (EXAADMM_BUS_KERNEL=lane): one lane per bus
-        hipLaunchKernelGGL(k_bus, grid_for(h->d.Ba, 64), dim3(64), 0, h->stream, h->d, h->baseMVA, c);
-    else
-        hipLaunchKernelGGL(k_bus_group, grid_for(h->d.Ba, BUS_BLOCK / BUS_W), dim3(BUS_BLOCK), 0, h->stream, h->d, h->baseMVA, c, (Ctrl*)nullptr);
+    if (h->bus_lane_kernel)  // A/B switch (EXAADMM_BUS_KERNEL=lane): one lane per bus, everything derived in place
+        hipLaunchKernelGGL(k_bus, grid_for(h->B, 64), dim3(64), 0, h->stream, h->d, h->baseMVA, c);
+    else {
+        flush_bus_const(h);
+        hipLaunchKernelGGL(k_bus_group, grid_for(h->B, BUS_BLOCK / BUS_W), dim3(BUS_BLOCK), 0, h->stream, h->d, h->baseMVA, c, (Ctrl*)nullptr);
+    }
 }
 static void launch_fused_zl(exaadmm_handle* h, double beta, const Ctrl* c)
 {
@@ -1032,7 +1046,7 @@ static void launch_final(exaadmm_handle* h, Ctrl* c, double* out = nullptr)
                            h->T, out ? out : h->d_sums, c);
     else
         hipLaunchKernelGGL(k_final_reduce, dim3(1), dim3(EW_BLOCK), 0, h->stream, h->d.partials, h->ew_blocks,
-                           out ? out : h->d_sums, c, 0);
+                           out ? out : h->d_sums, c, 0, 1);
 }
 
 static int sync_check(exaadmm_handle* h, bool force)
@@ -1051,6 +1065,10 @@ static int fetch_sums(exaadmm_handle* h, double out[4], bool take_sqrt)
     for (int j = 0; j < 4; j++) out[j] = take_sqrt ? sqrt(h->h_sums[j]) : h->h_sums[j];
     return 0;
 }
+
+// a partition with peers (dist_native.h): one grouped send / receive per peer + the unpack kernel
+static bool dist_has_peers(const exaadmm_handle* h);
+static int dist_exchange(exaadmm_handle* h, const Dev& dv, bool with_v, Ctrl* c, double* out, int need_pending);
 
 // ------------------------------------------------------------------ step-wise plugin surface
 extern "C" int exaadmm_inner_prestep(exaadmm_handle* h)
@@ -1180,6 +1198,11 @@ extern "C" int exaadmm_norm_z(exaadmm_handle* h, double* out)
     else
         hipLaunchKernelGGL(k_sumsq_z, dim3(h->ew_blocks), dim3(EW_BLOCK), 0, h->stream, h->d);
     launch_final(h, nullptr);
+    if (dist_has_peers(h)) {   // a partition: the owned elements' sum of squares, added over the ranks in rank order
+        hipLaunchKernelGGL(k_halo_pack_sums, dim3(1), dim3(64), 0, h->stream, h->d, h->d_sums, (const Ctrl*)nullptr);
+        int rc = dist_exchange(h, h->d, false, nullptr, h->d_sums, 0);
+        if (rc) return rc;
+    }
     double s[4];
     int rc = fetch_sums(h, s, true);
     if (rc) return rc;
@@ -1247,38 +1270,9 @@ extern "C" int exaadmm_branch_kernel_occupancy(exaadmm_handle* h, int* waves_per
     int blocks = 0;
     if (h->T > 1)
         HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_branch_t<true>, BR_BLOCK, 0));
-    else if (use_tp(h))
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_branch_tp, BR_BLOCK, 0));
     else
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_branch_t<false>, BR_BLOCK, 0));
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, (k_branch_t<false, true>), BR_BLOCK, 0));
     *waves_per_simd = blocks / 4;
-    return EXAADMM_OK;
-}
-
-// Lane assignment of the branch kernel: lane i solves reference branch order[i] (a permutation of
-// the active branches).  NULL restores the identity.  Results do not depend on it.
-extern "C" int exaadmm_set_branch_lane_order(exaadmm_handle* h, const int32_t* order, int64_t n)
-{
-    REQUIRE(h, "null handle");
-    HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    h->dev_dirty = true;
-    invalidate_graph(h);
-    if (!order) {
-        h->d.lane_order = nullptr;
-        return EXAADMM_OK;
-    }
-    REQUIRE(n == h->d.La, "order must list every active branch once");
-    std::vector<int> t(n);
-    std::vector<char> seen(h->L, 0);
-    for (int64_t i = 0; i < n; i++) {
-        REQUIRE(order[i] >= 0 && order[i] < h->d.La && !seen[order[i]], "order is not a permutation of the active branches");
-        seen[order[i]] = 1;
-        t[i] = h->perm[order[i]];
-    }
-    if (!h->d_lane_order) HIPCHK(hipMalloc((void**)&h->d_lane_order, (size_t)h->Lp * sizeof(int)));
-    HIPCHK(hipMemcpy(h->d_lane_order, t.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
-    h->d.lane_order = h->d_lane_order;
     return EXAADMM_OK;
 }
 
@@ -1302,12 +1296,15 @@ extern "C" int exaadmm_debug_wave_timeline(exaadmm_handle* h, unsigned long long
     return EXAADMM_OK;
 }
 
-// ------------------------------------------------------------------ speculative branch launch
-// (kernels.h, k_branch_t: the final reduction of iteration k rides in the branch launch of iteration k+1)
-static bool spec_eligible(const exaadmm_handle* h)
-{
-    return h->spec_on && h->T == 1 && h->d.owned == nullptr && h->d.La == h->L && h->d.Ba == h->B && !h->ctrl_mode;
-}
+// ------------------------------------------------------------------ the device-resident inner loop
+// Two launches per iteration (kernels.h):
+//     branch launch k+1 : [ z, l, residual terms of iteration k, per lane ] -> [ x-update k+1 ]      (k_branch_t<false, true>)
+//     bus launch    k+1 : [ bus update k+1 ]  ||  one extra block: residual sums of iteration k       (k_bus_group, `red`)
+// and, for a partition with peers, ONE exchange: the v entries the bus update has just produced for the local end of
+// every cut branch + this rank's four residual sums -> grouped ncclSend / ncclRecv -> k_halo_unpack (scatter, add the
+// sums in rank order, advance the loop control).  The loop test of iteration k is known one launch late; the iterate is
+// double-buffered by iteration parity so that the stopping iteration's state survives its speculative successor.
+static bool spec_eligible(const exaadmm_handle* h) { return h->spec_on && h->T == 1 && !h->ctrl_mode; }
 
 static int spec_prepare(exaadmm_handle* h)
 {
@@ -1322,12 +1319,7 @@ static int spec_prepare(exaadmm_handle* h)
             HIPCHK(hipMemsetAsync(q, 0, (size_t)h->Lp * sizeof(int), h->stream));
         }
         if ((rc = dev_alloc(h, &h->v_alt, (size_t)h->N))) return rc;
-        {
-            // room for any branches-per-wave setting the fused variant can run with
-            const int nblk = std::max(std::min(std::max(h->d.La, 1), BR_BLOCK * 2048), (int)grid_for(h->d.La, BR_BLOCK).x) +
-                             ((h->G > 0) ? (int)grid_for(h->G, BR_BLOCK).x : 0);
-            if ((rc = dev_alloc(h, &h->partials_br, (size_t)nblk * 4))) return rc;
-        }
+        if ((rc = dev_alloc(h, &h->partials_br, (size_t)(branch_blocks(h) + gen_blocks(h)) * 4))) return rc;
         HIPCHK(hipMemcpyAsync(h->v_alt, h->d.v, (size_t)h->N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         if ((rc = dev_alloc(h, &h->d_dspec[0], 1))) return rc;
         if ((rc = dev_alloc(h, &h->d_dspec[1], 1))) return rc;
@@ -1341,6 +1333,7 @@ static int spec_prepare(exaadmm_handle* h)
         HIPCHK(hipMemsetAsync(h->ls2_alt, 0, (size_t)h->Lp * sizeof(double), h->stream));
         HIPCHK(hipMemsetAsync(h->mu_alt, 0, (size_t)h->Lp * sizeof(double), h->stream));
     }
+    flush_bus_const(h);
     // odd iteration (j even): read the primary set, write the alternate one; even iteration: the reverse
     Dev a = h->d, b = h->d;
     a.u_in = h->d.u;      a.u = h->u_alt;
@@ -1351,20 +1344,12 @@ static int spec_prepare(exaadmm_handle* h)
     // ahead) must not overwrite the counters of the last accepted x-update
     a.st_auglag = h->st_alt[0];  a.st_minor = h->st_alt[1];  a.st_ticks = h->st_alt[2];
     b.u_in = h->u_alt;    b.ls1_in = h->ls1_alt;  b.ls2_in = h->ls2_alt;  b.mu_in = h->mu_alt;
-    a.npartials = b.npartials = h->ew_blocks;
-    // (at every size.  With the prologue written element by element -- eight dependent memory round trips per wave -- the
-    //  fused variant lost above ~2 waves queued per SIMD: 1M branches, k_branch 0.43 -> 0.61 ms against 0.10 ms for the
-    //  k_fused_zl it replaces.  With all loads ahead of the stores it wins there too: 1M branches 1 478 -> 1 529 it/s,
-    //  300 k branches 0.237 -> 0.226 ms per iteration; EXAADMM_ZLFUSE_MAX_WAVES=2048 restores the old size gate.)
-    if (h->zl_on && h->d.lane_order == nullptr && (int)grid_for(h->d.La, BR_BLOCK).x <= h->zl_max_waves && !use_tp(h) &&
-        (branch_blocks(h) <= BR_BLOCK * 2048 / BR_BLOCK || h->d.lpb == BR_BLOCK)) {   // (size test in 64-branch waves)
-        // v follows the same parity as u: the bus launch of an odd iteration writes the alternate v, which the next
-        // (even) iteration's branch launch reads
-        a.v_in = h->d.v;   a.v = h->v_alt;
-        b.v_in = h->v_alt; // b.v stays the primary buffer
-        a.partials_br = b.partials_br = h->partials_br;
-        a.npartials_br = b.npartials_br = branch_blocks(h) + ((h->G > 0) ? (int)grid_for(h->G, BR_BLOCK).x : 0);
-    }
+    // v follows the same parity as u: the bus launch of an odd iteration writes the alternate v, which the next
+    // (even) iteration's branch launch reads
+    a.v_in = h->d.v;   a.v = h->v_alt;
+    b.v_in = h->v_alt; // b.v stays the primary buffer
+    a.partials_br = b.partials_br = h->partials_br;
+    a.npartials_br = b.npartials_br = branch_blocks(h) + gen_blocks(h);
     if (memcmp(&a, &h->dspec[0], sizeof(Dev)) != 0 || memcmp(&b, &h->dspec[1], sizeof(Dev)) != 0) {
         invalidate_graph(h);
         h->dspec[0] = a;
@@ -1376,54 +1361,37 @@ static int spec_prepare(exaadmm_handle* h)
     return 0;
 }
 
-// iteration base + j + 1 of the speculative loop (j = position inside the batch; base is even)
-static void enqueue_iteration_spec(exaadmm_handle* h, Ctrl* c, int j, bool sample = false, hipEvent_t* bev = nullptr)
+// iteration base + j + 1 of the loop (j = position inside the batch; base is even)
+static int enqueue_iteration_spec(exaadmm_handle* h, Ctrl* c, int j, bool sample = false, hipEvent_t* bev = nullptr)
 {
     const int par = j & 1;
     const Dev& dv = h->dspec[par];
-    const int nb = use_tp(h) ? (int)grid_for(h->d.La, BR_BLOCK).x : branch_blocks(h);
-    const int ng = (h->G > 0) ? (int)grid_for(h->G, BR_BLOCK).x : 0;
+    const int nb = branch_blocks(h), ng = gen_blocks(h);
     if (sample) (void)hipEventRecord(h->tev[0], h->stream);
     if (bev) (void)hipEventRecord(bev[0], h->stream);
-#if defined(EXA_HAVE_ZL)
-    if (dv.partials_br != nullptr) {
-        // two launches per iteration: [z/l of the previous iteration + x-update] -> [bus update + reduction block]
-        hipLaunchKernelGGL((k_branch_t<false, true>), dim3(nb + ng), dim3(BR_BLOCK), 0, h->stream, h->d_dspec[par], h->bo, h->par.scale, 0, c,
-                           ng, h->baseMVA, j);
-        if (bev) (void)hipEventRecord(bev[1], h->stream);
-        if (sample) (void)hipEventRecord(h->tev[1], h->stream);
-        hipLaunchKernelGGL(k_bus_group, dim3(grid_for(h->d.Ba, BUS_BLOCK / BUS_W).x + 1), dim3(BUS_BLOCK), 0, h->stream, dv, h->baseMVA, c, c);
-        if (sample) {
-            (void)hipEventRecord(h->tev[2], h->stream);
-            (void)hipEventRecord(h->tev[3], h->stream);
-        }
-        return;
-    }
-#endif
-    if (use_tp(h))
-        hipLaunchKernelGGL(k_branch_tp, dim3(nb + ng + 1), dim3(BR_BLOCK), 0, h->stream, h->d_dspec[par], h->bo, h->par.scale, 0, c, ng, h->baseMVA, j);
-    else
-        hipLaunchKernelGGL((k_branch_t<false>), dim3(nb + ng + 1), dim3(BR_BLOCK), 0, h->stream, h->d_dspec[par], h->bo, h->par.scale, 0, c,
-                           ng, h->baseMVA, j);
+    hipLaunchKernelGGL((k_branch_t<false, true>), dim3(nb + ng), dim3(BR_BLOCK), 0, h->stream, h->d_dspec[par], h->bo, h->par.scale, 0, c,
+                       ng, h->baseMVA, j);
     if (bev) (void)hipEventRecord(bev[1], h->stream);
     if (sample) (void)hipEventRecord(h->tev[1], h->stream);
-    if (h->bus_lane_kernel)
-        hipLaunchKernelGGL(k_bus, grid_for(h->d.Ba, 64), dim3(64), 0, h->stream, dv, h->baseMVA, c);
-    else
-        hipLaunchKernelGGL(k_bus_group, grid_for(h->d.Ba, BUS_BLOCK / BUS_W), dim3(BUS_BLOCK), 0, h->stream, dv, h->baseMVA, c, (Ctrl*)nullptr);
-    if (sample) (void)hipEventRecord(h->tev[2], h->stream);
-    hipLaunchKernelGGL(k_fused_zl, dim3(h->ew_blocks), dim3(EW_BLOCK), 0, h->stream, dv, 0.0, c, &c->pending);
-    if (sample) (void)hipEventRecord(h->tev[3], h->stream);
+    hipLaunchKernelGGL(k_bus_group, dim3(grid_for(h->B, BUS_BLOCK / BUS_W).x + 1), dim3(BUS_BLOCK), 0, h->stream, dv, h->baseMVA, c, c);
+    if (dist_has_peers(h)) {
+        int rc = dist_exchange(h, dv, true, c, nullptr, 1);
+        if (rc) return rc;
+    }
+    if (sample) {
+        (void)hipEventRecord(h->tev[2], h->stream);
+        (void)hipEventRecord(h->tev[3], h->stream);
+    }
+    return 0;
 }
 
-// after a speculative loop of `iters` completed iterations the valid iterate sits in the alternate set
-// when `iters` is odd: bring it home so that every other entry point keeps using the primary buffers
+// after a loop of `iters` completed iterations the valid iterate sits in the alternate set when `iters` is odd:
+// bring it home so that every other entry point keeps using the primary buffers
 static int spec_finish(exaadmm_handle* h, int iters)
 {
     if (iters & 1) {
         HIPCHK(hipMemcpyAsync(h->d.u, h->u_alt, (size_t)h->N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-        if (h->dspec[0].partials_br != nullptr)   // fused z/l variant: v was ping-ponged as well
-            HIPCHK(hipMemcpyAsync(h->d.v, h->v_alt, (size_t)h->N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d.v, h->v_alt, (size_t)h->N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(h->d.ls1, h->ls1_alt, (size_t)h->Lp * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(h->d.ls2, h->ls2_alt, (size_t)h->Lp * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(h->d.mu, h->mu_alt, (size_t)h->Lp * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
@@ -1434,15 +1402,20 @@ static int spec_finish(exaadmm_handle* h, int iters)
     return 0;
 }
 
-// The last enqueued iteration has no successor: nothing would reduce its residual sums (plain speculative loop) or
-// even run its z/l pass (fused variant).  Both kernels return at once when the loop has already stopped.
-static void spec_complete_last(exaadmm_handle* h, int enqueued)
+// The last enqueued iteration has no successor: nothing would run its z/l pass or reduce its residual sums.  Every
+// kernel here returns at once when the loop has already stopped.
+static int spec_complete_last(exaadmm_handle* h, int enqueued)
 {
-    if (h->dspec[0].partials_br != nullptr && enqueued > 0) {
-        const Dev& dv = h->dspec[(enqueued - 1) & 1];   // the buffers the last enqueued iteration wrote
-        hipLaunchKernelGGL(k_fused_zl, dim3(h->ew_blocks), dim3(EW_BLOCK), 0, h->stream, dv, 0.0, h->d_ctrl, &h->d_ctrl->pending);
+    if (enqueued <= 0) return 0;
+    const Dev& dv = h->dspec[(enqueued - 1) & 1];   // the buffers the last enqueued iteration wrote
+    hipLaunchKernelGGL(k_fused_zl, dim3(h->ew_blocks), dim3(EW_BLOCK), 0, h->stream, dv, 0.0, h->d_ctrl, &h->d_ctrl->pending);
+    if (!dist_has_peers(h)) {
+        hipLaunchKernelGGL(k_final_reduce, dim3(1), dim3(EW_BLOCK), 0, h->stream, h->d.partials, h->ew_blocks, h->d_sums, h->d_ctrl, 1, 1);
+        return 0;
     }
-    hipLaunchKernelGGL(k_final_reduce, dim3(1), dim3(EW_BLOCK), 0, h->stream, h->d.partials, h->ew_blocks, h->d_sums, h->d_ctrl, 1);
+    hipLaunchKernelGGL(k_final_reduce, dim3(1), dim3(EW_BLOCK), 0, h->stream, h->d.partials, h->ew_blocks, h->d_sums, h->d_ctrl, 1, 0);
+    hipLaunchKernelGGL(k_halo_pack_sums, dim3(1), dim3(64), 0, h->stream, h->d, h->d_sums, (const Ctrl*)h->d_ctrl);
+    return dist_exchange(h, h->d, false, h->d_ctrl, h->d_sums, 1);
 }
 
 static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
@@ -1450,7 +1423,8 @@ static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
     int rc = spec_prepare(h);
     if (rc) return rc;
     const int batch = 8;
-    const bool graph_ok = h->use_graph && h->stream == h->own_stream;
+    // RCCL calls are not captured: a partition with peers enqueues every batch directly
+    const bool graph_ok = h->use_graph && h->stream == h->own_stream && !dist_has_peers(h);
     float ms_sample[3] = {0.f, 0.f, 0.f};
     int enq = 0;
     bool first = true;
@@ -1462,7 +1436,7 @@ static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
             if (!h->spec_graph) {
                 hipGraph_t g = nullptr;
                 HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-                for (int j = 0; j < batch; j++) enqueue_iteration_spec(h, h->d_ctrl, j);
+                for (int j = 0; j < batch; j++) (void)enqueue_iteration_spec(h, h->d_ctrl, j);
                 HIPCHK(hipStreamEndCapture(h->stream, &g));
                 hipError_t e = hipGraphInstantiate(&h->spec_graph, g, nullptr, nullptr, 0);
                 (void)hipGraphDestroy(g);
@@ -1473,7 +1447,8 @@ static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
             }
             HIPCHK(hipGraphLaunch(h->spec_graph, h->stream));
         } else {
-            for (int j = 0; j < nb; j++) enqueue_iteration_spec(h, h->d_ctrl, j, first && j == 0);
+            for (int j = 0; j < nb; j++)
+                if ((rc = enqueue_iteration_spec(h, h->d_ctrl, j, first && j == 0))) return rc;
         }
         enq += nb;
         HIPCHK(hipMemcpyAsync(hc, h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
@@ -1483,9 +1458,9 @@ static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
                 if (hipEventElapsedTime(&ms_sample[q], h->tev[q], h->tev[q + 1]) != hipSuccess) ms_sample[q] = 0.f;
             first = false;
         }
-        if (hc->done) break;
+        if (hc->done) break;   // (a partition: every rank sees the same sums, added in the same order -> the same decision)
     }
-    spec_complete_last(h, enq);
+    if ((rc = spec_complete_last(h, enq))) return rc;
     HIPCHK(hipMemcpyAsync(hc, h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
     if ((rc = sync_check(h, true))) return rc;
     if ((rc = spec_finish(h, hc->inner))) return rc;
@@ -1494,6 +1469,7 @@ static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
 }
 
 // ------------------------------------------------------------------ fused loops
+// the plain loop (multi-period model, EXAADMM_NO_SPEC / EXAADMM_BUS_KERNEL=lane A/B runs): four launches per iteration
 static void enqueue_iteration(exaadmm_handle* h, Ctrl* c, bool sample = false)
 {
     if (sample) (void)hipEventRecord(h->tev[0], h->stream);
@@ -1506,15 +1482,19 @@ static void enqueue_iteration(exaadmm_handle* h, Ctrl* c, bool sample = false)
     if (sample) (void)hipEventRecord(h->tev[3], h->stream);
 }
 
+static int64_t nvar_for_tolerances(const exaadmm_handle* h);   // a partition: nvar of the WHOLE grid (dist_native.h)
+
 extern "C" int exaadmm_run_inner(exaadmm_handle* h, int outer, int max_inner, double beta, int* inner_done, double out[4])
 {
     REQUIRE(h && outer >= 1 && max_inner >= 1, "bad argument");
     HIPCHK(hipSetDevice(h->device));
+    REQUIRE(!dist_has_peers(h) || spec_eligible(h), "a partition with peers runs the speculative loop only (single-period model, EXAADMM_NO_SPEC / EXAADMM_BUS_KERNEL unset)");
     Ctrl* hc = h->h_ctrl;
     memset(hc, 0, sizeof(Ctrl));
     hc->max_inner = max_inner;
-    hc->check_every = std::max(1, (int)h->par.check_every);
-    hc->eps_pri = sqrt((double)h->nvar_ctrl) / (2500.0 * outer);  // admm_two_level.jl:45
+    // (a partition tests every iteration: all ranks must take the same decision in the same iteration)
+    hc->check_every = dist_has_peers(h) ? 1 : std::max(1, (int)h->par.check_every);
+    hc->eps_pri = sqrt((double)nvar_for_tolerances(h)) / (2500.0 * outer);  // admm_two_level.jl:45
     hc->beta = beta;
     hc->first_iter = 1;
     HIPCHK(hipMemcpyAsync(h->d_ctrl, hc, sizeof(Ctrl), hipMemcpyHostToDevice, h->stream));
@@ -1527,16 +1507,16 @@ extern "C" int exaadmm_run_inner(exaadmm_handle* h, int outer, int max_inner, do
     int enq = 0;
     for (auto& e : h->tev)
         if (!e) HIPCHK(hipEventCreate(&e));
-    // Full batches after the first are replayed from a hipGraph (32 kernel nodes); the first batch
+    // Full batches after the first are replayed from a hipGraph; the first batch
     // of every call is launched directly with HIP events around its first iteration, which feed
     // the sampled step times (mod.info.time_*_update of the reference).  Capturing needs a real
     // stream: with the caller's null stream (exaadmm_set_stream(NULL)) launches stay direct.
     const bool graph_ok = h->use_graph && h->stream == h->own_stream;
     if (h->dev_dirty) {   // flush the Dev copy outside any capture; it is baked into the graph
         invalidate_graph(h);
-        HIPCHK(hipMemcpyAsync(h->d_dev, &h->d, sizeof(Dev), hipMemcpyHostToDevice, h->stream));
-        h->dev_dirty = false;
+        flush_dev(h);
     }
+    flush_bus_const(h);
     if (spec_eligible(h)) {
         int rc = run_inner_spec(h, max_inner, hc);
         if (rc) return rc;
@@ -1586,12 +1566,14 @@ extern "C" int exaadmm_run_inner(exaadmm_handle* h, int outer, int max_inner, do
 
 extern "C" int exaadmm_solve_two_level(exaadmm_handle* h, exaadmm_info* out)
 {
-    // admm_two_level (src/algorithms/admm_two_level.jl:1-88)
+    // admm_two_level (src/algorithms/admm_two_level.jl:1-88).  On a partition with peers every rank runs this same
+    // function: norms and loop decisions are identical on all ranks (sums added in rank order), the scalar logic is
+    // replicated, info.objval is THIS partition's share of the objective (the caller adds the shares).
     REQUIRE(h, "null handle");
     HIPCHK(hipSetDevice(h->device));
     exaadmm_params& par = h->par;
     exaadmm_info& info = h->info;
-    const double sqrt_d = sqrt((double)h->nvar_ctrl);
+    const double sqrt_d = sqrt((double)nvar_for_tolerances(h));
     const double OUTER_TOL = sqrt_d * par.outer_eps;
     memset(&info, 0, sizeof(info));
     info.mismatch = INFINITY;
@@ -1643,6 +1625,7 @@ extern "C" int exaadmm_run_fixed(exaadmm_handle* h, int iters, int first_major_i
 {
     REQUIRE(h && iters >= 1 && first_major_iter >= 1, "bad argument");
     HIPCHK(hipSetDevice(h->device));
+    REQUIRE(!dist_has_peers(h) || spec_eligible(h), "a partition with peers runs the speculative loop only");
     const bool time_branch = (ms_branch != nullptr);
     const size_t need = 2 + (time_branch ? 2 * (size_t)iters : 0);
     while (h->ev.size() < need) {
@@ -1651,9 +1634,10 @@ extern "C" int exaadmm_run_fixed(exaadmm_handle* h, int iters, int first_major_i
         h->ev.push_back(e);
     }
     h->residual_vectors_valid = false;
+    flush_dev(h);
+    flush_bus_const(h);
     if (spec_eligible(h)) {
-        // same kernels as the fused loop, with a control block that never stops: the reduction of iteration k
-        // rides in the branch launch of iteration k+1, the last one is reduced by a stand-alone launch
+        // same kernels as the fused loop, with a control block that never stops
         int rc = spec_prepare(h);
         if (rc) return rc;
         Ctrl* hc = h->h_ctrl;
@@ -1667,8 +1651,9 @@ extern "C" int exaadmm_run_fixed(exaadmm_handle* h, int iters, int first_major_i
         HIPCHK(hipMemcpyAsync(h->d_ctrl, hc, sizeof(Ctrl), hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         HIPCHK(hipEventRecord(h->ev[0], h->stream));
-        for (int i = 0; i < iters; i++) enqueue_iteration_spec(h, h->d_ctrl, i, false, time_branch ? &h->ev[2 + 2 * i] : nullptr);
-        spec_complete_last(h, iters);
+        for (int i = 0; i < iters; i++)
+            if ((rc = enqueue_iteration_spec(h, h->d_ctrl, i, false, time_branch ? &h->ev[2 + 2 * i] : nullptr))) return rc;
+        if ((rc = spec_complete_last(h, iters))) return rc;
         HIPCHK(hipEventRecord(h->ev[1], h->stream));
         if ((rc = spec_finish(h, iters))) return rc;
         double s[4];
@@ -1771,19 +1756,6 @@ extern "C" int exaadmm_set_async(exaadmm_handle* h, int async)
     return EXAADMM_OK;
 }
 
-extern "C" int exaadmm_set_active(exaadmm_handle* h, int64_t nbranch, int64_t nbus)
-{
-    REQUIRE(h && nbranch >= 0 && nbranch <= h->L && nbus >= 0 && nbus <= h->B, "active counts out of range");
-    REQUIRE(nbranch == h->d.La || getenv("EXAADMM_BRANCH_ORDER") != nullptr,
-            "active branch count must be given at create time (exaadmm_grid.nline_active): branches are stored bus-sorted");
-    h->d.La = (int)nbranch;
-    h->d.Ba = (int)nbus;
-    h->d.lpb = branch_lpb(h);
-    h->dev_dirty = true;
-    invalidate_graph(h);
-    return EXAADMM_OK;
-}
-
 static VecTable vec_table(exaadmm_handle* h)
 {
     VecTable t;
@@ -1836,25 +1808,6 @@ extern "C" int exaadmm_halo_unpack(exaadmm_handle* h, int slot, const double* de
     hipLaunchKernelGGL(k_scatter, grid_for(s.count, 256), dim3(256), 0, h->stream, vec_table(h), s.d_which, s.d_idx, s.count, dev_buf);
     h->residual_vectors_valid = false;
     return sync_check(h);
-}
-
-extern "C" int exaadmm_set_owned_mask(exaadmm_handle* h, const uint8_t* mask, int64_t nvar)
-{
-    REQUIRE(h, "null handle");
-    HIPCHK(hipSetDevice(h->device));
-    h->dev_dirty = true;
-    invalidate_graph(h);
-    if (!mask) {
-        h->d.owned = nullptr;
-        return EXAADMM_OK;
-    }
-    REQUIRE(nvar == h->nvar, "mask length must be nvar");
-    std::vector<unsigned char> t(h->N, 0);
-    for (int64_t r = 0; r < nvar; r++) t[soa_index(h, r)] = mask[r] ? 1 : 0;
-    if (!h->d_owned) HIPCHK(hipMalloc((void**)&h->d_owned, (size_t)h->N));
-    HIPCHK(hipMemcpy(h->d_owned, t.data(), (size_t)h->N, hipMemcpyHostToDevice));
-    h->d.owned = h->d_owned;
-    return EXAADMM_OK;
 }
 
 // ------------------------------------------------------------------ distributed inner loop inside the library (RCCL)

@@ -16,7 +16,7 @@ namespace exa {
 
 // loop control shared by the kernels of a fused inner loop (lives in device memory)
 struct Ctrl {
-    int done;         // set by k_final_reduce when the inner loop must stop
+    int done;         // set by the reduction (k_final_reduce / k_bus_group `red` / k_halo_unpack) when the inner loop must stop
     int inner;        // completed inner iterations
     int max_inner;
     int check_every;  // 1 = reference semantics
@@ -34,11 +34,9 @@ struct Ctrl {
 
 struct Dev {
     int G, L, B, Gp, Lp, N;
-    int La, Ba;  // active branches / buses (<= L, B): a partition's ghosts come after them
-    // branches per wavefront of the branch launch (1..64).  A trip of the solver loop costs a wavefront the MAXIMUM over
-    // its lanes of every data-dependent phase (faces, CG iterations, line-search trials), so while the chip has more
-    // SIMDs than the launch has wavefronts the branches are spread thinner than 64 per wave (exaadmm_hip.hip, branch_lpb)
-    int lpb;
+    // A partition (multi-GPU) stores the branches it owns first (from-bus local), then the replicas of the cut branches
+    // a peer owns (to-bus local).  All L are solved and updated here; only the first Lown count in the residual norms.
+    int Lown;
     double *u, *v, *z, *zp, *l, *lz, *rho;
     double *rp, *rd, *ax;
     const double* Y;    // 8 planes x Lp
@@ -48,22 +46,29 @@ struct Dev {
     const double *pgmin, *pgmax, *qgmin, *qgmax, *c2, *c1;
     const double* c0;  // multi-period model only (the ramp subproblem's objective carries the constant)
     const double *Pd, *Qd, *YshR, *YshI;
+    const double* busc;  // per bus, BUSC_N planes: what the bus update derives from rho and the shunt alone (k_bus_const)
     const int *FrStart, *FrIdx, *ToStart, *ToIdx, *GenStart, *GenIdx;
     const int *EndStart, *EndCode;  // per bus: generators, from-branches, to-branches (kind << 28 | index)
     // the same list laid out for the lane-group bus kernel: SlotCode[8 * bus + lane] = component of the bus's first chunk
     // served by that lane, EndCount[bus] = number of components -- one round of independent, coalesced loads instead of
     // the dependent pair EndStart -> EndCode (buses with more than 8 components use EndStart / EndCode for the rest)
     const int *SlotCode, *EndCount;
-    const unsigned char* owned;  // SoA order; nullptr = all owned
-    const int* lane_order;       // k_branch: lane i solves branch lane_order[i] (nullptr = identity)
     int *st_auglag, *st_minor, *st_ticks;
     unsigned long long* st_cyc;  // diagnostic build (EXA_PROFILE_PHASES): 13 x Lp phase cycle counters
     unsigned long long* st_tl;   // diagnostic build: 128 timeline entries per wavefront (2 x Lp)
     double* partials;  // [blocks][4]
-    // speculative branch launch: what the branch kernel READS (previous iterate; nullptr = the same buffers
-    // it writes), and the number of partial-sum blocks its extra block reduces
+    // speculative branch launch: what the branch kernel READS (previous iterate; nullptr = the same buffers it writes)
     const double *u_in, *ls1_in, *ls2_in, *mu_in;
-    int npartials;
+    // multi-GPU partition (dist_native.h): the ONE exchange of an iteration.  A bus-kernel lane that writes the v entries
+    // of a cut branch's local end also drops them into the send buffer (halo_pos[branch] = position of the 4 doubles;
+    // the component code carries END_CUT); the reduction block appends this rank's 4 partial sums to every peer's message.
+    // halo_off: [nranks] position of the sums in the message TO peer p, then [nranks] in the message FROM peer p.
+    int nranks, rank;
+    const int* halo_pos;
+    const int* halo_off;
+    double* halo_send;
+    const double* halo_recv;
+    double* halo_local;   // this rank's own 4 partial sums
     // fused z/l variant: v the branch launch reads (the bus launch of the same parity writes d.v), per-block partial
     // sums of the branch launch's z/l prologue
     const double* v_in;
@@ -190,60 +195,34 @@ __global__ void __launch_bounds__(64) k_gen_ramp(Dev d, BranchOptions o, double 
 // one lane per branch, 64 branches per wavefront.  Everything a lane needs -- the 32 read-only problem
 // constants (l, rho, v-z, Y), the packed 6x6 Hessian, its Cholesky factor and all vectors / scalars of
 // the solver -- lives in registers (256 VGPR + AGPR spill space, one wave per SIMD); the kernel uses no
-// LDS.  (The reference keeps 1728 B of shared memory per BRANCH and one 32-thread block per branch.)
-// Build variants kept for A/B runs and for bisecting compiler trouble: -DEXA_CONST_IN_LDS stages the
-// constants in LDS as [entry][lane] planes (16 KB per wavefront, conflict-free, compile-time offsets;
-// 3-15 % slower), -DEXA_A_IN_LDS / -DEXA_L_IN_LDS move the matrices there as well (another 6 %).
-#if !defined(EXA_CONST_IN_LDS) && !defined(EXA_A_IN_LDS) && !defined(EXA_L_IN_LDS) && !defined(EXA_CONST_IN_REGS)
-#define EXA_CONST_IN_REGS 1
-#endif
-#if defined(EXA_CONST_IN_REGS) && !defined(EXA_A_IN_LDS) && !defined(EXA_L_IN_LDS)
-#define EXA_HAVE_ZL 1   // the fused z/l prologue (k_branch_t<MP, true>) exists in this build
-#endif
-constexpr int BR_LDS_CONST = 32, BR_LDS_MAT = 21;
-#if defined(EXA_A_IN_LDS) && defined(EXA_L_IN_LDS)
-constexpr int BR_LDS_DOUBLES = BR_LDS_CONST + 2 * BR_LDS_MAT;
-#elif defined(EXA_A_IN_LDS) || defined(EXA_L_IN_LDS)
-constexpr int BR_LDS_DOUBLES = BR_LDS_CONST + BR_LDS_MAT;
-#elif defined(EXA_CONST_IN_REGS)
-constexpr int BR_LDS_DOUBLES = 0;
-#else
-constexpr int BR_LDS_DOUBLES = BR_LDS_CONST;
-#endif
-
+// LDS.  (The reference keeps 1728 B of shared memory per BRANCH and one 32-thread block per branch.
+// Variants measured and rejected -- constants / matrices staged in LDS, two waves per SIMD, fewer branches
+// per wavefront, lane regrouping: profiles/r02_two_waves_per_simd_experiments.txt, r02_lanes_per_wave.txt,
+// r02_wave_order_experiment.txt.)
+//
 // The Dev block is read through a pointer (not by-value kernel arguments): its ~40 pointers would
 // otherwise sit in SGPRs across the whole solver and spill.
 // MP = true: the generator blocks solve the ramp subproblems of the multi-period model (separate
 // instantiation so that the single-period kernel's code and register allocation stay untouched).
-// spec_j >= 0: speculative launch of iteration ctrl->base + spec_j + 1.  The launch does not wait for the
-// reduction of the previous iteration's residual sums: its LAST block performs that reduction (what
-// k_final_reduce does) while the other blocks already solve, reading the previous iterate from the *_in
-// buffers and writing the other set, so that a stop detected by the reduction leaves the iterate of the
-// stopping iteration intact.  One kernel boundary (4.3 us) less per iteration, no device-scope fence.
-#if !defined(EXA_BR_WAVES)
-#define EXA_BR_WAVES 1   // minimum waves per SIMD the register allocation must allow (2 -> at most 256 VGPR + AGPR)
-#endif
-// ZL = true (speculative loop on one GPU, single-period model): the z / l / residual pass of the PREVIOUS iteration rides
-// in this launch's prologue -- every lane already loads u, v, z, l, rho of its own 8 (generator lanes: 2) elements, so
-// the pass costs 8 more loads (lz) and its arithmetic instead of a kernel of its own (6 reads + 3 writes per element
-// and a launch); per-block partial sums of the four residual norms go to partials_br, the bus launch that follows
-// reduces them and advances the loop control (k_bus_group, `red`).  The launch is still speculative: it reads the
-// previous iterate (u_in, v_in, ls*_in) and writes the other buffer set, so a stop detected one launch later leaves
-// the iterate of the stopping iteration -- including the z, l this prologue has just completed for it -- intact.
+// ZL = true (the speculative loop, single-period model): launch of iteration ctrl->base + spec_j + 1.
+// The z / l / residual pass of the PREVIOUS iteration rides in this launch's prologue -- every lane already
+// loads u, v, z, l, rho of its own 8 (generator lanes: 2) elements, so the pass costs 8 more loads (lz) and
+// its arithmetic instead of a kernel of its own (6 reads + 3 writes per element and a launch); per-block
+// partial sums of the four residual norms go to partials_br, the bus launch that follows reduces them
+// (k_bus_group, `red`).  The launch is speculative: it does not wait for the loop test of the previous
+// iteration; it reads the previous iterate (u_in, v_in, ls*_in) and writes the other buffer set, so a stop
+// detected one launch later leaves the iterate of the stopping iteration -- including the z, l this prologue
+// has just completed for it -- intact.
+// A partition (multi-GPU) solves the cut branches it shares with a peer as well (bit-identical replicas on
+// both owners): branches at or past d.Lown run the same prologue and solve, but add nothing to the residual sums.
 template <bool MP, bool ZL = false>
-__global__ void __launch_bounds__(BR_BLOCK, EXA_BR_WAVES) k_branch_t(const Dev* __restrict__ dp, BranchOptions o, double scale, int major_iter, Ctrl* ctrl,
-                                                       int gen_blocks, double baseMVA, int spec_j)
+__global__ void __launch_bounds__(BR_BLOCK, 1) k_branch_t(const Dev* __restrict__ dp, BranchOptions o, double scale, int major_iter, Ctrl* ctrl,
+                                                           int gen_blocks, double baseMVA, int spec_j)
 {
-#if defined(EXA_CONST_IN_REGS) && !defined(EXA_A_IN_LDS) && !defined(EXA_L_IN_LDS)
-    double* const lds = nullptr;   // no LDS at all in the default build
-#else
-    __shared__ double lds[(BR_LDS_DOUBLES > 0 ? BR_LDS_DOUBLES : 1) * BR_BLOCK];
-#endif
 #if defined(EXA_PROFILE_PHASES)
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();   // first instruction of the wave
 #endif
     const Dev& d = *dp;
-    int extra = 0;
     bool do_zl = false;
     double zl_beta = 0.0;
     if (ZL) {
@@ -251,44 +230,14 @@ __global__ void __launch_bounds__(BR_BLOCK, EXA_BR_WAVES) k_branch_t(const Dev* 
         major_iter = ctrl->base + spec_j + 1;
         do_zl = (major_iter != ctrl->first_iter);
         zl_beta = ctrl->beta;
-        if (do_zl && blockIdx.x == 0 && threadIdx.x == 0) ctrl->pending = 1;   // read by the NEXT launch only (bus, `red`)
-    } else if (spec_j >= 0) {
-        extra = 1;
-        if ((int)blockIdx.x == (int)gridDim.x - 1) {   // the reduction block
-            if (ctrl->done || !ctrl->pending) return;
-            double s4[4] = {0.0, 0.0, 0.0, 0.0};
-            for (int bq = threadIdx.x; bq < d.npartials; bq += BR_BLOCK) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) s4[j] += d.partials[bq * 4 + j];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) s4[j] += __shfl_down(s4[j], off, 64);
-            }
-            if (threadIdx.x == 0) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    ctrl->sums[j] = s4[j];
-                    ctrl->res[j] = sqrt(s4[j]);
-                }
-                const int inner = ctrl->inner + 1;
-                ctrl->inner = inner;
-                ctrl->pending = 0;
-                const bool test = (ctrl->check_every <= 1) || (inner % ctrl->check_every == 0);
-                if ((test && ctrl->res[0] <= ctrl->eps_pri) || inner >= ctrl->max_inner) ctrl->done = 1;
-            }
-            return;
-        }
-        if (ctrl->done) return;   // (may be set concurrently by the reduction block: then this launch is discarded anyway)
-        major_iter = ctrl->base + spec_j + 1;
+        if (do_zl && blockIdx.x == 0 && threadIdx.x == 0) ctrl->pending = 1;   // read by the NEXT launches only (bus `red`, k_halo_unpack)
     } else if (ctrl != nullptr) {
         if (ctrl->done) return;
         major_iter = ctrl->inner + 1;
     }
     // blocks past the branch range do the generator update (independent of the branches; one
     // launch and one inter-kernel gap less per iteration).  gen_blocks = 0: branches only.
-    const int nbr_blocks = gridDim.x - gen_blocks - extra;
+    const int nbr_blocks = gridDim.x - gen_blocks;
     double zs[4] = {0.0, 0.0, 0.0, 0.0};   // ZL: this lane's residual terms
     if ((int)blockIdx.x >= nbr_blocks) {
         const int gi = ((int)blockIdx.x - nbr_blocks) * BR_BLOCK + threadIdx.x;
@@ -318,25 +267,21 @@ __global__ void __launch_bounds__(BR_BLOCK, EXA_BR_WAVES) k_branch_t(const Dev* 
             generator_update(d, baseMVA, gi);
         return;
     }
-    const int slot = blockIdx.x * d.lpb + threadIdx.x;
-    const bool lane_on = (int)threadIdx.x < d.lpb && slot < d.La;
+    const int slot = blockIdx.x * BR_BLOCK + threadIdx.x;
+    const bool lane_on = slot < d.L;
     if (!ZL && !lane_on) return;
 #if defined(EXA_PROFILE_PHASES)
     const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
 #endif
-    // which lane solves a branch does not change any result; lane_order exists for experiments
-    // (regrouping lanes by work does not pay in either regime)
-    const int b = (!ZL && d.lane_order) ? d.lane_order[slot] : (lane_on ? slot : 0);   // (ZL: lanes past the range read branch 0, write nothing)
+    const int b = lane_on ? slot : 0;   // (ZL: lanes past the range read branch 0, write nothing)
     const int Lp = d.Lp;
     const int base = 2 * d.Gp + b;
-    double* my = lds + threadIdx.x;
     const double* const uin = d.u_in ? d.u_in : d.u;
     const double* const vin = (ZL && d.v_in) ? d.v_in : d.v;
 
     double ub[8], bnd[8];
-#if defined(EXA_CONST_IN_REGS)
     BranchData bd;
-    double ls1_0 = 0.0, ls2_0 = 0.0, mu_0 = 0.0, rate_0 = 0.0;
+    double rate_0;
     if (ZL) {
         // Every load of the prologue first, every store after them.  As far as the compiler knows the planes may alias,
         // so a store between two loads is a full memory round trip: with the z/l pass written element by element
@@ -355,9 +300,9 @@ __global__ void __launch_bounds__(BR_BLOCK, EXA_BR_WAVES) k_branch_t(const Dev* 
             bd.Y_[k] = d.Y[b + k * Lp];
             bnd[k] = d.bnd[b + k * Lp];
         }
-        ls1_0 = (d.ls1_in ? d.ls1_in : d.ls1)[b];
-        ls2_0 = (d.ls2_in ? d.ls2_in : d.ls2)[b];
-        mu_0 = (d.mu_in ? d.mu_in : d.mu)[b];
+        bd.ls1 = (d.ls1_in ? d.ls1_in : d.ls1)[b];
+        bd.ls2 = (d.ls2_in ? d.ls2_in : d.ls2)[b];
+        const double mu_0 = (d.mu_in ? d.mu_in : d.mu)[b];
         rate_0 = d.rateA[b];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
@@ -374,6 +319,21 @@ __global__ void __launch_bounds__(BR_BLOCK, EXA_BR_WAVES) k_branch_t(const Dev* 
                 bd.xt_[k] = vv[k] - zo[k];
             }
         }
+        if (do_zl) {   // per-block partial sums of the four residual norms (fixed topology: wave shuffle, one wave per block)
+            const bool counts = (b < d.Lown);   // a peer's branch replicated here: its terms are summed by its owner
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (!counts) zs[j] = 0.0;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) zs[j] += __shfl_down(zs[j], off, 64);
+            }
+            if (threadIdx.x == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) d.partials_br[blockIdx.x * 4 + j] = zs[j];
+            }
+        }
+        if (!lane_on) return;
+        bd.mu = (major_iter == 1) ? 10.0 : mu_0;
     } else {
 #pragma unroll
         for (int k = 0; k < 8; k++) {
@@ -385,75 +345,29 @@ __global__ void __launch_bounds__(BR_BLOCK, EXA_BR_WAVES) k_branch_t(const Dev* 
             bd.Y_[k] = d.Y[b + k * Lp];
             bnd[k] = d.bnd[b + k * Lp];
         }
-    }
-    (void)my;
-#else
-    static_assert(!ZL, "the fused z/l prologue is only built for the register-resident constants layout");
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const int e = base + k * Lp;
-        ub[k] = uin[e];
-        my[k * BR_BLOCK] = d.l[e];
-        my[(8 + k) * BR_BLOCK] = d.rho[e];
-        my[(16 + k) * BR_BLOCK] = d.v[e] - d.z[e];
-        my[(24 + k) * BR_BLOCK] = d.Y[b + k * Lp];
-        bnd[k] = d.bnd[b + k * Lp];
-    }
-    BranchDataRef<BR_BLOCK> bd;
-    bd.p = my;
-#endif
-    if (ZL) {
-        if (do_zl) {   // per-block partial sums of the four residual norms (fixed topology: wave shuffle, one wave per block)
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) zs[j] += __shfl_down(zs[j], off, 64);
-            }
-            if (threadIdx.x == 0) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) d.partials_br[blockIdx.x * 4 + j] = zs[j];
-            }
-        }
-        if (!lane_on) return;
-    }
-#if defined(EXA_CONST_IN_REGS)
-    if (ZL) {
-        bd.ls1 = ls1_0;
-        bd.ls2 = ls2_0;
-        bd.mu = (major_iter == 1) ? 10.0 : mu_0;
-    } else
-#endif
-    {
         bd.ls1 = (d.ls1_in ? d.ls1_in : d.ls1)[b];
         bd.ls2 = (d.ls2_in ? d.ls2_in : d.ls2)[b];
         bd.mu = (major_iter == 1) ? 10.0 : (d.mu_in ? d.mu_in : d.mu)[b];
+        rate_0 = d.rateA[b];
     }
     bd.scale = scale;
-#if defined(EXA_A_IN_LDS)
-    SymRef<6, BR_BLOCK> A{my + BR_LDS_CONST * BR_BLOCK};
-#else
-    SymMat<6> A;
-#endif
-#if defined(EXA_L_IN_LDS)
-    SymRef<6, BR_BLOCK> L{my + (BR_LDS_DOUBLES - BR_LDS_MAT) * BR_BLOCK};
-#else
-    SymMat<6> L;
-#endif
+    SymMat<6> A, L;
 
     double x[6], xl[6], xu[6], phi[4];
-#if defined(EXA_CONST_IN_REGS)
-    branch_start(ub, bnd, ZL ? rate_0 : d.rateA[b], x, xl, xu);
-#else
-    branch_start(ub, bnd, d.rateA[b], x, xl, xu);
-#endif
+    branch_start(ub, bnd, rate_0, x, xl, xu);
     BranchStats st;
 #if defined(EXA_PROFILE_PHASES)
-    st.tl = d.st_tl ? d.st_tl + (size_t)blockIdx.x * 128 : nullptr;   // (the diagnostic build keeps 64 branches per wave)
+    st.tl = d.st_tl ? d.st_tl + (size_t)blockIdx.x * 128 : nullptr;
     // force the loads to land before the stamp: consume one loaded value in the asm dependency
     unsigned long long t_loaded;
     asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_loaded) : "v"(x[0]) : "memory");
 #endif
+#if defined(EXA_PARK_CONST)
+    __shared__ double park_lds[32 * BR_BLOCK];
+    branch_solve(bd, o, c_mupow, x, xl, xu, A, L, phi, st, park_lds + threadIdx.x);
+#else
     branch_solve(bd, o, c_mupow, x, xl, xu, A, L, phi, st);
+#endif
 #if defined(EXA_PROFILE_PHASES)
     const unsigned long long t_solved = __builtin_amdgcn_s_memtime();
 #endif
@@ -486,115 +400,6 @@ __global__ void __launch_bounds__(BR_BLOCK, EXA_BR_WAVES) k_branch_t(const Dev* 
 #endif
 }
 
-// ---------------------------------------------------------------- branch, throughput variant
-// Same solver, same arithmetic, laid out for TWO resident waves per SIMD (<= 256 VGPR + AGPR): used when the launch has
-// more wavefronts than the chip has SIMDs (1024), i.e. when waves queue behind each other and a second resident wave
-// fills the issue slots a single FP64 dependency chain leaves empty (one wave alone issues a VALU instruction every
-// ~8 cycles, PMC: VALU busy 0.54 at 1M branches).  What leaves the register file:
-//   * Hessian and Cholesky factor live in LDS as [entry][lane] planes (2 x 21 doubles x 64 lanes = 21.5 KB per wave,
-//     conflict-free, 7 waves per CU);
-//   * the 32 read-only problem constants are not held at all: every objective / derivative evaluation fetches them
-//     again from the planes of l, rho, v, z, Y (BranchDataGlobal) -- cache-resident, and the other wave computes meanwhile.
-// Single-period model; the generator blocks and the speculative reduction block are those of k_branch_t.
-// MEASURED AND REJECTED (round 2; off unless EXAADMM_TP_MIN_BLOCKS is set): with A, L and the constants out of the
-// register file the compiler still needs 256 VGPRs + 1292 B of scratch per lane (372 spilled registers: the peak is
-// the Hessian assembly -- 43 gradient intermediates + the 32 constants being consumed + the solver's persistent vectors),
-// and the scratch traffic makes the launch 3.2x (88 207 branches) to 4.6x (1M branches) slower than one wave per SIMD.
-// The plain register cap without LDS (-DEXA_BR_WAVES=2: 760 B scratch) is 2.3x slower, with the constants in LDS 1.8x.
-constexpr int TP_LDS_DOUBLES = 2 * 21;
-__global__ void __launch_bounds__(BR_BLOCK, 2) k_branch_tp(const Dev* __restrict__ dp, BranchOptions o, double scale, int major_iter, Ctrl* ctrl,
-                                                           int gen_blocks, double baseMVA, int spec_j)
-{
-    __shared__ double lds[TP_LDS_DOUBLES * BR_BLOCK];
-    const Dev& d = *dp;
-    int extra = 0;
-    if (spec_j >= 0) {
-        extra = 1;
-        if ((int)blockIdx.x == (int)gridDim.x - 1) {   // the reduction block (see k_branch_t)
-            if (ctrl->done || !ctrl->pending) return;
-            double s4[4] = {0.0, 0.0, 0.0, 0.0};
-            for (int bq = threadIdx.x; bq < d.npartials; bq += BR_BLOCK) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) s4[j] += d.partials[bq * 4 + j];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) s4[j] += __shfl_down(s4[j], off, 64);
-            }
-            if (threadIdx.x == 0) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    ctrl->sums[j] = s4[j];
-                    ctrl->res[j] = sqrt(s4[j]);
-                }
-                const int inner = ctrl->inner + 1;
-                ctrl->inner = inner;
-                ctrl->pending = 0;
-                const bool test = (ctrl->check_every <= 1) || (inner % ctrl->check_every == 0);
-                if ((test && ctrl->res[0] <= ctrl->eps_pri) || inner >= ctrl->max_inner) ctrl->done = 1;
-            }
-            return;
-        }
-        if (ctrl->done) return;
-        major_iter = ctrl->base + spec_j + 1;
-    } else if (ctrl != nullptr) {
-        if (ctrl->done) return;
-        major_iter = ctrl->inner + 1;
-    }
-    const int nbr_blocks = gridDim.x - gen_blocks - extra;
-    if ((int)blockIdx.x >= nbr_blocks) {
-        generator_update(d, baseMVA, ((int)blockIdx.x - nbr_blocks) * BR_BLOCK + threadIdx.x);
-        return;
-    }
-    const int b = blockIdx.x * BR_BLOCK + threadIdx.x;
-    if (b >= d.La) return;
-    const int Lp = d.Lp;
-    const int base = 2 * d.Gp + b;
-    const double* const uin = d.u_in ? d.u_in : d.u;
-    double x[6], xl[6], xu[6], phi[4];
-    {
-        double ub[8], bnd[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            ub[k] = uin[base + k * Lp];
-            bnd[k] = d.bnd[b + k * Lp];
-        }
-        branch_start(ub, bnd, d.rateA[b], x, xl, xu);
-    }
-    BranchDataGlobal bd;
-    bd.pl = d.l + 2 * d.Gp;
-    bd.prho = d.rho + 2 * d.Gp;
-    bd.pv = d.v + 2 * d.Gp;
-    bd.pz = d.z + 2 * d.Gp;
-    bd.pY = d.Y;
-    bd.Lp = Lp;
-    bd.b = (unsigned)b;
-    bd.ls1 = (d.ls1_in ? d.ls1_in : d.ls1)[b];
-    bd.ls2 = (d.ls2_in ? d.ls2_in : d.ls2)[b];
-    bd.mu = (major_iter == 1) ? 10.0 : (d.mu_in ? d.mu_in : d.mu)[b];
-    bd.scale = scale;
-    SymRef<6, BR_BLOCK> A{lds + threadIdx.x};
-    SymRef<6, BR_BLOCK> L{lds + 21 * BR_BLOCK + threadIdx.x};
-    BranchStats st;
-    st.tl = nullptr;
-    branch_solve(bd, o, c_mupow, x, xl, xu, A, L, phi, st);
-    d.u[base] = phi[0];
-    d.u[base + Lp] = phi[1];
-    d.u[base + 2 * Lp] = phi[2];
-    d.u[base + 3 * Lp] = phi[3];
-    d.u[base + 4 * Lp] = x[0] * x[0];
-    d.u[base + 5 * Lp] = x[1] * x[1];
-    d.u[base + 6 * Lp] = x[2];
-    d.u[base + 7 * Lp] = x[3];
-    d.ls1[b] = bd.ls1;
-    d.ls2[b] = bd.ls2;
-    d.mu[b] = bd.mu;
-    d.st_auglag[b] = st.auglag_it;
-    d.st_minor[b] = st.minor_it;
-    d.st_ticks[b] = st.ticks;
-}
-
 // Multi-period model: the real power of a generator of period t < T-1 is also tied to the copy
 // phat kept by period t+1 (ramp block index pg + g1); the last period has no such partner.
 __device__ __forceinline__ bool bus_gen_has_ramp(const Dev& d, int pg) { return d.T > 1 && pg < (d.T - 1) * d.g1; }
@@ -606,7 +411,7 @@ __global__ void k_bus(Dev d, double baseMVA, const Ctrl* ctrl)
 {
     if (loop_done(ctrl)) return;
     const int I = blockIdx.x * blockDim.x + threadIdx.x;
-    if (I >= d.Ba) return;
+    if (I >= d.B) return;
     const int Lp = d.Lp, Gp = d.Gp, lb = 2 * d.Gp;
     const double *u = d.u, *z = d.z, *l = d.l, *rho = d.rho;
     double* v = d.v;
@@ -712,23 +517,29 @@ __global__ void k_bus(Dev d, double baseMVA, const Ctrl* ctrl)
 // (acopf_bus_kernel_gpu.jl:1-119), organised for latency: BUS_W lanes serve one bus.
 //   * every lane fetches ONE incident component (generator / from-end / to-end) of the bus --
 //     the gathers of a bus are issued in parallel instead of one dependent loop per lane;
-//   * the records are parked in LDS ([entry][lane] inside the group) and the group leader
-//     accumulates them in the reference's order (generators, -Pd, from-ends, to-ends), so the
-//     floating-point result is identical to the one-lane-per-bus kernel;
+//   * each lane evaluates the TERMS the reference adds up, exactly as written there, and parks them in
+//     LDS ([term][lane] inside the group); the group leader adds them in the reference's order (generators,
+//     -Pd, from-ends, to-ends), so the floating-point result is identical to the one-lane-per-bus kernel;
+//   * everything that depends on rho and the shunt only -- the sums of rho and of 1/rho over the bus's
+//     components, the 2x2 matrix A11, A12, A22 built from them, A21/A11 and the pivot A22 - (A21/A11) A12 -- is
+//     constant while rho is (it is, inside a solve): k_bus_const evaluates it once per rho upload, in the
+//     reference's order, and the leader reads six doubles per bus instead of re-deriving them from 2 rho gathers per
+//     component, five divisions shorter;
 //   * the leader publishes mu1, mu2, w, theta through LDS and every lane writes the v entries
 //     of its own component from the registers it already holds.
 // Buses with more than BUS_W incident components are processed in chunks.
-#if !defined(EXA_BUS_W)
-#define EXA_BUS_W 8   // measured at 13 659 buses (kernel-trace average): 8 -> 12.8, 16 -> 13.5, 32 -> 15.5 us
-#endif
-constexpr int BUS_W = EXA_BUS_W;
+constexpr int BUS_W = 8;         // measured at 13 659 buses (kernel-trace average): 8 -> 12.8, 16 -> 13.5, 32 -> 15.5 us
 constexpr int BUS_BLOCK = 256;   // measured at 13 659 buses: 64 -> 15.1, 128 -> 14.5, 256 -> 12.4, 512 -> 11.9, 1024 -> 13.2 us; 512 loses 5 % of the non-branch time at 1M branches
+static_assert(BUS_BLOCK == EW_BLOCK, "the reduction block of k_bus_group uses block_reduce4, which is laid out for EW_BLOCK threads");
 constexpr int BUS_REC = 16;  // doubles per record: (u,z,l,rho) x (p,q,w,theta) or (u,z,l,rho) x (pg,qg)
 enum { END_GEN = 0, END_FROM = 1, END_TO = 2 };
+constexpr int END_CUT = 1 << 30;        // component code flag: the branch is shared with a peer partition (its v entries go into the halo message)
+constexpr int END_INDEX = 0x0fffffff;
+constexpr int BUSC_A11 = 0, BUSC_A12 = 1, BUSC_R21 = 2, BUSC_PIV = 3, BUSC_RW = 4, BUSC_RT = 5, BUSC_N = 6;   // planes of Dev::busc
 
 __device__ __forceinline__ void bus_load_end(const Dev& d, int code, double (&r)[BUS_REC], int (&idx)[4])
 {
-    const int kind = code >> 28, c = code & 0x0fffffff;
+    const int kind = (code >> 28) & 3, c = code & END_INDEX;
     const int Lp = d.Lp;
     if (kind == END_GEN) {
         idx[0] = c;
@@ -764,17 +575,76 @@ __device__ __forceinline__ void bus_load_end(const Dev& d, int code, double (&r)
     }
 }
 
+// The rho-only part of the bus update, one lane per bus, in the order k_bus adds things up: rerun whenever rho changes
+// (upload of rho, init_solution).  busc: BUSC_N planes of B doubles.
+__global__ void k_bus_const(Dev d, double* busc)
+{
+    const int I = blockIdx.x * blockDim.x + threadIdx.x;
+    if (I >= d.B) return;
+    const int Lp = d.Lp, Gp = d.Gp, lb = 2 * d.Gp;
+    const double* rho = d.rho;
+    double inv_rhosum_p = 0.0, inv_rhosum_q = 0.0, rhosum_w = 0.0, rhosum_t = 0.0;
+    for (int k = d.FrStart[I]; k < d.FrStart[I + 1]; k++) {
+        const int e = lb + d.FrIdx[k];
+        inv_rhosum_p += 1.0 / rho[e];
+        inv_rhosum_q += 1.0 / rho[e + Lp];
+        rhosum_w += rho[e + 4 * Lp];
+        rhosum_t += rho[e + 6 * Lp];
+    }
+    for (int k = d.ToStart[I]; k < d.ToStart[I + 1]; k++) {
+        const int e = lb + d.ToIdx[k];
+        inv_rhosum_p += 1.0 / rho[e + 2 * Lp];
+        inv_rhosum_q += 1.0 / rho[e + 3 * Lp];
+        rhosum_w += rho[e + 5 * Lp];
+        rhosum_t += rho[e + 7 * Lp];
+    }
+    double inv_rhosum_pg = 0.0, inv_rhosum_qg = 0.0;
+    for (int k = d.GenStart[I]; k < d.GenStart[I + 1]; k++) {
+        const int pg = d.GenIdx[k], qg = Gp + pg;
+        if (bus_gen_has_ramp(d, pg))
+            inv_rhosum_pg += 1.0 / (rho[pg] + d.r_rho[pg + d.g1]);
+        else
+            inv_rhosum_pg += 1.0 / rho[pg];
+        inv_rhosum_qg += 1.0 / rho[qg];
+    }
+    const double ysr = d.YshR[I], ysi = d.YshI[I];
+    const double A11 = (inv_rhosum_pg + inv_rhosum_p) + (ysr * ysr / rhosum_w);
+    const double A12 = -ysr * (ysi / rhosum_w);
+    const double A21 = A12;
+    const double A22 = (inv_rhosum_qg + inv_rhosum_q) + (ysi * ysi / rhosum_w);
+    const double r21 = A21 / A11;
+    busc[BUSC_A11 * d.B + I] = A11;
+    busc[BUSC_A12 * d.B + I] = A12;
+    busc[BUSC_R21 * d.B + I] = r21;
+    busc[BUSC_PIV * d.B + I] = A22 - r21 * A12;
+    busc[BUSC_RW * d.B + I] = rhosum_w;
+    busc[BUSC_RT * d.B + I] = rhosum_t;
+}
+
 __device__ __forceinline__ void block_reduce4(double (&s)[4]);   // (defined with the elementwise kernels below)
 
-// red != nullptr (fused z/l variant of the speculative loop): the launch carries one extra block that sums the
-// per-block residual terms the preceding branch launch's prologue left in partials_br and advances the loop control
-// (what k_final_reduce does), while the other blocks update their buses.
+// inner++, norms, stop test (admm_two_level.jl:45,60-62 evaluated on the device) from the four sums of squares
+__device__ __forceinline__ void ctrl_advance(Ctrl* c, const double (&s)[4])
+{
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        c->sums[j] = s[j];
+        c->res[j] = sqrt(s[j]);
+    }
+    const int inner = c->inner + 1;
+    c->inner = inner;
+    c->pending = 0;
+    const bool test = (c->check_every <= 1) || (inner % c->check_every == 0);
+    if ((test && c->res[0] <= c->eps_pri) || inner >= c->max_inner) c->done = 1;
+}
+
+// red != nullptr (the speculative loop): the launch carries one extra block that sums the per-block residual terms the
+// preceding branch launch's prologue left in partials_br.  One GPU: it advances the loop control itself (what
+// k_final_reduce does).  A partition with peers: it appends the four partial sums to every peer's halo message; the loop
+// control is advanced by k_halo_unpack once the peers' sums have arrived.
 __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group(Dev d, double baseMVA, const Ctrl* ctrl, Ctrl* red)
 {
-    // per component the lane computes the TERMS the reference adds up (each term is evaluated
-    // exactly as written there: l + rho*(u+z), 1/rho, (u+z) + l/rho); the leader only adds them
-    // in the reference's order, so its dependent chain contains no division.
-    constexpr int T_W = 0, T_T = 1, T_IP = 2, T_IQ = 3, T_RW = 4, T_RT = 5, T_P = 6, T_Q = 7, NTERM = 8;
+    constexpr int T_W = 0, T_T = 1, T_P = 2, T_Q = 3, NTERM = 4;
     __shared__ double term[BUS_BLOCK / BUS_W][NTERM][BUS_W];
     __shared__ int kinds[BUS_BLOCK / BUS_W][BUS_W];
     __shared__ double res[BUS_BLOCK / BUS_W][4];
@@ -787,16 +657,16 @@ __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group(Dev d, double baseMVA, 
         }
         block_reduce4(s4);
         if (threadIdx.x == 0) {
+            if (d.nranks > 1) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                red->sums[j] = s4[j];
-                red->res[j] = sqrt(s4[j]);
-            }
-            const int inner = red->inner + 1;
-            red->inner = inner;
-            red->pending = 0;
-            const bool test = (red->check_every <= 1) || (inner % red->check_every == 0);
-            if ((test && red->res[0] <= red->eps_pri) || inner >= red->max_inner) red->done = 1;
+                for (int j = 0; j < 4; j++) d.halo_local[j] = s4[j];
+                for (int p = 0; p < d.nranks; p++) {
+                    if (p == d.rank) continue;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) d.halo_send[d.halo_off[p] + j] = s4[j];
+                }
+            } else
+                ctrl_advance(red, s4);
         }
         return;
     }
@@ -806,7 +676,7 @@ __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group(Dev d, double baseMVA, 
 #if defined(EXA_PROFILE_PHASES)
     unsigned long long tb0 = __builtin_amdgcn_s_memtime(), tb1 = 0, tb2 = 0, tb3 = 0, tb4 = 0;
 #endif
-    if (I >= d.Ba) return;   // whole groups leave together
+    if (I >= d.B) return;   // whole groups leave together
     const int n = d.EndCount[I];
     const int code0 = d.SlotCode[I * BUS_W + lane];
     const int e0 = (n > BUS_W) ? d.EndStart[I] : 0;   // (only the rare large buses need the CSR offset)
@@ -815,40 +685,33 @@ __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group(Dev d, double baseMVA, 
 #endif
 
     // leader state (meaningful in lane 0 only)
-    double common_wi = 0.0, common_ti = 0.0, inv_rhosum_p = 0.0, inv_rhosum_q = 0.0;
-    double rhosum_w = 0.0, rhosum_t = 0.0, rhs1 = 0.0, rhs2 = 0.0, inv_rhosum_pg = 0.0, inv_rhosum_qg = 0.0;
+    double common_wi = 0.0, common_ti = 0.0, rhs1 = 0.0, rhs2 = 0.0;
     bool load_subtracted = false;
     const double pd = d.Pd[I] / baseMVA, qd = d.Qd[I] / baseMVA;
-    // (fetched here with everything else, ahead of the wavefront fences; measured neutral: 4.36 k -> 4.30 k clocks for the
-    //  leader's section, scripts/bus_stamps.py)
     const double ysr = d.YshR[I], ysi = d.YshI[I];
+    // the bus's rho-only constants (k_bus_const), fetched with everything else ahead of the wavefront fences
+    const double A11 = d.busc[BUSC_A11 * d.B + I], A12 = d.busc[BUSC_A12 * d.B + I], r21 = d.busc[BUSC_R21 * d.B + I];
+    const double piv = d.busc[BUSC_PIV * d.B + I], rhosum_w = d.busc[BUSC_RW * d.B + I], rhosum_t = d.busc[BUSC_RT * d.B + I];
 
     double r[BUS_REC];
-    int idx[4], kind = -1;
+    int idx[4], kind = -1, code = 0;
     for (int c0 = 0; c0 < n; c0 += BUS_W) {
         const int m = min(BUS_W, n - c0);
         if (lane < m) {
-            const int code = (c0 == 0) ? code0 : d.EndCode[e0 + c0 + lane];
-            kind = code >> 28;
+            code = (c0 == 0) ? code0 : d.EndCode[e0 + c0 + lane];
+            kind = (code >> 28) & 3;
             bus_load_end(d, code, r, idx);
 #if defined(EXA_PROFILE_PHASES)
             asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb2) : "v"(r[0]) : "memory");
 #endif
             kinds[grp][lane] = kind;
-            if (idx[2] <= -2) {  // generator with a ramp partner (mpacopf_bus_kernel_cpu.jl:53-62)
-                const double den = r[3] + r[11];
-                term[grp][T_P][lane] = ((r[2] + r[3] * (r[0] + r[1])) + (r[10] + r[11] * (r[8] + r[9]))) / den;
-                term[grp][T_IP][lane] = 1.0 / den;
-            } else {
+            if (idx[2] <= -2)  // generator with a ramp partner (mpacopf_bus_kernel_cpu.jl:53-62)
+                term[grp][T_P][lane] = ((r[2] + r[3] * (r[0] + r[1])) + (r[10] + r[11] * (r[8] + r[9]))) / (r[3] + r[11]);
+            else
                 term[grp][T_P][lane] = (r[0] + r[1]) + (r[2] / r[3]);
-                term[grp][T_IP][lane] = 1.0 / r[3];
-            }
             term[grp][T_Q][lane] = (r[4] + r[5]) + (r[6] / r[7]);
-            term[grp][T_IQ][lane] = 1.0 / r[7];
             term[grp][T_W][lane] = r[10] + r[11] * (r[8] + r[9]);
             term[grp][T_T][lane] = r[14] + r[15] * (r[12] + r[13]);
-            term[grp][T_RW][lane] = r[11];
-            term[grp][T_RT][lane] = r[15];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -858,8 +721,6 @@ __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group(Dev d, double baseMVA, 
                 if (kinds[grp][k] == END_GEN) {
                     rhs1 += term[grp][T_P][k];
                     rhs2 += term[grp][T_Q][k];
-                    inv_rhosum_pg += term[grp][T_IP][k];
-                    inv_rhosum_qg += term[grp][T_IQ][k];
                 } else {
                     if (!load_subtracted) {
                         rhs1 -= pd;
@@ -868,10 +729,6 @@ __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group(Dev d, double baseMVA, 
                     }
                     common_wi += term[grp][T_W][k];
                     common_ti += term[grp][T_T][k];
-                    inv_rhosum_p += term[grp][T_IP][k];
-                    inv_rhosum_q += term[grp][T_IQ][k];
-                    rhosum_w += term[grp][T_RW][k];
-                    rhosum_t += term[grp][T_RT][k];
                     rhs1 -= term[grp][T_P][k];
                     rhs2 -= term[grp][T_Q][k];
                 }
@@ -888,11 +745,7 @@ __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group(Dev d, double baseMVA, 
         common_wi /= rhosum_w;
         rhs1 -= ysr * common_wi;
         rhs2 += ysi * common_wi;
-        const double A11 = (inv_rhosum_pg + inv_rhosum_p) + (ysr * ysr / rhosum_w);
-        const double A12 = -ysr * (ysi / rhosum_w);
-        const double A21 = A12;
-        const double A22 = (inv_rhosum_qg + inv_rhosum_q) + (ysi * ysi / rhosum_w);
-        const double mu2 = (rhs2 - (A21 / A11) * rhs1) / (A22 - (A21 / A11) * A12);
+        const double mu2 = (rhs2 - r21 * rhs1) / piv;
         const double mu1 = (rhs1 - A12 * mu2) / A11;
         res[grp][0] = mu1;
         res[grp][1] = mu2;
@@ -911,8 +764,8 @@ __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group(Dev d, double baseMVA, 
         const int m = min(BUS_W, n - c0);
         if (lane < m) {
             if (n > BUS_W) {  // registers only hold the last chunk: fetch this one again
-                const int code = (c0 == 0) ? code0 : d.EndCode[e0 + c0 + lane];
-                kind = code >> 28;
+                code = (c0 == 0) ? code0 : d.EndCode[e0 + c0 + lane];
+                kind = (code >> 28) & 3;
                 bus_load_end(d, code, r, idx);
             }
             if (kind == END_GEN) {
@@ -922,10 +775,19 @@ __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group(Dev d, double baseMVA, 
                     d.v[idx[0]] = (r[0] + r[1]) + (r[2] - mu1) / r[3];
                 d.v[idx[1]] = (r[4] + r[5]) + (r[6] - mu2) / r[7];
             } else {
-                d.v[idx[0]] = (r[0] + r[1]) + (r[2] + mu1) / r[3];
-                d.v[idx[1]] = (r[4] + r[5]) + (r[6] + mu2) / r[7];
+                const double vp = (r[0] + r[1]) + (r[2] + mu1) / r[3];
+                const double vq = (r[4] + r[5]) + (r[6] + mu2) / r[7];
+                d.v[idx[0]] = vp;
+                d.v[idx[1]] = vq;
                 d.v[idx[2]] = wi;
                 d.v[idx[3]] = ti;
+                if (code & END_CUT) {   // this end's new v entries are the peer's missing half of the branch: into its message
+                    double* q = d.halo_send + d.halo_pos[code & END_INDEX];
+                    q[0] = vp;
+                    q[1] = vq;
+                    q[2] = wi;
+                    q[3] = ti;
+                }
             }
         }
     }
@@ -938,16 +800,70 @@ __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group(Dev d, double baseMVA, 
 #endif
 }
 
+// The receiving half of a partition's one exchange per iteration (dist_native.h), after the grouped ncclSend / ncclRecv:
+//   * thread i scatters the 4 v entries of cut branch i that the peer's bus update produced (the half of the branch
+//     that lives on the peer's bus) into v;
+//   * thread 0 adds the ranks' partial residual sums IN RANK ORDER (the same order, hence the same bits and the same
+//     decision, on every rank) and advances the loop control -- or, out != nullptr, just delivers the totals.
+// rcode[i] = (side << 28) | local branch, side END_FROM / END_TO = which half ARRIVES, rpos[i] = where in the receive
+// buffer (a peer's message is its cut branches' entries followed by its four sums); n_cut = 0: sums only.
+__global__ void k_halo_unpack(Dev d, const int* rcode, const int* rpos, int n_cut, Ctrl* ctrl, double* out, int need_pending)
+{
+    if (ctrl != nullptr && ctrl->done) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_cut) {
+        const int code = rcode[i], c = code & END_INDEX;
+        const bool from = ((code >> 28) & 3) == END_FROM;
+        const double* q = d.halo_recv + rpos[i];
+        const int e = 2 * d.Gp + c, Lp = d.Lp;
+        d.v[e + (from ? 0 : 2) * Lp] = q[0];
+        d.v[e + (from ? 1 : 3) * Lp] = q[1];
+        d.v[e + (from ? 4 : 5) * Lp] = q[2];
+        d.v[e + (from ? 6 : 7) * Lp] = q[3];
+    }
+    if (i != 0) return;
+    if (need_pending && !ctrl->pending) return;   // first iteration of a loop: no residual sums travel yet
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int p = 0; p < d.nranks; p++) {
+        const double* q = (p == d.rank) ? d.halo_local : d.halo_recv + d.halo_off[d.nranks + p];
+#pragma unroll
+        for (int j = 0; j < 4; j++) s[j] += q[j];
+    }
+    if (out != nullptr) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) out[j] = s[j];
+    }
+    if (ctrl != nullptr) ctrl_advance(ctrl, s);
+}
+
+// sums-only exchange (end of an inner loop, ||z|| of the outer loop): this rank's four sums into every peer's message
+__global__ void k_halo_pack_sums(Dev d, const double* sums4, const Ctrl* ctrl)
+{
+    if (loop_done(ctrl)) return;
+    const int j = threadIdx.x;
+    if (j >= 4) return;
+    d.halo_local[j] = sums4[j];
+    for (int p = 0; p < d.nranks; p++)
+        if (p != d.rank) d.halo_send[d.halo_off[p] + j] = sums4[j];
+}
+
 // ---------------------------------------------------------------- elementwise, step-wise
 __global__ void k_copy_z(Dev d)  // copy_data_kernel (utilities_gpu.jl:1-8)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.N; i += gridDim.x * blockDim.x) d.zp[i] = d.z[i];
 }
 
+// Element i of the SoA buffers counts in this partition's share of the norms: everything except the replicas of a
+// peer's cut branches (stored after the Lown owned ones in every branch plane; single GPU: Lown = L).  The updates
+// themselves run on every element -- replicas are kept bit-identical on both owners.
+__device__ __forceinline__ bool elem_counts(const Dev& d, int i)
+{
+    return d.Lown >= d.L || i < 2 * d.Gp || (i - 2 * d.Gp) % d.Lp < d.Lown;
+}
+
 __global__ void k_update_z(Dev d, double beta)  // update_zv_kernel (acopf_admm_update_z_gpu.jl:1-11)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.N; i += gridDim.x * blockDim.x) {
-        if (d.owned && !d.owned[i]) continue;
         d.z[i] = (-(d.lz[i] + d.l[i] + d.rho[i] * (d.u[i] - d.v[i]))) / (beta + d.rho[i]);
     }
 }
@@ -955,7 +871,6 @@ __global__ void k_update_z(Dev d, double beta)  // update_zv_kernel (acopf_admm_
 __global__ void k_update_l(Dev d, double beta)  // update_l_kernel (acopf_admm_update_l_gpu.jl:1-14)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.N; i += gridDim.x * blockDim.x) {
-        if (d.owned && !d.owned[i]) continue;
         d.l[i] = -(d.lz[i] + beta * d.z[i]);
     }
 }
@@ -963,7 +878,6 @@ __global__ void k_update_l(Dev d, double beta)  // update_l_kernel (acopf_admm_u
 __global__ void k_update_lz(Dev d, double beta, double maxmult)  // update_lz_kernel (acopf_admm_update_lz_gpu.jl:1-9)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.N; i += gridDim.x * blockDim.x) {
-        if (d.owned && !d.owned[i]) continue;
         d.lz[i] = fmax(-maxmult, fmin(maxmult, d.lz[i] + (beta * d.z[i])));
     }
 }
@@ -1000,7 +914,6 @@ __global__ void __launch_bounds__(EW_BLOCK) k_residual(Dev d)
 {
     double s[4] = {0.0, 0.0, 0.0, 0.0};
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.N; i += gridDim.x * blockDim.x) {
-        if (d.owned && !d.owned[i]) continue;
         const double z = d.z[i];
         const double rp = d.u[i] - d.v[i] + z;
         const double rd = z - d.zp[i];
@@ -1008,6 +921,7 @@ __global__ void __launch_bounds__(EW_BLOCK) k_residual(Dev d)
         d.rp[i] = rp;
         d.rd[i] = rd;
         d.ax[i] = ax;
+        if (!elem_counts(d, i)) continue;
         s[0] += rp * rp;
         s[1] += rd * rd;
         s[2] += z * z;
@@ -1024,7 +938,7 @@ __global__ void __launch_bounds__(EW_BLOCK) k_sumsq_z(Dev d)
 {
     double s[4] = {0.0, 0.0, 0.0, 0.0};
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.N; i += gridDim.x * blockDim.x) {
-        if (d.owned && !d.owned[i]) continue;
+        if (!elem_counts(d, i)) continue;
         const double z = d.z[i];
         s[2] += z * z;
     }
@@ -1046,7 +960,6 @@ __global__ void __launch_bounds__(EW_BLOCK) k_fused_zl(Dev d, double beta_arg, c
     const double beta = ctrl ? ctrl->beta : beta_arg;
     double s[4] = {0.0, 0.0, 0.0, 0.0};
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.N; i += gridDim.x * blockDim.x) {
-        if (d.owned && !d.owned[i]) continue;
         const double u = d.u[i], v = d.v[i], rho = d.rho[i], lz = d.lz[i];
         const double zold = d.z[i];
         const double z = (-(lz + d.l[i] + rho * (u - v))) / (beta + rho);
@@ -1056,6 +969,7 @@ __global__ void __launch_bounds__(EW_BLOCK) k_fused_zl(Dev d, double beta_arg, c
         d.zp[i] = zold;
         d.z[i] = z;
         d.l[i] = -(lz + beta * z);
+        if (!elem_counts(d, i)) continue;
         s[0] += rp * rp;
         s[1] += rd * rd;
         s[2] += z * z;
@@ -1070,11 +984,13 @@ __global__ void __launch_bounds__(EW_BLOCK) k_fused_zl(Dev d, double beta_arg, c
 
 // Sum the per-block partials in a fixed order; optionally advance the loop control:
 // inner++, res = sqrt(sums), done = (primres <= eps_pri) || inner == max_inner
-// (admm_two_level.jl:45,60-62 evaluated on the device).
-__global__ void __launch_bounds__(EW_BLOCK) k_final_reduce(const double* partials, int nblk, double* out_sums, Ctrl* ctrl, int need_pending)
+// (admm_two_level.jl:45,60-62 evaluated on the device).  advance = 0: the sums only (a partition with peers adds the
+// other ranks' sums before anything is decided: k_halo_pack_sums / k_halo_unpack).
+__global__ void __launch_bounds__(EW_BLOCK) k_final_reduce(const double* partials, int nblk, double* out_sums, Ctrl* ctrl, int need_pending,
+                                                           int advance)
 {
     if (ctrl != nullptr && ctrl->done) return;
-    if (need_pending && !ctrl->pending) return;   // speculative loop: the branch launch already reduced this iteration
+    if (need_pending && !ctrl->pending) return;   // speculative loop: the bus launch already reduced this iteration
     double s[4] = {0.0, 0.0, 0.0, 0.0};
     for (int b = threadIdx.x; b < nblk; b += EW_BLOCK) {
 #pragma unroll
@@ -1084,18 +1000,7 @@ __global__ void __launch_bounds__(EW_BLOCK) k_final_reduce(const double* partial
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int j = 0; j < 4; j++) out_sums[j] = s[j];
-        if (ctrl != nullptr) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                ctrl->sums[j] = s[j];
-                ctrl->res[j] = sqrt(s[j]);
-            }
-            const int inner = ctrl->inner + 1;
-            ctrl->inner = inner;
-            ctrl->pending = 0;
-            const bool test = (ctrl->check_every <= 1) || (inner % ctrl->check_every == 0);
-            if ((test && ctrl->res[0] <= ctrl->eps_pri) || inner >= ctrl->max_inner) ctrl->done = 1;
-        }
+        if (ctrl != nullptr && advance) ctrl_advance(ctrl, s);
     }
 }
 
@@ -1220,18 +1125,12 @@ __global__ void __launch_bounds__(EW_BLOCK) k_final_reduce_mp(const double* part
     }
 }
 
-// distributed loop: consume all-reduced sums (admm_two_level.jl:45,60-62 on the device)
+// Python-driven distributed loop: consume all-reduced sums (admm_two_level.jl:45,60-62 on the device)
 __global__ void k_ctrl_step(const double* sums, Ctrl* ctrl)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0 || ctrl->done) return;
-    for (int j = 0; j < 4; j++) {
-        ctrl->sums[j] = sums[j];
-        ctrl->res[j] = sqrt(sums[j]);
-    }
-    const int inner = ctrl->inner + 1;
-    ctrl->inner = inner;
-    const bool test = (ctrl->check_every <= 1) || (inner % ctrl->check_every == 0);
-    if ((test && ctrl->res[0] <= ctrl->eps_pri) || inner >= ctrl->max_inner) ctrl->done = 1;
+    const double s[4] = {sums[0], sums[1], sums[2], sums[3]};
+    ctrl_advance(ctrl, s);
 }
 
 // rp, rd, Ax_plus_By from u, v, z, z_prev (only needed when a caller downloads them after a fused loop)

@@ -257,8 +257,7 @@ extern "C" int exaadmm_case_grid(const exaadmm_case* c, exaadmm_grid* g)
     g->FrStart = c->FrStart.data(); g->FrIdx = c->FrIdx.data();
     g->ToStart = c->ToStart.data(); g->ToIdx = c->ToIdx.data();
     g->GenStart = c->GenStart.data(); g->GenIdx = c->GenIdx.data();
-    g->nline_active = 0;
-    g->nbus_active = 0;
+    g->nline_owned = 0;
     return EXAADMM_OK;
 }
 

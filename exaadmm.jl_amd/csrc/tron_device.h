@@ -10,8 +10,8 @@
 //    11 work vectors in shared memory, with 26-31 of 32 lanes idle.  Here one LANE
 //    owns one branch and every loop has a compile-time trip count N, so after
 //    unrolling all vectors, both packed-symmetric matrices and the 32 read-only
-//    problem constants live in registers (512 per lane on gfx950); the default build
-//    uses no LDS (SymRef / BranchDataRef are the LDS-staged A/B variants).
+//    problem constants live in registers (512 per lane on gfx950); no LDS.  (LDS-staged
+//    matrices / constants were measured 3-15 % slower: profiles/r02_two_waves_per_simd_experiments.txt.)
 //  * The face loop of the subspace CG does not compact the free variables into
 //    a smaller system (that needs run-time indexing -> scratch memory).  It keeps
 //    a free-variable MASK and works on the N x N system whose bound rows/columns
@@ -36,11 +36,7 @@
 #if defined(__HIPCC__)
 #define EXA_HD __host__ __device__ __forceinline__
 #define EXA_UNROLL _Pragma("unroll")
-#if defined(EXA_NOINLINE_BIG)
-#define EXA_BIG __host__ __device__ __attribute__((noinline))
-#else
 #define EXA_BIG EXA_HD
-#endif
 #else
 #define EXA_HD inline
 #define EXA_BIG inline
@@ -70,9 +66,7 @@ namespace exa {
 enum { TRON_RUN = 0, TRON_CONV = 4, TRON_WARN = 10, TRON_MAXMINOR = 20, TRON_MAXFEVAL = 21 };
 
 // Packed lower triangle of a symmetric N x N matrix, (i,j) with i >= j at i(i+1)/2 + j.
-// SymMat owns its storage (registers / local memory); SymRef<N,STRIDE> views storage with an
-// element stride -- the GPU kernel points it into LDS laid out [entry][lane] (STRIDE = 64),
-// so lane-local matrices cost no VGPRs and every LDS access of a wave is conflict-free.
+// SymMat owns its storage (registers after unrolling).
 // Host-only loop counters for tests/tools/count_solver_loops.py (how many trips do the searches of a model step make?).
 #if defined(EXA_HOST_COUNTERS) && !defined(__HIP_DEVICE_COMPILE__)
 extern "C" long long exa_cnt[16];
@@ -89,13 +83,6 @@ struct SymMat {
     EXA_HD double get(int i, int j) const { return i >= j ? a[i * (i + 1) / 2 + j] : a[j * (j + 1) / 2 + i]; }
     EXA_HD double& lo(int i, int j) { return a[i * (i + 1) / 2 + j]; }  // requires i >= j
     EXA_HD double lo(int i, int j) const { return a[i * (i + 1) / 2 + j]; }
-};
-
-template <int N, int STRIDE>
-struct SymRef {
-    double* a;
-    EXA_HD double get(int i, int j) const { return i >= j ? a[(i * (i + 1) / 2 + j) * STRIDE] : a[(j * (j + 1) / 2 + i) * STRIDE]; }
-    EXA_HD double& lo(int i, int j) const { return a[(i * (i + 1) / 2 + j) * STRIDE]; }
 };
 
 template <int N>
@@ -181,6 +168,22 @@ EXA_HD void gpstep(const double (&x)[N], const double (&xl)[N], const double (&x
     }
 }
 
+// The same step with the distances to the bounds dl = xl - x, du = xu - x computed by the caller: the searches project
+// from ONE point along ONE direction for several alpha, and with both arms of the selection ready-made the compiler emits
+// selects where the form above gets two nested divergent branches per component (same values, same bits).
+template <int N>
+EXA_HD void gpstep_d(const double (&x)[N], const double (&xl)[N], const double (&xu)[N], const double (&dl)[N],
+                     const double (&du)[N], double alpha, const double (&w)[N], double (&s)[N])
+{
+    EXA_UNROLL
+    for (int i = 0; i < N; i++) {
+        const double aw = alpha * w[i];
+        const double t = x[i] + aw;
+        const double hi = (t > xu[i]) ? du[i] : aw;
+        s[i] = (t < xl[i]) ? dl[i] : hi;
+    }
+}
+
 // q(s) = 1/2 s'As + g's and g's; wa receives A s
 template <int N, class MA>
 EXA_HD void quad_model(const MA& A, const double (&g)[N], const double (&s)[N], double& q, double& gts, double (&wa)[N])
@@ -205,7 +208,13 @@ EXA_BIG void cauchy(const double (&x)[N], const double (&xl)[N], const double (&
     bool interp;
     as_valid = false;
     EXA_CNT(CNT_CAUCHY);
-    gpstep<N>(x, xl, xu, -alpha, g, s);
+    double dl[N], du[N];
+    EXA_UNROLL
+    for (int i = 0; i < N; i++) {
+        dl[i] = xl[i] - x[i];
+        du[i] = xu[i] - x[i];
+    }
+    gpstep_d<N>(x, xl, xu, dl, du, -alpha, g, s);
     if (nrm2<N>(s) > delta) {
         interp = true;
         EXA_CNT(CNT_CAUCHY_FIRST_OUT);
@@ -234,7 +243,7 @@ EXA_BIG void cauchy(const double (&x)[N], const double (&xl)[N], const double (&
     // 400 trips take any finite alpha to 0 / past every break point (guard against NaN spins)
     for (int guard = 0; search && (interp || alpha <= brptmax) && guard < 400; guard++) {
         alpha = (interp ? interpf : extrapf) * alpha;
-        gpstep<N>(x, xl, xu, -alpha, g, s);
+        gpstep_d<N>(x, xl, xu, dl, du, -alpha, g, s);
         const bool inside = (nrm2<N>(s) <= delta);
         double q = 0.0, gts = 0.0;
         if (inside) quad_model<N>(A, g, s, q, gts, as);
@@ -250,7 +259,7 @@ EXA_BIG void cauchy(const double (&x)[N], const double (&xl)[N], const double (&
     }
     if (!interp) {
         alpha = alphas;
-        gpstep<N>(x, xl, xu, -alpha, g, s);
+        gpstep_d<N>(x, xl, xu, dl, du, -alpha, g, s);
         as_valid = false;
     }
 }
@@ -564,11 +573,17 @@ EXA_BIG void prsrch_masked(unsigned fr, double (&x)[N], const double (&xl)[N], c
     breakpt<N>(x, xl, xu, w, brptmin, brptmax);
     EXA_CNT(CNT_PRSRCH);
 
+    double dl[N], du[N];
+    EXA_UNROLL
+    for (int i = 0; i < N; i++) {
+        dl[i] = xl[i] - x[i];
+        du[i] = xu[i] - x[i];
+    }
     bool search = true;
     bool wa1_current = false;   // wa1 = P[x + alpha w] - x for the CURRENT alpha (the accepted trial's step need not be projected twice)
     for (int guard = 0; search && alpha > brptmin && guard < 1100; guard++) {
         EXA_CNT(CNT_PRSRCH_TRIP);
-        gpstep<N>(x, xl, xu, alpha, w, wa1);
+        gpstep_d<N>(x, xl, xu, dl, du, alpha, w, wa1);
         symv<N>(A, wa1, wa2);
         mask_vec<N>(fr, wa2);
         double gts = dot<N>(gf, wa1);
@@ -585,7 +600,7 @@ EXA_BIG void prsrch_masked(unsigned fr, double (&x)[N], const double (&xl)[N], c
         wa1_current = false;
     }
 
-    if (!wa1_current) gpstep<N>(x, xl, xu, alpha, w, wa1);
+    if (!wa1_current) gpstep_d<N>(x, xl, xu, dl, du, alpha, w, wa1);
     EXA_UNROLL
     for (int i = 0; i < N; i++) {
         double xi = x[i] + alpha * w[i];

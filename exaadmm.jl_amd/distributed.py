@@ -5,19 +5,18 @@ called for padding: /root/reference/src/models/acopf/acopf_model.jl:49-53; the i
 per-rank branch offset `shift_lines` is vestigial: src/utils/environment.jl:23,58).
 This module is new work, designed for 8 MI355X on one node (xGMI, point-to-point links):
 
-  * buses are split into P contiguous ranges (the loader's bus order; a BFS reordering is
-    applied first when `reorder=True`); a generator lives with its bus; a branch lives with
-    the owner of its FROM bus ("native" there) and, when its TO bus belongs to another rank,
-    appears on that rank as a "ghost" (stored after the natives);
-  * per inner iteration: x-update (local) -> halo A: owner sends u,z,l of the 4 to-side entries
-    of every cut branch (12 doubles) to the to-bus owner -> bus update -> halo B: the 4 new v
-    entries travel back -> fused z/l/residual on owned elements -> ONE all-reduce of 4 partial
-    sums of squares -> loop control on the device (exaadmm_ctrl_step), so there is no host
-    round trip per iteration;
-  * collectives: torch.distributed (backend "nccl" == RCCL on ROCm; "gloo" in the CPU tests).
-    The halo is an all_to_all_single with per-peer split sizes (direct pairwise transfers, which
-    is what point-to-point xGMI wants; messages are ~KB, latency-bound), the residual an
-    all_reduce(SUM) of 32 bytes.
+  * buses are split into P contiguous ranges of a breadth-first bus order; a generator lives with its
+    bus; a branch lives with the owner of its FROM bus ("native" there: it counts in that rank's share of
+    the residual norms) and, when its TO bus belongs to another rank, is REPLICATED on that rank (a "ghost",
+    stored after the natives);
+  * both owners of a cut branch solve it and update its z, l, lz -- same inputs, same code, bit-identical
+    results -- so u, z, l never travel.  Per inner iteration there is ONE exchange: after the bus update each
+    side sends the 4 new v entries of its own end of every cut branch, together with its 4 partial
+    residual sums; the sums are added in rank order on every rank (identical break decisions without an
+    all-reduce);
+  * in-library loop (default): csrc/dist_native.h issues that exchange to RCCL from C++ as one grouped
+    ncclSend / ncclRecv per peer and keeps the fused loop's two launches per iteration; the step-wise
+    loop below (torch.distributed collectives; gloo in the CPU tests) is the debugging twin.
 
 The orchestration (DistributedAcopf) talks to a backend object; `HipBackend` drives the C ABI of
 libexaadmm_hip.so.  The CPU/gloo tests plug a test-only backend into the same orchestration.
@@ -31,7 +30,8 @@ import time
 
 import numpy as np
 
-TO_SIDE = (2, 3, 5, 7)   # pji, qji, wj, thetaj of a branch
+FROM_SIDE = (0, 1, 4, 6)  # pij, qij, wi, thetai of a branch: produced by the bus update of its from-bus
+TO_SIDE = (2, 3, 5, 7)    # pji, qji, wj, thetaj: produced by the bus update of its to-bus
 U, V, L_, RHO, Z, LZ = 0, 1, 2, 3, 6, 8   # exaadmm_vector ids
 
 
@@ -120,15 +120,17 @@ class Partition:
         br_l[self.branches] = np.arange(Ll)
         self.br_local = br_l
 
-        # halo plans, per peer, ordered by global branch id
+        # cut branches per peer, ordered by global branch id: both sides build the same list
         cut_out = self.native[to_own[self.native] != rank]          # natives whose to-bus is remote
-        self.send_uzl = {p: cut_out[to_own[cut_out] == p] for p in range(world)}
-        self.recv_uzl = {p: self.ghost[fr_own[self.ghost] == p] for p in range(world)}
+        self.cut = {}
+        for p in range(world):
+            mine = np.concatenate([cut_out[to_own[cut_out] == p], self.ghost[fr_own[self.ghost] == p]])
+            self.cut[p] = np.sort(mine)
         self.n_cut = len(cut_out)
 
         # local grid
         g = {"ngen": Gl, "nline": Ll, "nbus": Bl, "baseMVA": float(grid["baseMVA"]),
-             "nline_active": self.n_native, "nbus_active": Bl}
+             "nline_owned": self.n_native}
         for k in ("pgmin", "pgmax", "qgmin", "qgmax", "c2", "c1", "c0"):
             g[k] = np.ascontiguousarray(np.asarray(grid[k])[self.gens])
         for k in ("YffR", "YffI", "YftR", "YftI", "YttR", "YttI", "YtfR", "YtfI", "rateA"):
@@ -162,34 +164,28 @@ class Partition:
         self.nvar_owned = 2 * Gl + 8 * self.n_native
         self.G_global = G
 
-        # halo index lists (vector id, local reference-layout index)
+        # the one exchange of an iteration, per peer and cut branch: the 4 v entries of the LOCAL end go out,
+        # the 4 of the REMOTE end come in (step-wise twin of dist_native.h: exaadmm_set_halo_index slots 0 / 1)
         ls = 2 * Gl
+        fs, ts = np.asarray(FROM_SIDE, dtype=np.int64), np.asarray(TO_SIDE, dtype=np.int64)
 
-        to_side = np.asarray(TO_SIDE, dtype=np.int64)
-
-        def entries(branches, vecs):
-            loc = br_l[np.asarray(branches, dtype=np.int64)]
-            one = (ls + 8 * loc[:, None] + to_side[None, :]).ravel()           # per branch: its 4 to-side entries
-            idx = np.tile(one, len(vecs))                                        # vector-major, like the round-1 lists
-            which = np.repeat(np.asarray(vecs, dtype=np.int32), one.size)
-            return which, idx
-
-        def plan(peer_lists, vecs):
-            which, idx, counts = [], [], []
+        def plan(local_end):
+            idx, counts = [], []
             for p in range(world):
-                w, i = entries(peer_lists[p], vecs)
-                which.append(w)
+                b = self.cut[p]
+                loc = br_l[b]
+                native = fr_own[b] == rank
+                side = np.where((native == local_end)[:, None], fs[None, :], ts[None, :])
+                i = (ls + 8 * loc[:, None] + side).ravel()
                 idx.append(i)
                 counts.append(int(i.size))
-            return (np.concatenate(which).astype(np.int32), np.concatenate(idx).astype(np.int64), counts)
+            idx = np.concatenate(idx).astype(np.int64)
+            return (np.full(idx.size, V, dtype=np.int32), idx, counts)
 
-        self.plan_send_uzl = plan(self.send_uzl, (U, Z, L_))   # slot 0: gather on the owner
-        self.plan_recv_uzl = plan(self.recv_uzl, (U, Z, L_))   # slot 1: scatter into the ghosts
-        self.plan_send_v = plan(self.recv_uzl, (V,))           # slot 2: gather v of the ghosts
-        self.plan_recv_v = plan(self.send_uzl, (V,))           # slot 3: scatter into the natives
-        mask = np.zeros(self.nvar_local, dtype=np.uint8)
-        mask[:self.nvar_owned] = 1
-        self.owned_mask = mask
+        self.plan_send_v = plan(True)     # slot 0: gather the local ends' v entries
+        self.plan_recv_v = plan(False)    # slot 1: scatter the peers' into the remote ends
+        self.cut_local = np.concatenate([br_l[self.cut[p]] for p in range(world)]).astype(np.int64)
+        self.cut_counts = np.asarray([len(self.cut[p]) for p in range(world)], dtype=np.int64)
 
     # ---- global <-> local vectors (reference layout)
     def local_index_map(self):
@@ -224,69 +220,103 @@ class HipBackend:
         self.mod = pkg.ModelAcopf(env)
         self.lib = pkg.library()
         h = self.mod.handle
-        pkg._check(self.lib.exaadmm_set_active(h, part.n_native, part.Bl), "exaadmm_set_active")
-        pkg._check(self.lib.exaadmm_set_owned_mask(h, part.owned_mask.ctypes.data_as(C.POINTER(C.c_uint8)),
-                                                   part.nvar_local), "exaadmm_set_owned_mask")
-        for slot, (which, idx, _) in enumerate((part.plan_send_uzl, part.plan_recv_uzl, part.plan_send_v, part.plan_recv_v)):
+        for slot, (which, idx, _) in enumerate((part.plan_send_v, part.plan_recv_v)):
             pkg._check(self.lib.exaadmm_set_halo_index(h, slot, which.ctypes.data_as(C.POINTER(C.c_int32)),
                                                        idx.ctypes.data_as(pkg.c_i64_p), len(idx)), "exaadmm_set_halo_index")
         self.sums = torch.zeros(4, dtype=torch.float64, device=self.dev)
-        stream = torch.cuda.current_stream(self.dev).cuda_stream
-        pkg._check(self.lib.exaadmm_set_stream(h, C.c_void_p(stream)), "exaadmm_set_stream")
-        pkg._check(self.lib.exaadmm_set_async(h, 1), "exaadmm_set_async")
+        self._use_torch_stream()
+
+    def _use_torch_stream(self):
+        """step-wise twin: the library's launches go onto torch's current stream, asynchronously, so that torch's
+        collectives order themselves against them"""
+        h = self.mod.handle
+        stream = self.torch.cuda.current_stream(self.dev).cuda_stream
+        self.pkg._check(self.lib.exaadmm_set_stream(h, C.c_void_p(stream)), "exaadmm_set_stream")
+        self.pkg._check(self.lib.exaadmm_set_async(h, 1), "exaadmm_set_async")
 
     # ---- distributed loop inside the library (csrc/dist_native.h): RCCL called from C++ on the handle's own stream
     native = False
 
     def attach_native(self, dist):
-        """Collective over the ranks of `dist` (torch.distributed, used only to hand the 128-byte RCCL id around):
-        creates the library-side communicator and halo buffers.  From here on run_inner / run_fixed / norm_z run
-        inside the library, eight iterations per host visit."""
+        """Collective over the ranks of `dist` (torch.distributed, used only to hand the 128-byte RCCL id around and
+        to agree on failures): creates the library-side communicator and message buffers.  From here on run_inner /
+        run_fixed / norm_z run inside the library.  Returns False -- on EVERY rank, with the handle back on torch's
+        stream -- when any rank could not attach; the step-wise loop then serves as the fallback."""
         pkg, lib, h, p = self.pkg, self.lib, self.mod.handle, self.part
         world, rank = dist.get_world_size(), dist.get_rank()
-        ident = [None]
-        if world == 1 and os.environ.get("EXAADMM_DIST_ONE_RANK_COMM"):   # tests: a real one-rank communicator
-            buf = C.create_string_buffer(128)
-            pkg._check(lib.exaadmm_dist_unique_id(buf, 128), "exaadmm_dist_unique_id")
-            ident[0] = buf.raw
-        if world > 1:
+
+        def all_ok(ok):
+            if world == 1:
+                return bool(ok)
+            t = self.torch.tensor([1 if ok else 0], dtype=self.torch.int32, device=self.dev if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(int(t.cpu()[0]))
+
+        def fail(where, err):
+            if err is not None:
+                sys.stderr.write("exaadmm: rank %d: %s failed (%s)\n" % (rank, where, err))
+            try:
+                lib.exaadmm_dist_detach(h)
+            except Exception:
+                pass
+            self._use_torch_stream()
+            self.native = False
+            return False
+
+        self.torch.cuda.synchronize(self.dev)
+        pkg._check(lib.exaadmm_set_stream(h, C.c_void_p(pkg.OWN_STREAM)), "exaadmm_set_stream")
+        pkg._check(lib.exaadmm_set_async(h, 0), "exaadmm_set_async")
+        # phase 1, local: bind RCCL, check the cut lists against the grid, allocate the message buffers
+        err = None
+        try:
+            pkg._check(lib.exaadmm_dist_prepare(h, world, rank, p.nvar_global, p.cut_counts.ctypes.data_as(pkg.c_i64_p),
+                                                p.cut_local.ctypes.data_as(pkg.c_i64_p)), "exaadmm_dist_prepare")
+        except pkg.ExaAdmmError as e:
+            err = e
+        if not all_ok(err is None):
+            return fail("exaadmm_dist_prepare", err)
+        one_rank_comm = world == 1 and os.environ.get("EXAADMM_DIST_ONE_RANK_COMM")   # tests: a real one-rank communicator
+        if world > 1 or one_rank_comm:
+            # phase 2: the id (rank 0), agreed on before anybody enters ncclCommInitRank
+            ident = [None]
             if rank == 0:
                 buf = C.create_string_buffer(128)
                 try:
                     pkg._check(lib.exaadmm_dist_unique_id(buf, 128), "exaadmm_dist_unique_id")
                     ident[0] = buf.raw
-                except pkg.ExaAdmmError as e:      # no usable RCCL next to the HIP runtime: every rank falls back together
-                    sys.stderr.write("exaadmm: library-side RCCL unavailable (%s); using the Python-driven loop\n" % e)
-            dist.broadcast_object_list(ident, src=0)
+                except pkg.ExaAdmmError as e:
+                    err = e
+            if world > 1:
+                dist.broadcast_object_list(ident, src=0)
             if ident[0] is None:
-                return False
-        counts = np.asarray([p.plan_send_uzl[2], p.plan_recv_uzl[2], p.plan_send_v[2], p.plan_recv_v[2]], dtype=np.int64)
-        assert counts.shape == (4, world)
-        self.torch.cuda.synchronize(self.dev)
-        pkg._check(lib.exaadmm_set_stream(h, C.c_void_p(pkg.OWN_STREAM)), "exaadmm_set_stream")
-        pkg._check(lib.exaadmm_set_async(h, 0), "exaadmm_set_async")
-        pkg._check(lib.exaadmm_dist_attach(h, world, rank, ident[0], 128 if ident[0] else 0, p.nvar_global,
-                                           counts.ctypes.data_as(pkg.c_i64_p)), "exaadmm_dist_attach")
+                return fail("exaadmm_dist_unique_id", err)
+            # phase 3, collective: every rank is known to be ready
+            try:
+                pkg._check(lib.exaadmm_dist_connect(h, ident[0], 128), "exaadmm_dist_connect")
+            except pkg.ExaAdmmError as e:
+                err = e
+            if not all_ok(err is None):
+                return fail("exaadmm_dist_connect", err)
         self.native = True
         return True
 
     def run_inner_native(self, outer, max_inner, beta):
         done = C.c_int()
         res = np.zeros(4)
-        self.pkg._check(self.lib.exaadmm_dist_run_inner(self.mod.handle, int(outer), int(max_inner), float(beta), C.byref(done),
-                                                        self.pkg._dp(res)), "exaadmm_dist_run_inner")
+        self.pkg._check(self.lib.exaadmm_run_inner(self.mod.handle, int(outer), int(max_inner), float(beta), C.byref(done),
+                                                   self.pkg._dp(res)), "exaadmm_run_inner")
         return done.value, res
 
     def run_fixed_native(self, iters, first_major_iter, beta):
         res = np.zeros(4)
         ms = C.c_double()
-        self.pkg._check(self.lib.exaadmm_dist_run_fixed(self.mod.handle, int(iters), int(first_major_iter), float(beta),
-                                                        self.pkg._dp(res), C.byref(ms)), "exaadmm_dist_run_fixed")
+        self.pkg._check(self.lib.exaadmm_run_fixed(self.mod.handle, int(iters), int(first_major_iter), float(beta),
+                                                   self.pkg._dp(res), C.byref(ms), None), "exaadmm_run_fixed")
         return res, ms.value
 
     def norm_z_native(self):
         v = C.c_double()
-        self.pkg._check(self.lib.exaadmm_dist_norm_z(self.mod.handle, C.byref(v)), "exaadmm_dist_norm_z")
+        self.pkg._check(self.lib.exaadmm_norm_z(self.mod.handle, C.byref(v)), "exaadmm_norm_z")
         return v.value
 
     def new_buffer(self, n):
@@ -356,7 +386,7 @@ class DistributedAcopf:
     def __init__(self, part, backend, dist, global_state, params, check_every=1):
         self.part, self.be, self.dist = part, backend, dist
         # check_every = 1: the reference's per-iteration break test (default).  k > 1 is an explicit
-        # opt-in relaxation: the residual all-reduce (and the test) only happen every k-th inner
+        # opt-in relaxation of the step-wise loop: the residual all-reduce (and the test) only happen every k-th inner
         # iteration, the loop may run up to k-1 iterations longer than the reference's.
         self.check_every = max(1, int(check_every))
         backend.set_check_every(self.check_every)
@@ -364,8 +394,6 @@ class DistributedAcopf:
         for name in ("v_curr", "rho"):
             backend.upload(name, part.slice_global(global_state[name]))
         p = part
-        self.buf_send_uzl = backend.new_buffer(sum(p.plan_send_uzl[2]))
-        self.buf_recv_uzl = backend.new_buffer(sum(p.plan_recv_uzl[2]))
         self.buf_send_v = backend.new_buffer(sum(p.plan_send_v[2]))
         self.buf_recv_v = backend.new_buffer(sum(p.plan_recv_v[2]))
         self.info = {"outer": 0, "inner": 0, "cumul": 0, "status": "IterationLimit"}
@@ -399,15 +427,15 @@ class DistributedAcopf:
             self.dist.all_reduce(t)
 
     def inner_iteration(self, major_iter, beta, max_inner=None):
+        """step-wise twin of the in-library iteration: x-update of every local branch (natives and replicas), bus
+        update, ONE exchange (the v entries of the cut branches' local ends), z / l / residual on every local element
+        with the sums taken over the owned ones, all-reduce of the 4 sums"""
         be, p = self.be, self.part
         be.update_x(major_iter)
-        be.pack(0, self.buf_send_uzl)
-        self._exchange(self.buf_send_uzl, self.buf_recv_uzl, p.plan_send_uzl[2], p.plan_recv_uzl[2])
-        be.unpack(1, self.buf_recv_uzl)
         be.update_xbar()
-        be.pack(2, self.buf_send_v)
+        be.pack(0, self.buf_send_v)
         self._exchange(self.buf_send_v, self.buf_recv_v, p.plan_send_v[2], p.plan_recv_v[2])
-        be.unpack(3, self.buf_recv_v)
+        be.unpack(1, self.buf_recv_v)
         sums = be.update_zl_partial(beta)
         if self.check_every == 1 or major_iter % self.check_every == 0 or major_iter == max_inner:
             self._all_reduce(sums)      # otherwise the (untested) local sums are only stored
@@ -485,16 +513,14 @@ DEFAULT_PAR = dict(initial_beta=1e3, inc_c=6.0, theta=0.8, outer_eps=2e-4, outer
 
 
 # --------------------------------------------------------------------------- bench (N > 1)
-SHARDED_CASES = ("case_ACTIVSg70k", "synthetic1M")     # BASELINE.json configs 4, 5: ONE grid cut N ways (strong scaling)
-
-
 def bench_main(args, rank, world, local_rank):
-    """bench.py --gpus N.
-    default case (case13659pegase): WEAK scaling -- one banded synthetic grid of N areas of the benchmark size
-    (N x ngen, N x nline, N x nbus) cut into N bus ranges, one per GPU; cut branches are the tie lines;
-    value = N x (inner iterations/s of the N-area grid) = area-iterations/s.
-    --case case_ACTIVSg70k / synthetic1M: STRONG scaling -- the one grid of that size sharded N ways
-    (BASELINE.json configs 4 and 5); value = inner iterations/s of that grid.
+    """bench.py --gpus N [--case C] [--scaling weak|strong].
+    weak (default): one banded synthetic grid of N areas of the case's size (N x ngen, N x nline, N x nbus) cut into N bus
+      ranges, one per GPU; the cut branches are the tie lines between areas; value = N x (inner iterations/s of the
+      N-area grid) = area-iterations/s.  `--case case_ACTIVSg70k` gives north_star's target configuration: N areas of
+      70k buses.
+    strong: ONE grid of the case's size sharded N ways (BASELINE.json configs 4 and 5 as written); value = inner
+      iterations/s of that grid.
     The per-iteration sequence runs inside the library (csrc/dist_native.h, RCCL called from C++)."""
     import torch
     import torch.distributed as dist
@@ -513,13 +539,13 @@ def bench_main(args, rank, world, local_rank):
     world = dist.get_world_size()
     params = B.CASE_PARAMS[args.case]
     g0, l0, b0 = syn.CASE_SIZES[args.case]
-    sharded = args.case in SHARDED_CASES
+    sharded = (getattr(args, "scaling", "weak") == "strong")
     gkw = dict(cost="market") if args.case == "case_ACTIVSg70k" else {}
     if sharded:
         grid = syn.synthetic_grid(g0, l0, b0, seed=0, **gkw)
         workload = "synthetic-%s-sized sharded %d ways" % (args.case, world)
     else:
-        grid = syn.synthetic_grid(world * g0, world * l0, world * b0, seed=0)
+        grid = syn.synthetic_grid(world * g0, world * l0, world * b0, seed=0, **gkw)
         workload = "synthetic-%s-sized x %d areas" % (args.case, world)
     part = Partition(grid, world, rank)
     st = init_state(grid, params["rho_pq"], params["rho_va"])
@@ -530,28 +556,27 @@ def bench_main(args, rank, world, local_rank):
     if native:
         native = bool(be.attach_native(dist))
     beta = DEFAULT_PAR["initial_beta"]
+    exch0 = int(be.lib.exaadmm_dist_exchange_count())
 
     def run(n, first):
         if n <= 0:
             return
         if native:
-            be.run_fixed_native(n, first, beta)          # eight-deep batches are not needed here: no break test
+            be.run_fixed_native(n, first, beta)
         else:
-            for i in range(n):                           # round-1 path: Python issues every step and collective
+            for i in range(n):                           # step-wise twin: Python issues every step and collective
                 model_inner_fixed(model, first + i, beta)
 
     def model_inner_fixed(m, major_iter, beta):
         bk, p = m.be, m.part
         bk.update_x(major_iter)
-        bk.pack(0, m.buf_send_uzl)
-        m._exchange(m.buf_send_uzl, m.buf_recv_uzl, p.plan_send_uzl[2], p.plan_recv_uzl[2])
-        bk.unpack(1, m.buf_recv_uzl)
         bk.update_xbar()
-        bk.pack(2, m.buf_send_v)
+        bk.pack(0, m.buf_send_v)
         m._exchange(m.buf_send_v, m.buf_recv_v, p.plan_send_v[2], p.plan_recv_v[2])
-        bk.unpack(3, m.buf_recv_v)
+        bk.unpack(1, m.buf_recv_v)
         sums = bk.update_zl_partial(beta)
-        dist.all_reduce(sums)
+        if world > 1:
+            dist.all_reduce(sums)
 
     prep = max(0, getattr(args, "prep", 0))     # untimed preparation iterations that define the benchmark state
     run(prep, 1)
@@ -559,12 +584,14 @@ def bench_main(args, rank, world, local_rank):
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
+    exch1 = int(be.lib.exaadmm_dist_exchange_count())
     t0 = time.perf_counter()
     run(args.steps, prep + args.warmup + 1)
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+    exch2 = int(be.lib.exaadmm_dist_exchange_count())
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = float(dt.cpu()[0])
     if native:
@@ -589,8 +616,8 @@ def bench_main(args, rank, world, local_rank):
             "metric": "ADMM inner iterations/sec", "value": value, "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "value_is": ("inner iterations/s of the one grid, sharded over the GPUs" if sharded else
-                         "N x (inner iterations/s of the N-area grid): iterations/s per benchmark-sized area, summed over the N areas "
+            "value_definition": ("inner iterations/s of the one grid, sharded over the GPUs" if sharded else
+                         "N x (inner iterations/s of the N-area grid): iterations/s per case-sized area, summed over the N areas "
                          "(equal to plain iterations/s at N = 1); the N-area grid itself iterates at grid_iterations_per_s"),
             "grid_iterations_per_s": its,
             "config": {"workload": workload, "ngen": G, "nline": Ln, "nbus": Bn,
@@ -598,9 +625,11 @@ def bench_main(args, rank, world, local_rank):
                        "cut_branches": int(cuts.cpu()[0]), "cut_fraction": float(cuts.cpu()[0] / max(cuts.cpu()[1], 1.0)),
                        "mode": "fixed-count inner iterations, no early break",
                        "state": "ADMM state after %d untimed preparation iterations from init_solution!" % prep,
-                       "loop": "inside the library, RCCL from C++ (dist_native.h)" if native else "Python-driven steps + torch collectives",
-                       "parallelism": "bus/branch partition x%d (breadth-first bus ranges), per iteration 2 halo exchanges "
-                                      "(grouped ncclSend/ncclRecv) + one 32-byte all-reduce (RCCL)" % world},
+                       "loop": "inside the library, RCCL from C++ (dist_native.h)" if native else "step-wise twin: Python-driven steps + torch collectives",
+                       "exchanges_per_iteration_rank0": (exch2 - exch1) / float(max(args.steps, 1)) if native else None,
+                       "parallelism": "bus/branch partition x%d (breadth-first bus ranges); cut branches solved on both owners; per "
+                                      "iteration ONE grouped ncclSend/ncclRecv per peer (4 v entries per cut branch + 4 residual sums), "
+                                      "sums added in rank order, no all-reduce" % world},
             "roofline": {"bound": "hbm", "achieved": B.BYTES_PER_ITER(G, Ln, Bn) * its / 1e9, "peak": world * B.HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": B.BYTES_PER_ITER(G, Ln, Bn) * its / 1e9 / (world * B.HBM_PEAK_GBS),
                          "traffic": None, "note": "whole-iteration algorithmic bytes of the grid / wall time"},

@@ -57,9 +57,10 @@ typedef struct {
     const int64_t *brBusIdx;                                              /* 2*nline (from,to) */
     const double *Pd, *Qd, *Vmin, *Vmax, *YshR, *YshI;                    /* nbus */
     const int64_t *FrStart, *FrIdx, *ToStart, *ToIdx, *GenStart, *GenIdx; /* CSR bus -> branch/gen */
-    /* partitions only (multi-GPU): the first nline_active branches / nbus_active buses are this
-     * rank's own, the rest are ghost copies; 0 = everything is active (single GPU) */
-    int64_t nline_active, nbus_active;
+    /* partitions only (multi-GPU): the first nline_owned branches are this rank's own (their from-bus is
+     * one of its buses) and count in the residual norms; the rest are replicas of cut branches a peer owns
+     * (to-bus local), solved and updated here as well, bit-identically.  0 = everything is owned (single GPU) */
+    int64_t nline_owned;
 } exaadmm_grid;
 
 /* Mirrors Parameters (src/utils/environment.jl:6-76), fields the path reads. */
@@ -102,6 +103,9 @@ typedef enum {
 const char *exaadmm_version(void);
 const char *exaadmm_last_error(void);
 int exaadmm_device_count(void); /* visible HIP devices (0 = none); starts the library's HIP runtime */
+/* text: path and version of the HIP runtime the library is bound to in this process, and the HIP version it was
+ * compiled against; returns (runtime major - compiled major), 0 = compatible */
+int exaadmm_hip_runtime_info(char *out, int64_t n);
 const char *exaadmm_io_error(void); /* message of the last failed exaadmm_load_matpower */
 void exaadmm_default_params(exaadmm_params *p);
 
@@ -149,10 +153,6 @@ int exaadmm_branch_stats(exaadmm_handle *h, double *avg_auglag_it, double *avg_m
 int exaadmm_download_branch_counters(exaadmm_handle *h, int32_t *auglag_it, int32_t *minor_it, int32_t *ticks, int64_t nline);
 /* resident wavefronts per SIMD that the branch kernel's register / LDS footprint allows (occupancy API) */
 int exaadmm_branch_kernel_occupancy(exaadmm_handle *h, int *waves_per_simd);
-/* lane assignment of the branch kernel: lane i solves branch order[i] (zero-based reference branch
- * ids, a permutation of the active branches; NULL = identity).  Grouping branches with similar
- * solver work into the same wavefront reduces divergence; results do not depend on it. */
-int exaadmm_set_branch_lane_order(exaadmm_handle *h, const int32_t *order, int64_t n);
 
 /* ---- fused: control stays on the device side ---- */
 /* Inner while-loop of admm_two_level (admm_two_level.jl:34-63) for outer iteration `outer`:
@@ -167,7 +167,40 @@ int exaadmm_solve_two_level(exaadmm_handle *h, exaadmm_info *out);
 int exaadmm_run_fixed(exaadmm_handle *h, int iters, int first_major_iter, double beta, double out[4],
                       double *ms_total, double *ms_branch);
 
-/* ---- multi-GPU helpers (one handle = one partition of the grid) ---- */
+/* ---- multi-GPU (one handle = one partition of the grid, one process per GPU) ----
+ * Buses are partitioned; a partition holds the generators and branches of its buses.  A branch whose two buses
+ * belong to different partitions (a cut branch) is held and SOLVED by both: its u, z, l, lz and line-limit
+ * multipliers are bit-identical replicas, and the only thing a partition must be told per iteration is the half
+ * of such a branch's v that the peer's bus update produces (4 doubles per cut branch, each way).
+ * exaadmm_create flags the cut branches itself: a branch listed in only one of FrIdx / ToIdx has its other end on
+ * a peer's bus.
+ *
+ * In-library loop (RCCL over xGMI, bound at run time): once a handle is attached to its peers, the ordinary entry
+ * points exaadmm_run_inner / exaadmm_run_fixed / exaadmm_norm_z / exaadmm_solve_two_level are collective over the
+ * ranks: per inner iteration ONE grouped ncclSend / ncclRecv per peer (the cut branches' new v entries + this
+ * rank's four partial residual sums), the sums are added in rank order on every rank (identical decisions, no
+ * all-reduce), tolerances use nvar_global.  exaadmm_objective / info.objval stay this partition's share.
+ *   exaadmm_dist_unique_id  on ONE rank; the 128 bytes reach the others by the caller's means (torch.distributed, MPI)
+ *   exaadmm_dist_prepare    local: binds RCCL, checks the cut lists, allocates the message buffers.  ncut_per_peer
+ *                           [nranks]; cut_branch: for every peer in rank order the zero-based local ids of the
+ *                           branches shared with it, in the order both sides agree on (ascending global branch id)
+ *   exaadmm_dist_connect    collective: ncclCommInitRank.  Callers agree on the outcome of prepare across the ranks
+ *                           first (a rank that failed alone would leave the others waiting here forever)
+ *   exaadmm_dist_attach     prepare + connect in one call (nranks = 1: no id needed, nothing is exchanged) */
+int exaadmm_dist_unique_id(void *out128, int64_t nbytes);
+int exaadmm_dist_prepare(exaadmm_handle *h, int nranks, int rank, int64_t nvar_global, const int64_t *ncut_per_peer,
+                         const int64_t *cut_branch);
+int exaadmm_dist_connect(exaadmm_handle *h, const void *unique_id, int64_t id_bytes);
+int exaadmm_dist_attach(exaadmm_handle *h, int nranks, int rank, const void *unique_id, int64_t id_bytes,
+                        int64_t nvar_global, const int64_t *ncut_per_peer, const int64_t *cut_branch);
+int exaadmm_dist_detach(exaadmm_handle *h);
+/* the sums exchange + a ring send / receive of n doubles on the handle's stream; max_err = deviation from the
+ * expected values.  Checks that RCCL and the library share one HIP runtime. */
+int exaadmm_dist_selftest(exaadmm_handle *h, int64_t n, double *max_err);
+const char *exaadmm_dist_rccl_path(void); /* the RCCL the library bound (next to its own HIP runtime), "" before */
+int64_t exaadmm_dist_exchange_count(void); /* grouped exchanges enqueued by the calling thread so far (tests) */
+
+/* Caller-driven variant (torch.distributed / gloo / debugging): the step-wise entry points plus these helpers. */
 /* run on a caller-provided HIP stream (e.g. torch's current stream).  NULL is the device's
  * default (null) stream -- which is what torch.cuda.current_stream().cuda_stream returns unless a
  * side stream is active; EXAADMM_OWN_STREAM switches back to the handle's private stream. */
@@ -176,26 +209,19 @@ int exaadmm_set_stream(exaadmm_handle *h, void *hip_stream);
 /* async != 0: step-wise entry points only enqueue (no stream synchronisation on return);
  * the caller orders them against its collectives through the stream */
 int exaadmm_set_async(exaadmm_handle *h, int async);
-/* a partition stores its own ("native") branches first and ghost copies of remote branches
- * after them, owned buses first: restrict the branch kernel to the first nbranch branches and
- * the bus kernel to the first nbus buses (defaults: all) */
-int exaadmm_set_active(exaadmm_handle *h, int64_t nbranch, int64_t nbus);
-/* elementwise steps restricted by an ownership mask (1 = this rank owns the element's
- * z / l / lz / residual contribution); NULL restores "owns everything" */
-int exaadmm_set_owned_mask(exaadmm_handle *h, const uint8_t *mask, int64_t nvar);
 /* halo lists: entry i moves element idx[i] (zero-based reference-layout index) of solution
  * vector which[i] (exaadmm_vector).  pack gathers into a contiguous DEVICE buffer, unpack
  * scatters from one; 8 slots per handle */
 int exaadmm_set_halo_index(exaadmm_handle *h, int slot, const int32_t *which, const int64_t *idx, int64_t count);
 int exaadmm_halo_pack(exaadmm_handle *h, int slot, double *dev_buf);
 int exaadmm_halo_unpack(exaadmm_handle *h, int slot, const double *dev_buf);
-/* fused z_prev/z/l update of the owned elements; the 4 partial sums of squares
- * {|rp|^2, |rd|^2, |z|^2, |Ax+By|^2} are written to dev_out4 (DEVICE memory) for an
- * all-reduce by the caller.  exaadmm_sumsq_z_partial: dev_out4[2] = sum z^2 of owned elements. */
+/* fused z_prev/z/l update of every local element; the 4 partial sums of squares
+ * {|rp|^2, |rd|^2, |z|^2, |Ax+By|^2} over the OWNED elements are written to dev_out4 (DEVICE memory) for an
+ * all-reduce by the caller.  exaadmm_sumsq_z_partial: dev_out4[2] = sum z^2 of the owned elements. */
 int exaadmm_update_zl_partial(exaadmm_handle *h, double beta, double *dev_out4);
 int exaadmm_sumsq_z_partial(exaadmm_handle *h, double *dev_out4);
-/* Device-resident loop control for a distributed inner loop (same Ctrl block the fused
- * single-GPU loop uses).  ctrl_begin arms it for outer iteration `outer`; while armed, the
+/* Device-resident loop control for a caller-driven distributed inner loop (same Ctrl block the fused
+ * loop uses).  ctrl_begin arms it for outer iteration `outer`; while armed, the
  * step-wise entry points become no-ops on the device once the loop has converged, the branch
  * kernel takes major_iter = completed iterations + 1, z/l updates take beta from the block.
  * ctrl_step consumes the ALL-REDUCED sums (device pointer): inner++, norms = sqrt(sums),
@@ -204,31 +230,6 @@ int exaadmm_ctrl_begin(exaadmm_handle *h, int outer, int max_inner, double beta,
 int exaadmm_ctrl_step(exaadmm_handle *h, const double *dev_sums4);
 int exaadmm_ctrl_read(exaadmm_handle *h, int *done, int *inner, double res[4]);
 int exaadmm_ctrl_end(exaadmm_handle *h);
-
-/* ---- distributed inner loop inside the library (one process per GPU, RCCL over xGMI) ----
- * The per-iteration sequence  x-update -> halo A (u,z,l of cut branches) -> bus update -> halo B (v back) ->
- * z/l/residual on owned elements -> all-reduce of the 4 partial sums -> device-side loop control  is enqueued from
- * C++ on the handle's own stream, eight iterations per host visit; RCCL (grouped ncclSend/ncclRecv per peer, one
- * 32-byte ncclAllReduce) is bound at run time.  The halo index lists are those of exaadmm_set_halo_index:
- * slot 0 = what this rank sends after the x-update, slot 1 = where the received block is scattered,
- * slot 2 / 3 = the same for the v entries travelling back; within a slot the entries are grouped per peer in rank order.
- * exaadmm_dist_unique_id: called on ONE rank, the 128 bytes go to all ranks by the caller's own means
- * (torch.distributed, MPI, a file).  exaadmm_dist_attach: collective over the ranks.  counts: 4 x nranks int64,
- * [send u/z/l | recv u/z/l | send v | recv v] per peer, in doubles.  nranks = 1 needs no id (NULL). */
-int exaadmm_dist_unique_id(void *out128, int64_t nbytes);
-int exaadmm_dist_attach(exaadmm_handle *h, int nranks, int rank, const void *unique_id, int64_t id_bytes,
-                        int64_t nvar_global, const int64_t *counts);
-int exaadmm_dist_detach(exaadmm_handle *h);
-/* all-reduce + grouped send/receive of n doubles round the ranks on the handle's stream (one rank: to itself);
- * max_err = deviation from the expected values.  Checks that RCCL and the library share one HIP runtime. */
-int exaadmm_dist_selftest(exaadmm_handle *h, int64_t n, double *max_err);
-const char *exaadmm_dist_rccl_path(void); /* the RCCL the library bound (next to its own HIP runtime), "" before */
-/* inner while-loop of admm_two_level.jl:34-63 over all partitions: eps_pri from the GLOBAL nvar, identical
- * break decision on every rank (all ranks see the same all-reduced sums) */
-int exaadmm_dist_run_inner(exaadmm_handle *h, int outer, int max_inner, double beta, int *inner_done, double out[4]);
-/* K iterations without convergence test (benchmark mode); out = norms of the last one; ms_total = device time */
-int exaadmm_dist_run_fixed(exaadmm_handle *h, int iters, int first_major_iter, double beta, double out[4], double *ms_total);
-int exaadmm_dist_norm_z(exaadmm_handle *h, double *out); /* admm_outer_prestep over all partitions */
 
 /* ---- multi-period ACOPF: ModelMpacopf (src/models/mpacopf/mpacopf_model.jl:40-112) ----
  * T periods of the same network with their own loads, coupled through generator ramp constraints

@@ -27,7 +27,7 @@ struct ExaadmmGrid            # == exaadmm_grid
     YshR::Ptr{Float64}; YshI::Ptr{Float64}
     FrStart::Ptr{Int64}; FrIdx::Ptr{Int64}; ToStart::Ptr{Int64}; ToIdx::Ptr{Int64}
     GenStart::Ptr{Int64}; GenIdx::Ptr{Int64}
-    nline_active::Int64; nbus_active::Int64   # 0 = all (single GPU)
+    nline_owned::Int64   # partitions only: branches past it are replicas of a peer's cut branches; 0 = all (single GPU)
 end
 
 mutable struct ExaadmmParams  # == exaadmm_params
@@ -61,7 +61,7 @@ function HipNative(env::AdmmEnv, mod::ModelAcopf; gpu_no::Int=0)
         pointer(d.YtfR), pointer(d.YtfI), pointer(d.FrVmBound), pointer(d.ToVmBound), pointer(d.FrVaBound),
         pointer(d.ToVaBound), pointer(d.rateA), pointer(d.brBusIdx), pointer(d.Pd), pointer(d.Qd), pointer(d.Vmin),
         pointer(d.Vmax), pointer(d.YshR), pointer(d.YshI), pointer(d.FrStart), pointer(d.FrIdx), pointer(d.ToStart),
-        pointer(d.ToIdx), pointer(d.GenStart), pointer(d.GenIdx), 0, 0)
+        pointer(d.ToIdx), pointer(d.GenStart), pointer(d.GenIdx), 0)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     p = to_params(env.params)
     GC.@preserve d begin
@@ -180,7 +180,7 @@ function HipNative(env::AdmmEnv, mod::ModelMpacopf; gpu_no::Int=0)
         pointer(d.YtfR), pointer(d.YtfI), pointer(d.FrVmBound), pointer(d.ToVmBound), pointer(d.FrVaBound),
         pointer(d.ToVaBound), pointer(d.rateA), pointer(d.brBusIdx), pointer(d.Pd), pointer(d.Qd), pointer(d.Vmin),
         pointer(d.Vmax), pointer(d.YshR), pointer(d.YshI), pointer(d.FrStart), pointer(d.FrIdx), pointer(d.ToStart),
-        pointer(d.ToIdx), pointer(d.GenStart), pointer(d.GenIdx), 0, 0)
+        pointer(d.ToIdx), pointer(d.GenStart), pointer(d.GenIdx), 0)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     p = to_params(env.params)
     GC.@preserve d pd qd begin

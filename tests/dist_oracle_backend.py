@@ -1,7 +1,8 @@
 """TEST-ONLY backend for exaadmm.jl_amd/distributed.py: the same interface as HipBackend, computed
 by the CPU oracle on numpy arrays, so the partition / halo / all-reduce orchestration can run
 under torch.distributed's gloo backend without a GPU.  Lives in tests/: the product has no CPU
-path."""
+path.  Same scheme as the HIP path: every local branch (natives and the replicas of the peers' cut
+branches) is solved and updated here; only the owned entries count in the residual sums."""
 import ctypes as C
 import math
 
@@ -18,14 +19,10 @@ class OracleBackend:
         self.part = part
         self.m = O.OracleModel(part.grid, rho_pq, rho_va, scale=scale)
         self.L = O.lib()
-        # view of the local grid restricted to the native branches (they come first)
-        self.cg_native = O.Grid()
-        C.pointer(self.cg_native)[0] = self.m.cg
-        self.cg_native.nline = part.n_native
         self.sums = torch.zeros(4, dtype=torch.float64)
         self.ctrl = None
         self.check_every = 1
-        self.plans = (part.plan_send_uzl, part.plan_recv_uzl, part.plan_send_v, part.plan_recv_v)
+        self.plans = (part.plan_send_v, part.plan_recv_v)
 
     # -- plumbing
     def set_check_every(self, k):
@@ -72,7 +69,7 @@ class OracleBackend:
             major_iter = self.ctrl["inner"] + 1
         m = self.m
         self.L.oracle_generator_update(C.byref(m.cg), C.byref(m.cs))
-        self.L.oracle_branch_update(C.byref(self.cg_native), C.byref(m.par), C.byref(m.cs), int(major_iter), C.byref(m.info))
+        self.L.oracle_branch_update(C.byref(m.cg), C.byref(m.par), C.byref(m.cs), int(major_iter), C.byref(m.info))
 
     def update_xbar(self):
         if self._skip():
@@ -98,7 +95,7 @@ class OracleBackend:
             return self.sums
         if self.ctrl is not None:
             beta = self.ctrl["beta"]
-        m, g = self.m, self.cg_native
+        m, g = self.m, self.m.cg
         self.L.oracle_inner_prestep(C.byref(g), C.byref(m.cs))
         self.L.oracle_update_z(C.byref(g), C.byref(m.cs), beta)
         self.L.oracle_update_l(C.byref(g), C.byref(m.cs), beta)
@@ -116,4 +113,4 @@ class OracleBackend:
         return self.sums
 
     def update_lz(self, beta):
-        self.L.oracle_update_lz(C.byref(self.cg_native), C.byref(self.m.cs), beta, self.m.par.MAX_MULTIPLIER)
+        self.L.oracle_update_lz(C.byref(self.m.cg), C.byref(self.m.cs), beta, self.m.par.MAX_MULTIPLIER)

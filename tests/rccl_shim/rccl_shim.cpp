@@ -1,10 +1,10 @@
-// TEST INFRASTRUCTURE ONLY -- an in-process stand-in for the nine RCCL entry points csrc/dist_native.h binds, so that
+// TEST INFRASTRUCTURE ONLY -- an in-process stand-in for the eight RCCL entry points csrc/dist_native.h binds, so that
 // the library's distributed inner loop can be executed with SEVERAL ranks on a ONE-GPU box: every rank is a host
 // thread of the same process driving its own handle (its own stream) on the same device; "ranks" rendezvous through
 // mutex-protected mailboxes and move data with device-to-device copies.  (Real RCCL refuses two ranks on one device.)
 // Semantics kept: ncclSend / ncclRecv inside a group are matched per (source, destination) pair in posting order, a
-// rank need not take part in a group it has no messages in, ncclAllReduce(sum) returns the same bits on every rank
-// (ranks are added in rank order).  Everything is blocking on the host -- slower than RCCL, same results.
+// rank need not take part in a group it has no messages in.  Everything is blocking on the host -- slower than RCCL,
+// same results.  rccl_shim_counts() reports how many groups / sends / receives were issued.
 // Selected with EXAADMM_RCCL_LIB=<this .so>; built and used by tests/test_gpu_dist_threads.py.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -25,10 +25,6 @@ struct Msg {
 struct World {
     int nranks = 0, attached = 0;
     std::map<std::pair<int, int>, std::deque<Msg*>> box;   // (from, to) -> posted sends
-    // all-reduce rendezvous
-    int ar_arrived = 0, ar_generation = 0;
-    std::vector<std::vector<double>> ar_in;
-    std::vector<double> ar_out;
 };
 struct Comm {
     World* w;
@@ -39,6 +35,7 @@ struct Comm {
 };
 std::mutex g_mu;
 std::condition_variable g_cv;
+long long g_counts[3] = {0, 0, 0};
 std::map<unsigned long long, World*> g_worlds;
 unsigned long long g_next_id = 1;
 
@@ -103,10 +100,7 @@ ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int
     auto it = g_worlds.find(k);
     if (it == g_worlds.end()) return ncclInvalidArgument;
     World* w = it->second;
-    if (w->nranks == 0) {
-        w->nranks = nranks;
-        w->ar_in.assign(nranks, {});
-    }
+    if (w->nranks == 0) w->nranks = nranks;
     if (w->nranks != nranks || rank < 0 || rank >= nranks) return ncclInvalidArgument;
     w->attached++;
     g_cv.notify_all();
@@ -123,7 +117,6 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm)
 ncclResult_t ncclGroupStart() { return ncclSuccess; }   // ops carry their communicator: grouping is per communicator below
 ncclResult_t ncclGroupEnd();
 static thread_local Comm* t_group_comm = nullptr;
-static thread_local int t_group_depth = 0;
 }
 extern "C" ncclResult_t ncclSend(const void* buf, size_t count, ncclDataType_t t, int peer, ncclComm_t comm, hipStream_t s)
 {
@@ -145,35 +138,19 @@ extern "C" ncclResult_t ncclGroupEnd()
 {
     Comm* c = t_group_comm;
     t_group_comm = nullptr;
-    return c ? run_ops(c) : ncclSuccess;
-}
-extern "C" ncclResult_t ncclAllReduce(const void* sendbuf, void* recvbuf, size_t count, ncclDataType_t t, ncclRedOp_t op, ncclComm_t comm,
-                                      hipStream_t s)
-{
-    if (t != ncclDouble || op != ncclSum) return ncclInvalidArgument;
-    Comm* c = reinterpret_cast<Comm*>(comm);
-    World* w = c->w;
-    std::vector<double> mine(count);
-    if (hipStreamSynchronize(s) != hipSuccess) return ncclUnhandledCudaError;
-    if (hipMemcpy(mine.data(), sendbuf, count * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
-    std::vector<double> out;
+    if (!c) return ncclSuccess;
     {
-        std::unique_lock<std::mutex> lk(g_mu);
-        const int gen = w->ar_generation;
-        w->ar_in[c->rank] = mine;
-        if (++w->ar_arrived == w->nranks) {
-            w->ar_out.assign(count, 0.0);
-            for (int r = 0; r < w->nranks; r++)
-                for (size_t i = 0; i < count; i++) w->ar_out[i] += w->ar_in[r][i];
-            w->ar_arrived = 0;
-            w->ar_generation++;
-            g_cv.notify_all();
-        } else {
-            g_cv.wait(lk, [&] { return w->ar_generation != gen; });
-        }
-        out = w->ar_out;
+        std::lock_guard<std::mutex> lk(g_mu);
+        g_counts[0] += 1;
+        for (auto& op : c->ops) g_counts[op.send ? 1 : 2] += 1;
     }
-    if (hipMemcpy(recvbuf, out.data(), count * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
-    return ncclSuccess;
+    return run_ops(c);
+}
+// call counters for the tests: {groups that carried operations, sends, receives}.  (There is no ncclAllReduce here on
+// purpose: the library's loop must not need one.)
+extern "C" void rccl_shim_counts(long long out[3])
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (int i = 0; i < 3; i++) out[i] = g_counts[i];
 }
 extern "C" const char* ncclGetErrorString(ncclResult_t r) { return r == ncclSuccess ? "ok" : "rccl_shim error"; }

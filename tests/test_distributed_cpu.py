@@ -1,6 +1,6 @@
-"""world_size-2 (and 3) gloo tests of the multi-GPU orchestration: partitioning, halo plans,
-all_to_all halo exchange, residual all-reduce and device-style loop control must reproduce the
-single-process solve of the global grid."""
+"""world_size-2 (and 3) gloo tests of the multi-GPU orchestration: partitioning, cut branches replicated and
+solved on both owners, the ONE halo exchange per iteration (v entries of the cut branches' local ends),
+residual all-reduce and device-style loop control must reproduce the single-process solve of the global grid."""
 import json
 import os
 import socket
@@ -108,11 +108,17 @@ def test_partition_invariants():
     assert sorted(np.concatenate([p.gens for p in parts]).tolist()) == list(range(40))
     assert sorted(np.concatenate([p.buses for p in parts]).tolist()) == list(range(400))
     for a in parts:
+        assert len(a.cut[a.rank]) == 0
         for b in parts:
             if a.rank != b.rank:
-                assert np.array_equal(a.send_uzl[b.rank], b.recv_uzl[a.rank])
-                assert a.plan_send_uzl[2][b.rank] == b.plan_recv_uzl[2][a.rank]
-                assert a.plan_recv_v[2][b.rank] == b.plan_send_v[2][a.rank]
+                # both owners of a cut branch list it, in the same (global id) order; 4 doubles per branch each way
+                assert np.array_equal(a.cut[b.rank], b.cut[a.rank])
+                assert a.plan_send_v[2][b.rank] == b.plan_recv_v[2][a.rank] == 4 * len(a.cut[b.rank])
+        # what goes out are the v entries of the LOCAL ends, what comes in those of the REMOTE ends: disjoint, and
+        # together all 8 entries of every cut branch
+        sent, recv = set(a.plan_send_v[1].tolist()), set(a.plan_recv_v[1].tolist())
+        assert not (sent & recv) and len(sent) == len(recv) == 4 * len(a.cut_local)
+        assert sent | recv == set((2 * a.Gl + 8 * a.cut_local[:, None] + np.arange(8)[None, :]).ravel().tolist())
     # owned entries of all ranks tile the global vector exactly once
     cover = np.zeros(2 * 40 + 8 * 600, dtype=int)
     for p in parts:

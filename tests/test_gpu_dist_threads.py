@@ -1,12 +1,13 @@
-"""-m gpu: the distributed inner loop INSIDE the library (csrc/dist_native.h) with 2 and 3 ranks on a one-GPU box.
+"""-m gpu: the distributed inner loop INSIDE the library (csrc/dist_native.h) with 2, 3 and 4 ranks on a one-GPU box.
 
 Real RCCL refuses two ranks on one device, so the ranks are host threads of one process, each driving its own handle
-(= its own partition and stream), and the nine RCCL entry points the library binds at run time are provided by a
+(= its own partition and stream), and the eight RCCL entry points the library binds at run time are provided by a
 test-only in-process stand-in (tests/rccl_shim/rccl_shim.cpp, selected with EXAADMM_RCCL_LIB).  What this executes
-that nothing else can on one GPU: the C++ loop with real peers -- halo gather / grouped send + receive / scatter in
-both directions, the all-reduce of the residual sums, identical break decisions on every rank, eight iterations per
-host visit.  Must reproduce the fused single-GPU solve: same outer / cumulative iteration counts, u / v / z to 1e-10.
-Runs in a subprocess (the RCCL binding is per process)."""
+that nothing else can on one GPU: the C++ loop with real peers -- cut branches solved on both owners, the bus kernel's
+direct writes into the peers' messages, ONE grouped send + receive per iteration (counted by the stand-in, which has no
+ncclAllReduce at all), the unpack kernel's scatter and rank-ordered residual sums, identical break decisions on every
+rank, eight iterations per host visit.  Must reproduce the fused single-GPU solve: same outer / cumulative iteration
+counts, u / v / z / l to 1e-10, and bit for bit in fixed-count mode.  Runs in a subprocess (the RCCL binding is per process)."""
 import json
 import os
 import subprocess
@@ -29,7 +30,11 @@ dm = exaadmm_loader.load_submodule("distributed")
 import ctypes as C
 world = %(world)d
 case = %(case)r
-if case:
+fixed_only = False
+if case == "activsg70k":                  # BASELINE config 4's size (88 207 branches), fixed-count mode only
+    g = syn.sized_like("case_ACTIVSg70k", seed=0)
+    rho, par_over, fixed_only = (3e4, 3e5), {}, True
+elif case:
     g = pkg.opf_loaddata(case)            # the reference's 118-bus anchor case, cut into `world` partitions
     rho, par_over = (4e2, 4e4), dict(outer_iterlim=25, outer_eps=2e-5)
 else:
@@ -42,12 +47,28 @@ buf = C.create_string_buffer(128)
 pkg._check(pkg.library().exaadmm_dist_unique_id(buf, 128), "unique_id")
 assert b"rccl_shim" in pkg.library().exaadmm_dist_rccl_path()
 
+shim = C.CDLL(os.environ["EXAADMM_RCCL_LIB"])
+def shim_counts():
+    c = (C.c_longlong * 3)()
+    shim.rccl_shim_counts(c)
+    return list(c)
+
 class Stub:
+    """torch.distributed for ranks that are threads: what attach_native needs (id broadcast, agreement on failures)"""
+    class ReduceOp: MIN = "min"
+    barrier = threading.Barrier(world)
+    slots = [None] * world
     def __init__(self, rank): self.rank = rank
     def get_world_size(self): return world
     def get_rank(self): return self.rank
-    def get_backend(self): return "nccl"
+    def get_backend(self): return "threads"
     def broadcast_object_list(self, lst, src=0): lst[0] = buf.raw
+    def all_reduce(self, t, op=None):
+        Stub.slots[self.rank] = int(t[0])
+        Stub.barrier.wait()
+        v = min(Stub.slots)
+        Stub.barrier.wait()
+        t[0] = v
 
 bes = [dm.HipBackend(pkg, p, rho[0], rho[1], device_index=0) for p in parts]
 par = dict(dm.DEFAULT_PAR); par.update(par_over)
@@ -62,45 +83,62 @@ def run(r):
         infos[r] = models[r].solve()
     except BaseException as ex:
         errs[r] = repr(ex)
-ths = [threading.Thread(target=run, args=(r,)) for r in range(world)]
-[t.start() for t in ths]; [t.join(180) for t in ths]
-assert not any(t.is_alive() for t in ths), "a rank hung"
-assert not any(errs), errs
-env, mod = pkg.solve_acopf("syn", grid=g, rho_pq=rho[0], rho_va=rho[1], verbose=0, **par_over)
-out = {"cut": int(sum(p.n_cut for p in parts)), "cumul": [i["cumul"] for i in infos], "outer": [i["outer"] for i in infos],
-       "mismatch": [i["mismatch"] for i in infos], "single": [mod.info.outer, mod.info.cumul, mod.info.mismatch], "err": {}}
-for name in ("u_curr", "v_curr", "z_curr", "l_curr"):
-    glob = np.zeros(parts[0].nvar_global)
-    for p, be in zip(parts, bes):
-        glob[p.local_index_map()[:p.nvar_owned]] = be.download(name)[:p.nvar_owned]
-    one = getattr(mod.solution, name)
-    out["err"][name] = float(np.abs(glob - one).max() / max(1.0, np.abs(one).max()))
+out = {"cut": int(sum(p.n_cut for p in parts)), "err": {}}
+if not fixed_only:
+    ths = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in ths]; [t.join(180) for t in ths]
+    assert not any(t.is_alive() for t in ths), "a rank hung"
+    assert not any(errs), errs
+    env, mod = pkg.solve_acopf("syn", grid=g, rho_pq=rho[0], rho_va=rho[1], verbose=0, **par_over)
+    out.update({"cumul": [i["cumul"] for i in infos], "outer": [i["outer"] for i in infos],
+                "mismatch": [i["mismatch"] for i in infos], "single": [mod.info.outer, mod.info.cumul, mod.info.mismatch]})
+    for name in ("u_curr", "v_curr", "z_curr", "l_curr"):
+        glob = np.zeros(parts[0].nvar_global)
+        for p, be in zip(parts, bes):
+            glob[p.local_index_map()[:p.nvar_owned]] = be.download(name)[:p.nvar_owned]
+        one = getattr(mod.solution, name)
+        out["err"][name] = float(np.abs(glob - one).max() / max(1.0, np.abs(one).max()))
 # fixed-count mode (the benchmark path): the partitioned loop must be BITWISE the single-handle loop -- every kernel sees
 # the same inputs in the same order, only the residual sums are added in a different order (and are not fed back)
 bes2 = [dm.HipBackend(pkg, p, rho[0], rho[1], device_index=0) for p in parts]
 for p, be in zip(parts, bes2):
     for name in ("v_curr", "rho"):
         be.upload(name, p.slice_global(st[name]))
+NFIX = 60
 errs = [None] * world
+exch = [None] * world
 def run2(r):
     try:
         assert bes2[r].attach_native(Stub(r))
-        bes2[r].run_fixed_native(60, 1, 1e3)
+        Stub.barrier.wait()
+        if r == 0: out["shim_counts_before"] = shim_counts()
+        Stub.barrier.wait()
+        e0 = pkg.library().exaadmm_dist_exchange_count()
+        bes2[r].run_fixed_native(NFIX, 1, 1e3)
+        exch[r] = pkg.library().exaadmm_dist_exchange_count() - e0
     except BaseException as ex:
         errs[r] = repr(ex)
 ths = [threading.Thread(target=run2, args=(r,)) for r in range(world)]
 [t.start() for t in ths]; [t.join(180) for t in ths]
 assert not any(t.is_alive() for t in ths), "a rank hung"
 assert not any(errs), errs
+out["shim_counts_after"] = shim_counts()
+out["exchanges_in_60_iterations"] = exch
 env3 = pkg.AdmmEnv("single", rho[0], rho[1], verbose=0, grid=g)
 m3 = pkg.ModelAcopf(env3)
-m3.run_fixed(60, first_major_iter=1, beta=1e3)
+m3.run_fixed(NFIX, first_major_iter=1, beta=1e3)
 out["fixed_nonzero_differences"] = {}
+out["replica_differences"] = {}
 for name in ("u_curr", "v_curr", "z_curr", "l_curr"):
     glob = np.zeros(parts[0].nvar_global)
-    for p, be in zip(parts, bes2):
-        glob[p.local_index_map()[:p.nvar_owned]] = be.download(name)[:p.nvar_owned]
+    loc = [be.download(name) for be in bes2]
+    for p, v in zip(parts, loc):
+        glob[p.local_index_map()[:p.nvar_owned]] = v[:p.nvar_owned]
     out["fixed_nonzero_differences"][name] = int(np.count_nonzero(glob - getattr(m3.solution, name)))
+    # the replicas of the cut branches (solved on both owners) are bit-identical copies of the owner's entries
+    out["replica_differences"][name] = int(sum(np.count_nonzero(v[p.nvar_owned:] - glob[p.local_index_map()[p.nvar_owned:]])
+                                               for p, v in zip(parts, loc)))
+out["n_replica_entries"] = int(sum(p.nvar_local - p.nvar_owned for p in parts))
 print("RESULT " + json.dumps(out))
 '''
 
@@ -121,7 +159,7 @@ def _run_worker(world, case):
     return json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4])
 def test_library_distributed_loop_with_several_ranks_on_one_gpu(world):
     out = _run_worker(world, "")
     assert out["cut"] > 0
@@ -129,6 +167,12 @@ def test_library_distributed_loop_with_several_ranks_on_one_gpu(world):
     assert all(abs(m - out["single"][2]) <= 1e-10 * out["single"][2] for m in out["mismatch"]), out
     assert all(e <= 1e-10 for e in out["err"].values()), out
     assert all(n == 0 for n in out["fixed_nonzero_differences"].values()), out
+    assert out["n_replica_entries"] == 8 * out["cut"] and all(n == 0 for n in out["replica_differences"].values()), out
+    # ONE grouped exchange per inner iteration and rank (+ one sums-only exchange that closes the loop), every group one
+    # send and one receive per peer, and no collective besides (the stand-in has no ncclAllReduce to offer)
+    assert out["exchanges_in_60_iterations"] == [61] * world, out
+    groups, sends, recvs = (a - b for a, b in zip(out["shim_counts_after"], out["shim_counts_before"]))
+    assert groups == 61 * world and sends == recvs == 61 * world * (world - 1), out
 
 
 def test_library_distributed_loop_reproduces_the_case118_anchor():
@@ -140,3 +184,32 @@ def test_library_distributed_loop_reproduces_the_case118_anchor():
     assert out["single"][:2] == [20, 1232], out
     assert all(e <= 1e-10 for e in out["err"].values()), out
     assert all(n == 0 for n in out["fixed_nonzero_differences"].values()), out
+
+
+def test_activsg70k_sized_grid_sharded_four_ways_is_bitwise_the_single_handle_loop():
+    """BASELINE config 4's size (88 207 branches, 70 000 buses) cut into 4 partitions: 60 fixed-count iterations of the
+    in-library loop leave u, v, z, l bit for bit where the single-handle loop leaves them, the replicas of the cut branches
+    are bit-identical on both owners, one exchange per iteration."""
+    out = _run_worker(4, "activsg70k")
+    assert out["cut"] > 0
+    assert all(n == 0 for n in out["fixed_nonzero_differences"].values()), out
+    assert out["n_replica_entries"] == 8 * out["cut"] and all(n == 0 for n in out["replica_differences"].values()), out
+    assert out["exchanges_in_60_iterations"] == [61] * 4, out
+
+
+def test_bench_under_the_launcher_one_rank_dist_path():
+    """The driver's multi-GPU command line with one rank: python -m torch.distributed.run --nproc-per-node 1 bench.py
+    --gpus 1 --force-dist ...; the LAST stdout line must be the JSON record (so that the first real 8-GPU run does not
+    die on plumbing)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "5", "--warmup", "2",
+           "--prep", "20", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rec["n_gpus"] == 1 and rec["steps"] == 5 and rec["warmup"] == 2 and rec["value"] > 0
+    assert rec["scaling"] == "weak" and "inside the library" in rec["config"]["loop"]

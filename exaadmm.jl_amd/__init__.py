@@ -173,6 +173,8 @@ def library():
     L.exaadmm_run_inner.argtypes = [H, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int), c_double_p]
     L.exaadmm_solve_two_level.argtypes = [H, C.POINTER(Info)]
     L.exaadmm_run_fixed.argtypes = [H, C.c_int, C.c_int, C.c_double, c_double_p, c_double_p, c_double_p]
+    L.exaadmm_state_save.argtypes = [H]
+    L.exaadmm_state_restore.argtypes = [H]
     L.exaadmm_set_stream.argtypes = [H, C.c_void_p]
     L.exaadmm_set_async.argtypes = [H, C.c_int]
     L.exaadmm_set_halo_index.argtypes = [H, C.c_int, C.POINTER(C.c_int32), c_i64_p, C.c_int64]
@@ -406,6 +408,12 @@ class ModelAcopf:
         _check(library().exaadmm_run_fixed(self._h, int(iters), int(first_major_iter), float(beta), _dp(out),
                                            C.byref(ms), C.byref(msb) if time_branch else None), "exaadmm_run_fixed")
         return out, ms.value, (msb.value if time_branch else None)
+
+    def state_save(self):
+        _check(library().exaadmm_state_save(self._h), "exaadmm_state_save")
+
+    def state_restore(self):
+        _check(library().exaadmm_state_restore(self._h), "exaadmm_state_restore")
 
     def run_inner(self, outer, max_inner, beta):
         out = np.zeros(4)

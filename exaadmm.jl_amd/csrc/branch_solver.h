@@ -34,11 +34,13 @@ struct BranchData {
     EXA_HD double rho(int k) const { return rho_[k]; }
     EXA_HD double xt(int k) const { return xt_[k]; }
     EXA_HD double Y(int k) const { return Y_[k]; }
-#if defined(EXA_PARK_CONST) && defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__)
     // The 32 read-only constants are only consumed by the objective / derivative evaluations.  A copy is parked in LDS
-    // ([entry][lane], conflict-free) when the solve starts; before the model step (two thirds of a trip, which never looks
-    // at them) the register copies are dropped, after it they are fetched back: 64 registers less at the solver's
-    // pressure peak.
+    // ([entry][lane], conflict-free, 16 KB per wavefront) when the solve starts; the register copies are dead across the
+    // model step (two thirds of a trip, which never looks at them) and are fetched back after it: 64 registers less at
+    // the solver's pressure peak, 217 -> 140 AGPRs of spill space, a quarter of the AGPR moves gone; +2.8 % iterations/s
+    // at 13 659 buses, +4 % on the whole solve (profiles/r03_parked_constants.txt).  (Round 1's variant read the constants
+    // from LDS at every use inside the evaluations and lost 3-15 %.)
     __device__ __forceinline__ void park(double* p) const
     {
         EXA_UNROLL

@@ -194,8 +194,8 @@ __global__ void __launch_bounds__(64) k_gen_ramp(Dev d, BranchOptions o, double 
 // auglag_linelimit_two_level_alternative (acopf_auglag_linelimit_kernel_gpu.jl:1-151):
 // one lane per branch, 64 branches per wavefront.  Everything a lane needs -- the 32 read-only problem
 // constants (l, rho, v-z, Y), the packed 6x6 Hessian, its Cholesky factor and all vectors / scalars of
-// the solver -- lives in registers (256 VGPR + AGPR spill space, one wave per SIMD); the kernel uses no
-// LDS.  (The reference keeps 1728 B of shared memory per BRANCH and one 32-thread block per branch.
+// the solver -- lives in registers (256 VGPR + AGPR spill space, one wave per SIMD); LDS only parks the
+// constants while the model step runs.  (The reference keeps 1728 B of shared memory per BRANCH and one 32-thread block per branch.
 // Variants measured and rejected -- constants / matrices staged in LDS, two waves per SIMD, fewer branches
 // per wavefront, lane regrouping: profiles/r02_two_waves_per_simd_experiments.txt, r02_lanes_per_wave.txt,
 // r02_wave_order_experiment.txt.)
@@ -362,12 +362,8 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_branch_t(const Dev* __restrict_
     unsigned long long t_loaded;
     asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_loaded) : "v"(x[0]) : "memory");
 #endif
-#if defined(EXA_PARK_CONST)
-    __shared__ double park_lds[32 * BR_BLOCK];
+    __shared__ double park_lds[32 * BR_BLOCK];   // the branch's 32 read-only constants, parked across the model steps (branch_solver.h)
     branch_solve(bd, o, c_mupow, x, xl, xu, A, L, phi, st, park_lds + threadIdx.x);
-#else
-    branch_solve(bd, o, c_mupow, x, xl, xu, A, L, phi, st);
-#endif
 #if defined(EXA_PROFILE_PHASES)
     const unsigned long long t_solved = __builtin_amdgcn_s_memtime();
 #endif
@@ -781,7 +777,8 @@ __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group(Dev d, double baseMVA, 
                 d.v[idx[1]] = vq;
                 d.v[idx[2]] = wi;
                 d.v[idx[3]] = ti;
-                if (code & END_CUT) {   // this end's new v entries are the peer's missing half of the branch: into its message
+                if ((code & END_CUT) && d.halo_pos != nullptr) {   // this end's new v entries are the peer's missing half of the branch: into its message
+                                                                    // (attached partitions only; the step-wise twin gathers them with exaadmm_halo_pack)
                     double* q = d.halo_send + d.halo_pos[code & END_INDEX];
                     q[0] = vp;
                     q[1] = vq;

@@ -155,6 +155,44 @@ def test_multi_period_trajectory_matches_oracle(pkg, syn, oracle):
     assert abs(mod.info.objval - om.objective()) <= 1e-8 * abs(om.objective())
 
 
+def test_multi_period_trajectory_at_1354_bus_size_matches_oracle(pkg, syn, oracle):
+    """What `bench.py --periods 4` runs, at a size the serial oracle follows in seconds: the synthetic case1354pegase-sized
+    grid (1 991 branches, 260 generators) over T = 4 load levels with the README's rho: 10 fused fixed-count iterations
+    from the cold start, then every vector of every period and ramp block against the CPU oracle.  (Multi-period parity
+    stopped at 118 buses before.)"""
+    grid = syn.sized_like("case1354pegase", seed=0)
+    T = 4
+    al = 1.0 + 0.01 * np.sin(np.arange(T) * 2 * np.pi / T)       # the load profile of bench.py --periods
+    pd = np.stack([grid["Pd"] * a for a in al], 1)
+    qd = np.stack([grid["Qd"] * a for a in al], 1)
+    env = pkg.AdmmEnv("syn1354", 1e1, 1e3, verbose=0, grid=grid)
+    mod = pkg.ModelMpacopf(env, (pd, qd), end_period=T, ramp_ratio=0.02)
+    env.params.scale, env.params.beta = 1e-4, 1e3
+    om = _oracle_mp(oracle, env.data, pd, qd, 1e1, 1e3, ramp_ratio=0.02, scale=1e-4)
+    om.par.beta = 1e3
+    NIT = 10
+    norms, _, _ = mod.run_fixed(NIT, first_major_iter=1, beta=1e3)
+    for it in range(1, NIT + 1):
+        om.inner_prestep(); om.update_x(it); om.update_xbar(); om.update_z(); om.update_l()
+        ores = om.update_residual()
+    assert np.allclose(norms, ores, rtol=1e-8, atol=1e-12), (norms, ores)
+    worst = 0.0
+    for t in range(T):
+        for name in ("u_curr", "v_curr", "z_curr", "l_curr"):
+            got = getattr(mod.models[t].solution, name)
+            ref = om.periods[t].sol[name]
+            err = np.abs(got - ref).max() / max(1.0, np.abs(ref).max())
+            worst = max(worst, err)
+            assert err <= 1e-7, (t, name, err)
+        if t > 0:
+            for name in ("u_curr", "s_curr", "z_curr", "l_curr"):
+                got = getattr(mod.solution[t], name)
+                ref = om.ramp[t][name]
+                assert np.abs(got - ref).max() <= 1e-7 * max(1.0, np.abs(ref).max()), (t, "ramp " + name)
+            assert np.array_equal(mod.solution[t].xi, om.gen_membuf[t][:, 7])    # ramp penalties: exact
+    print("1354-bus-sized grid x 4 periods, %d iterations: max relative deviation from the oracle %.2e" % (NIT, worst))
+
+
 def test_multi_period_fused_loop_matches_oracle(pkg, syn, oracle):
     """Fused device-resident loop (hipGraph replay, device-side break test with the max-over-periods
     norm): same inner-iteration counts as the oracle's admm_two_level over 3 outer iterations."""

@@ -134,6 +134,23 @@ EXA_HD double gpnorm(const double (&x)[N], const double (&xl)[N], const double (
     return r;
 }
 
+// ||a|| > delta, decided exactly as the comparison of the (correctly rounded) norm with delta decides it, but without the
+// square root wherever the squares are not within rounding distance of each other: 1e-14 is ~90 ulps, far outside what
+// the roundings of delta^2 and of the root can move; only near-ties -- delta is often exactly the norm of an earlier step
+// -- take the root (a lone wavefront pays 103 clocks for it, the Cauchy search asks this question ~4 times per model step).
+template <int N>
+EXA_HD bool norm_exceeds(const double (&a)[N], double delta)
+{
+#if defined(EXA_EXACT_ORACLE_ARITH)
+    return nrm2<N>(a) > delta;
+#else
+    const double n2 = dot<N>(a, a), d2 = delta * delta;
+    if (n2 > d2 * (1.0 + 1e-14)) return true;
+    if (n2 < d2 * (1.0 - 1e-14)) return false;
+    return sqrt(n2) > delta;
+#endif
+}
+
 template <int N>
 EXA_HD void breakpt(const double (&x)[N], const double (&xl)[N], const double (&xu)[N], const double (&w)[N],
                     double& brptmin, double& brptmax)
@@ -215,7 +232,7 @@ EXA_BIG void cauchy(const double (&x)[N], const double (&xl)[N], const double (&
         du[i] = xu[i] - x[i];
     }
     gpstep_d<N>(x, xl, xu, dl, du, -alpha, g, s);
-    if (nrm2<N>(s) > delta) {
+    if (norm_exceeds<N>(s, delta)) {
         interp = true;
         EXA_CNT(CNT_CAUCHY_FIRST_OUT);
     } else {
@@ -244,7 +261,7 @@ EXA_BIG void cauchy(const double (&x)[N], const double (&xl)[N], const double (&
     for (int guard = 0; search && (interp || alpha <= brptmax) && guard < 400; guard++) {
         alpha = (interp ? interpf : extrapf) * alpha;
         gpstep_d<N>(x, xl, xu, dl, du, -alpha, g, s);
-        const bool inside = (nrm2<N>(s) <= delta);
+        const bool inside = !norm_exceeds<N>(s, delta);
         double q = 0.0, gts = 0.0;
         if (inside) quad_model<N>(A, g, s, q, gts, as);
         if (inside) EXA_CNT(CNT_CAUCHY_TRIP_IN); else EXA_CNT(CNT_CAUCHY_TRIP_OUT);
@@ -300,6 +317,33 @@ EXA_HD void trsol_t(const ML& L, const double (&id)[N], double (&r)[N])
     }
 }
 
+// sqrt(x) and 1 / sqrt(x) from ONE Goldschmidt iteration (fast device build).  The compiler's double-precision square root
+// is v_rsq_f64 refined by exactly this coupled iteration, which carries h ~ 1 / (2 sqrt x) along for free; the pivot's
+// reciprocal is 2h after one correction step instead of a full IEEE division (13 dependent instructions, 78 clocks for a
+// lone wavefront, next to 103 for the square root: scripts/microbench/valu_latency.hip).  s is the correctly rounded
+// root for normal x > 0 (the same operations the compiler emits, minus its range scaling for x < 2^-767); r is within an
+// ulp of 1 / s.  x <= 0 or NaN yields NaN / garbage: the caller tests the pivot's sign itself.
+EXA_HD void sqrt_rcp(double x, double& s, double& r)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(EXA_EXACT_ORACLE_ARITH)
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double e = fma(-h, g, 0.5);
+    g = fma(g, e, g);
+    h = fma(h, e, h);
+    double d = fma(-g, g, x);
+    g = fma(d, h, g);
+    d = fma(-g, g, x);
+    g = fma(d, h, g);
+    s = g;
+    const double r0 = h + h;
+    r = fma(fma(-g, r0, 1.0), r0, r0);
+#else
+    s = sqrt(x);
+    r = 1.0 / s;
+#endif
+}
+
 // In-place left-looking Cholesky of the packed lower triangle (TRON dicf, dense), columns in order.
 // rd[j] receives 1 / L(j,j).  Returns false when a pivot is not positive (the factor is then garbage).
 template <int N, class ML>
@@ -314,11 +358,10 @@ EXA_HD bool chol_inplace(ML& L, double (&rd)[N])
             EXA_UNROLL
             for (int i = j; i < N; i++) L.lo(i, j) = EXA_FMA(-L.lo(i, k), ljk, L.lo(i, j));
         }
-        double d = L.lo(j, j);
+        double d = L.lo(j, j), r;
         ok = ok && (d > 0.0);
-        d = sqrt(d);
+        sqrt_rcp(d, d, r);
         L.lo(j, j) = d;
-        const double r = 1.0 / d;
         rd[j] = r;
         EXA_UNROLL
 #if defined(EXA_EXACT_ORACLE_ARITH)

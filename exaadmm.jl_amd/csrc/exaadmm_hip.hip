@@ -540,6 +540,32 @@ extern "C" int exaadmm_create(const exaadmm_grid* g, const exaadmm_params* p, in
             TRY(upload_vec(h, dcn, cnt));
             d.SlotCode = dsl;
             d.EndCount = dcn;
+            // "push" records of the fused loop (kernels.h, Dev::rec): where every generator / branch end drops what the bus
+            // update needs from it.  Component k of bus I: slot 8 I + k, from the 9th component on 8 B + (position in EndCode)
+            if (getenv("EXAADMM_NO_REC") == nullptr) {   // (A/B switch: the fused loop then gathers like the step-wise path)
+                std::vector<int> rbr(2 * (size_t)h->Lp, -1), rgen(h->Gp, -1);
+                for (int I = 0; I < h->B; I++)
+                    for (int k = 0; k < cnt[I]; k++) {
+                        const int code = ec[(size_t)es[I] + k], kind = (code >> 28) & 3, c = code & END_INDEX;
+                        const int rs = (k < BUS_W) ? I * BUS_W + k : BUS_W * h->B + es[I] + k;
+                        if (kind == END_GEN)
+                            rgen[c] = rs;
+                        else
+                            rbr[2 * (size_t)c + (kind == END_FROM ? 0 : 1)] = rs;
+                    }
+                int *drb, *drg;
+                double* drec;
+                const size_t nrec = ((size_t)BUS_W * h->B + ec.size()) * 8;
+                TRY(dev_alloc(h, &drb, rbr.size()));
+                TRY(dev_alloc(h, &drg, rgen.size()));
+                TRY(dev_alloc(h, &drec, nrec));
+                TRY(upload_vec(h, drb, rbr));
+                TRY(upload_vec(h, drg, rgen));
+                if (hipMemset(drec, 0, nrec * sizeof(double)) != hipSuccess) { set_err("hipMemset failed"); exaadmm_destroy(h); return EXAADMM_ERR_HIP; }
+                d.rec_br = drb;
+                d.rec_gen = drg;
+                d.rec = drec;
+            }
         }
     }
     // reduction scratch + loop control
@@ -1029,7 +1055,7 @@ static void launch_bus(exaadmm_handle* h, const Ctrl* c)
         hipLaunchKernelGGL(k_bus, grid_for(h->B, 64), dim3(64), 0, h->stream, h->d, h->baseMVA, c);
     else {
         flush_bus_const(h);
-        hipLaunchKernelGGL(k_bus_group, grid_for(h->B, BUS_BLOCK / BUS_W), dim3(BUS_BLOCK), 0, h->stream, h->d, h->baseMVA, c, (Ctrl*)nullptr);
+        hipLaunchKernelGGL((k_bus_group_t<false>), grid_for(h->B, BUS_BLOCK / BUS_W), dim3(BUS_BLOCK), 0, h->stream, h->d, h->baseMVA, c, (Ctrl*)nullptr);
     }
 }
 static void launch_fused_zl(exaadmm_handle* h, double beta, const Ctrl* c)
@@ -1300,7 +1326,7 @@ extern "C" int exaadmm_debug_wave_timeline(exaadmm_handle* h, unsigned long long
 // ------------------------------------------------------------------ the device-resident inner loop
 // Two launches per iteration (kernels.h):
 //     branch launch k+1 : [ z, l, residual terms of iteration k, per lane ] -> [ x-update k+1 ]      (k_branch_t<false, true>)
-//     bus launch    k+1 : [ bus update k+1 ]  ||  one extra block: residual sums of iteration k       (k_bus_group, `red`)
+//     bus launch    k+1 : [ bus update k+1 ]  ||  one extra block: residual sums of iteration k       (k_bus_group_t<true>, `red`)
 // and, for a partition with peers, ONE exchange: the v entries the bus update has just produced for the local end of
 // every cut branch + this rank's four residual sums -> grouped ncclSend / ncclRecv -> k_halo_unpack (scatter, add the
 // sums in rank order, advance the loop control).  The loop test of iteration k is known one launch late; the iterate is
@@ -1374,7 +1400,10 @@ static int enqueue_iteration_spec(exaadmm_handle* h, Ctrl* c, int j, bool sample
                        ng, h->baseMVA, j);
     if (bev) (void)hipEventRecord(bev[1], h->stream);
     if (sample) (void)hipEventRecord(h->tev[1], h->stream);
-    hipLaunchKernelGGL(k_bus_group, dim3(grid_for(h->B, BUS_BLOCK / BUS_W).x + 1), dim3(BUS_BLOCK), 0, h->stream, dv, h->baseMVA, c, c);
+    if (dv.rec != nullptr)   // the branch launch has pushed the bus records
+        hipLaunchKernelGGL((k_bus_group_t<true>), dim3(grid_for(h->B, BUS_BLOCK / BUS_W).x + 1), dim3(BUS_BLOCK), 0, h->stream, dv, h->baseMVA, c, c);
+    else
+        hipLaunchKernelGGL((k_bus_group_t<false>), dim3(grid_for(h->B, BUS_BLOCK / BUS_W).x + 1), dim3(BUS_BLOCK), 0, h->stream, dv, h->baseMVA, c, c);
     if (dist_has_peers(h)) {
         int rc = dist_exchange(h, dv, true, c, nullptr, 1);
         if (rc) return rc;

@@ -53,6 +53,14 @@ struct Dev {
     // served by that lane, EndCount[bus] = number of components -- one round of independent, coalesced loads instead of
     // the dependent pair EndStart -> EndCode (buses with more than 8 components use EndStart / EndCode for the rest)
     const int *SlotCode, *EndCount;
+    // "push" layout of the fused loop (k_bus_rec): the branch / generator lanes drop, for every end on a local bus, the
+    // 8 doubles the bus update needs from it -- (u+z, l, rho) of p and q and the two consensus terms of w and theta -- into
+    // rec[8 * slot], slot = 8 * bus + position in the bus's component list (later chunks of a bus with more than 8
+    // components: 8 * B + position in EndCode).  A bus lane's address then follows from its thread id alone: one
+    // contiguous 64-byte read per component instead of an index load followed by 16 dependent 8-byte gathers.
+    // rec_br[2 * branch + {0 from, 1 to}], rec_gen[generator] = slot or -1 (that end's bus belongs to a peer).
+    double* rec;
+    const int *rec_br, *rec_gen;
     int *st_auglag, *st_minor, *st_ticks;
     unsigned long long* st_cyc;  // diagnostic build (EXA_PROFILE_PHASES): 13 x Lp phase cycle counters
     unsigned long long* st_tl;   // diagnostic build: 128 timeline entries per wavefront (2 x Lp)
@@ -92,16 +100,23 @@ __device__ __forceinline__ bool loop_done(const Ctrl* c) { return c != nullptr &
 
 // ---------------------------------------------------------------- generator
 // generator_kernel_two_level (acopf_generator_kernel_gpu.jl:1-22), one lane per generator
-__device__ __forceinline__ void generator_update(const Dev& d, double baseMVA, int i, const double* vsrc = nullptr)
+__device__ __forceinline__ void generator_update(const Dev& d, double baseMVA, int i, const double* vsrc, double& up, double& uq)
 {
-    if (i >= d.G) return;
     const double* const v = vsrc ? vsrc : d.v;
     const int pg = i, qg = d.Gp + i;
     const double M = baseMVA;
     double t = (-(d.c1[i] * M + d.l[pg] + d.rho[pg] * (-v[pg] + d.z[pg]))) / (2 * d.c2[i] * (M * M) + d.rho[pg]);
-    d.u[pg] = fmax(d.pgmin[i], fmin(d.pgmax[i], t));
+    up = fmax(d.pgmin[i], fmin(d.pgmax[i], t));
+    d.u[pg] = up;
     t = (-(d.l[qg] + d.rho[qg] * (-v[qg] + d.z[qg]))) / d.rho[qg];
-    d.u[qg] = fmax(d.qgmin[i], fmin(d.qgmax[i], t));
+    uq = fmax(d.qgmin[i], fmin(d.qgmax[i], t));
+    d.u[qg] = uq;
+}
+__device__ __forceinline__ void generator_update(const Dev& d, double baseMVA, int i, const double* vsrc = nullptr)
+{
+    if (i >= d.G) return;
+    double up, uq;
+    generator_update(d, baseMVA, i, vsrc, up, uq);
 }
 
 // z_prev <- z ; z-update ; l-update ; residual terms of ONE element, the arithmetic of k_fused_zl
@@ -246,12 +261,26 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_branch_t(const Dev* __restrict_
         else if (ZL) {
             const double* const uin = d.u_in ? d.u_in : d.u;
             const double* const vin = d.v_in ? d.v_in : d.v;
-            if (do_zl && gi < d.G) {
-                double ln, zn;
-                zl_element(d, gi, uin[gi], vin[gi], d.rho[gi], zl_beta, zs, ln, zn);
-                zl_element(d, d.Gp + gi, uin[d.Gp + gi], vin[d.Gp + gi], d.rho[d.Gp + gi], zl_beta, zs, ln, zn);
+            if (gi < d.G) {
+                const int pg = gi, qg = d.Gp + gi;
+                const double rho_p = d.rho[pg], rho_q = d.rho[qg];
+                double lp = d.l[pg], lq = d.l[qg], zp = d.z[pg], zq = d.z[qg];
+                if (do_zl) {
+                    zl_element(d, pg, uin[pg], vin[pg], rho_p, zl_beta, zs, lp, zp);
+                    zl_element(d, qg, uin[qg], vin[qg], rho_q, zl_beta, zs, lq, zq);
+                }
+                double up, uq;
+                generator_update(d, baseMVA, gi, vin, up, uq);
+                if (d.rec != nullptr) {   // what the bus update needs from this generator, where its bus lane will look for it
+                    double* q = d.rec + 8 * (size_t)d.rec_gen[gi];
+                    q[0] = up + zp;
+                    q[1] = lp;
+                    q[2] = rho_p;
+                    q[3] = uq + zq;
+                    q[4] = lq;
+                    q[5] = rho_q;
+                }
             }
-            generator_update(d, baseMVA, gi, vin);
             if (do_zl) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
@@ -279,6 +308,9 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_branch_t(const Dev* __restrict_
     const double* const uin = d.u_in ? d.u_in : d.u;
     const double* const vin = (ZL && d.v_in) ? d.v_in : d.v;
 
+    // LDS, [entry][lane]: the branch's 32 read-only constants, parked across the model steps (branch_solver.h), and -- fused
+    // loop -- the 8 z entries of the iterate for the epilogue
+    __shared__ double park_lds[40 * BR_BLOCK];
     double ub[8], bnd[8];
     BranchData bd;
     double rate_0;
@@ -314,10 +346,12 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_branch_t(const Dev* __restrict_
                 d.z[e] = zn;
                 d.l[e] = bd.lam_[k];
                 bd.xt_[k] = vv[k] - zn;
+                zo[k] = zn;
             } else {
                 bd.lam_[k] = lo[k];
                 bd.xt_[k] = vv[k] - zo[k];
             }
+            park_lds[(32 + k) * BR_BLOCK + threadIdx.x] = zo[k];   // z of the iterate: the epilogue's bus records need it again
         }
         if (do_zl) {   // per-block partial sums of the four residual norms (fixed topology: wave shuffle, one wave per block)
             const bool counts = (b < d.Lown);   // a peer's branch replicated here: its terms are summed by its owner
@@ -362,7 +396,6 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_branch_t(const Dev* __restrict_
     unsigned long long t_loaded;
     asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_loaded) : "v"(x[0]) : "memory");
 #endif
-    __shared__ double park_lds[32 * BR_BLOCK];   // the branch's 32 read-only constants, parked across the model steps (branch_solver.h)
     branch_solve(bd, o, c_mupow, x, xl, xu, A, L, phi, st, park_lds + threadIdx.x);
 #if defined(EXA_PROFILE_PHASES)
     const unsigned long long t_solved = __builtin_amdgcn_s_memtime();
@@ -376,6 +409,30 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_branch_t(const Dev* __restrict_
     d.u[base + 5 * Lp] = x[1] * x[1];
     d.u[base + 6 * Lp] = x[2];
     d.u[base + 7 * Lp] = x[3];
+    if (ZL && d.rec != nullptr) {
+        // "push": what the bus update needs from the two ends of this branch -- (u+z, l, rho) of p and q, and the terms
+        // l + rho (u + z) of w and theta, evaluated exactly as the bus kernels evaluate them -- goes where the lanes of the
+        // end's bus will read it with an address that follows from their thread id (k_bus_rec)
+        double zz[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) zz[k] = park_lds[(32 + k) * BR_BLOCK + threadIdx.x];
+        const double un[8] = {phi[0], phi[1], phi[2], phi[3], x[0] * x[0], x[1] * x[1], x[2], x[3]};
+        const int rf = d.rec_br[2 * b], rt = d.rec_br[2 * b + 1];
+        if (rf >= 0) {
+            double* q = d.rec + 8 * (size_t)rf;
+            q[0] = un[0] + zz[0];  q[1] = bd.lam_[0];  q[2] = bd.rho_[0];
+            q[3] = un[1] + zz[1];  q[4] = bd.lam_[1];  q[5] = bd.rho_[1];
+            q[6] = bd.lam_[4] + bd.rho_[4] * (un[4] + zz[4]);
+            q[7] = bd.lam_[6] + bd.rho_[6] * (un[6] + zz[6]);
+        }
+        if (rt >= 0) {
+            double* q = d.rec + 8 * (size_t)rt;
+            q[0] = un[2] + zz[2];  q[1] = bd.lam_[2];  q[2] = bd.rho_[2];
+            q[3] = un[3] + zz[3];  q[4] = bd.lam_[3];  q[5] = bd.rho_[3];
+            q[6] = bd.lam_[5] + bd.rho_[5] * (un[5] + zz[5]);
+            q[7] = bd.lam_[7] + bd.rho_[7] * (un[7] + zz[7]);
+        }
+    }
     d.ls1[b] = bd.ls1;
     d.ls2[b] = bd.ls2;
     d.mu[b] = bd.mu;
@@ -634,11 +691,35 @@ __device__ __forceinline__ void ctrl_advance(Ctrl* c, const double (&s)[4])
     if ((test && c->res[0] <= c->eps_pri) || inner >= c->max_inner) c->done = 1;
 }
 
+// index of the v entries a component of a bus receives (generator: pg, qg; branch end: p, q, w, theta of that end)
+__device__ __forceinline__ void bus_end_index(const Dev& d, int code, int (&idx)[4])
+{
+    const int kind = (code >> 28) & 3, c = code & END_INDEX, Lp = d.Lp;
+    if (kind == END_GEN) {
+        idx[0] = c;
+        idx[1] = d.Gp + c;
+        idx[2] = idx[3] = -1;
+    } else {
+        const int e = 2 * d.Gp + c;
+        const int off = (kind == END_FROM) ? 0 : 2;
+        idx[0] = e + off * Lp;
+        idx[1] = e + (off + 1) * Lp;
+        idx[2] = e + ((kind == END_FROM) ? 4 : 5) * Lp;
+        idx[3] = e + ((kind == END_FROM) ? 6 : 7) * Lp;
+    }
+}
+
 // red != nullptr (the speculative loop): the launch carries one extra block that sums the per-block residual terms the
 // preceding branch launch's prologue left in partials_br.  One GPU: it advances the loop control itself (what
 // k_final_reduce does).  A partition with peers: it appends the four partial sums to every peer's halo message; the loop
 // control is advanced by k_halo_unpack once the peers' sums have arrived.
-__global__ void __launch_bounds__(BUS_BLOCK) k_bus_group(Dev d, double baseMVA, const Ctrl* ctrl, Ctrl* red)
+// REC = false: every lane gathers its component's (u, z, l, rho) from the solution planes (step-wise path, multi-period
+// model).  REC = true (the fused loop): the branch launch has pushed, for every component, the 8 doubles the bus update
+// needs into d.rec at the slot this lane owns (see Dev::rec) -- the launch starts with ONE round of loads whose addresses
+// all follow from the thread id, instead of an index load followed by 16 dependent gathers per lane spread over 16
+// cache lines; same terms, same order, same bits.
+template <bool REC>
+__global__ void __launch_bounds__(BUS_BLOCK) k_bus_group_t(Dev d, double baseMVA, const Ctrl* ctrl, Ctrl* red)
 {
     constexpr int T_W = 0, T_T = 1, T_P = 2, T_Q = 3, NTERM = 4;
     __shared__ double term[BUS_BLOCK / BUS_W][NTERM][BUS_W];
@@ -676,6 +757,14 @@ __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group(Dev d, double baseMVA, 
     const int n = d.EndCount[I];
     const int code0 = d.SlotCode[I * BUS_W + lane];
     const int e0 = (n > BUS_W) ? d.EndStart[I] : 0;   // (only the rare large buses need the CSR offset)
+    // REC: the first chunk's records, fetched with everything else (a lane past the bus's component count reads its own,
+    // unused, slot: no branch in front of the loads)
+    double r[BUS_REC];
+    if (REC) {
+        const double* q = d.rec + 8 * (size_t)(I * BUS_W + lane);
+#pragma unroll
+        for (int k = 0; k < 8; k++) r[k] = q[k];
+    }
 #if defined(EXA_PROFILE_PHASES)
     asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb1) : "v"(n) : "memory");
 #endif
@@ -689,25 +778,39 @@ __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group(Dev d, double baseMVA, 
     const double A11 = d.busc[BUSC_A11 * d.B + I], A12 = d.busc[BUSC_A12 * d.B + I], r21 = d.busc[BUSC_R21 * d.B + I];
     const double piv = d.busc[BUSC_PIV * d.B + I], rhosum_w = d.busc[BUSC_RW * d.B + I], rhosum_t = d.busc[BUSC_RT * d.B + I];
 
-    double r[BUS_REC];
     int idx[4], kind = -1, code = 0;
     for (int c0 = 0; c0 < n; c0 += BUS_W) {
         const int m = min(BUS_W, n - c0);
         if (lane < m) {
             code = (c0 == 0) ? code0 : d.EndCode[e0 + c0 + lane];
             kind = (code >> 28) & 3;
-            bus_load_end(d, code, r, idx);
+            if (REC) {
+                if (c0 > 0) {
+                    const double* q = d.rec + 8 * (size_t)(BUS_W * d.B + e0 + c0 + lane);
+#pragma unroll
+                    for (int k = 0; k < 8; k++) r[k] = q[k];
+                }
+                bus_end_index(d, code, idx);
+            } else
+                bus_load_end(d, code, r, idx);
 #if defined(EXA_PROFILE_PHASES)
             asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb2) : "v"(r[0]) : "memory");
 #endif
             kinds[grp][lane] = kind;
-            if (idx[2] <= -2)  // generator with a ramp partner (mpacopf_bus_kernel_cpu.jl:53-62)
-                term[grp][T_P][lane] = ((r[2] + r[3] * (r[0] + r[1])) + (r[10] + r[11] * (r[8] + r[9]))) / (r[3] + r[11]);
-            else
-                term[grp][T_P][lane] = (r[0] + r[1]) + (r[2] / r[3]);
-            term[grp][T_Q][lane] = (r[4] + r[5]) + (r[6] / r[7]);
-            term[grp][T_W][lane] = r[10] + r[11] * (r[8] + r[9]);
-            term[grp][T_T][lane] = r[14] + r[15] * (r[12] + r[13]);
+            if (REC) {   // record: (u+z, l, rho) of p / pg, the same of q / qg, the w term, the theta term
+                term[grp][T_P][lane] = r[0] + (r[1] / r[2]);
+                term[grp][T_Q][lane] = r[3] + (r[4] / r[5]);
+                term[grp][T_W][lane] = r[6];
+                term[grp][T_T][lane] = r[7];
+            } else {
+                if (idx[2] <= -2)  // generator with a ramp partner (mpacopf_bus_kernel_cpu.jl:53-62)
+                    term[grp][T_P][lane] = ((r[2] + r[3] * (r[0] + r[1])) + (r[10] + r[11] * (r[8] + r[9]))) / (r[3] + r[11]);
+                else
+                    term[grp][T_P][lane] = (r[0] + r[1]) + (r[2] / r[3]);
+                term[grp][T_Q][lane] = (r[4] + r[5]) + (r[6] / r[7]);
+                term[grp][T_W][lane] = r[10] + r[11] * (r[8] + r[9]);
+                term[grp][T_T][lane] = r[14] + r[15] * (r[12] + r[13]);
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -762,17 +865,26 @@ __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group(Dev d, double baseMVA, 
             if (n > BUS_W) {  // registers only hold the last chunk: fetch this one again
                 code = (c0 == 0) ? code0 : d.EndCode[e0 + c0 + lane];
                 kind = (code >> 28) & 3;
-                bus_load_end(d, code, r, idx);
+                if (REC) {
+                    const double* q = d.rec + 8 * (size_t)((c0 == 0) ? (I * BUS_W + lane) : (BUS_W * d.B + e0 + c0 + lane));
+#pragma unroll
+                    for (int k = 0; k < 8; k++) r[k] = q[k];
+                    bus_end_index(d, code, idx);
+                } else
+                    bus_load_end(d, code, r, idx);
             }
+            // (u+z), l, rho of the component's p (pg) and q (qg) entries
+            const double uzp = REC ? r[0] : (r[0] + r[1]), lp = REC ? r[1] : r[2], rhop = REC ? r[2] : r[3];
+            const double uzq = REC ? r[3] : (r[4] + r[5]), lq = REC ? r[4] : r[6], rhoq = REC ? r[5] : r[7];
             if (kind == END_GEN) {
-                if (idx[2] <= -2)
+                if (!REC && idx[2] <= -2)
                     d.v[idx[0]] = ((r[2] + r[3] * (r[0] + r[1])) + (r[10] + r[11] * (r[8] + r[9])) - mu1) / (r[3] + r[11]);
                 else
-                    d.v[idx[0]] = (r[0] + r[1]) + (r[2] - mu1) / r[3];
-                d.v[idx[1]] = (r[4] + r[5]) + (r[6] - mu2) / r[7];
+                    d.v[idx[0]] = uzp + (lp - mu1) / rhop;
+                d.v[idx[1]] = uzq + (lq - mu2) / rhoq;
             } else {
-                const double vp = (r[0] + r[1]) + (r[2] + mu1) / r[3];
-                const double vq = (r[4] + r[5]) + (r[6] + mu2) / r[7];
+                const double vp = uzp + (lp + mu1) / rhop;
+                const double vq = uzq + (lq + mu2) / rhoq;
                 d.v[idx[0]] = vp;
                 d.v[idx[1]] = vq;
                 d.v[idx[2]] = wi;

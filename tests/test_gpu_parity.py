@@ -394,6 +394,30 @@ def test_rolling_horizon_matches_oracle(pkg, oracle, case9_grid, tmp_path):
     assert np.allclose(mod.pgmin_curr, ref.pgmin_curr, atol=1e-8) and np.allclose(mod.pgmax_curr, ref.pgmax_curr, atol=1e-8)
 
 
+@pytest.mark.parametrize("case,rho,iters", [("case1354pegase", (1e1, 1e3), 40), ("case_ACTIVSg70k", (3e4, 3e5), 12)])
+def test_pushed_bus_records_leave_every_bit_where_the_gathers_leave_it(pkg, syn, case, rho, iters):
+    """The fused loop's bus launch reads what the branch launch pushed into its per-component records (k_bus_group_t<true>);
+    EXAADMM_NO_REC=1 makes it gather from the solution planes like the step-wise path (k_bus_group_t<false>).  Same terms
+    in the same order: u, v, z, l, the line-limit multipliers and the norms must be bit-identical -- also on the
+    ACTIVSg70k-sized grid, whose hub buses have more than 8 components (the record slots of the later chunks)."""
+    g = syn.sized_like(case, seed=0)
+    outs = []
+    for no_rec in (False, True):
+        if no_rec:
+            os.environ["EXAADMM_NO_REC"] = "1"
+        try:
+            env = pkg.AdmmEnv("syn", rho[0], rho[1], verbose=0, grid=g)
+            mod = pkg.ModelAcopf(env)
+        finally:
+            os.environ.pop("EXAADMM_NO_REC", None)
+        norms, _, _ = mod.run_fixed(iters, first_major_iter=1, beta=1e3)
+        outs.append((norms, mod.solution.u_curr, mod.solution.v_curr, mod.solution.z_curr, mod.solution.l_curr, mod.membuf))
+        mod.close()
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)
+    assert np.isfinite(outs[0][0]).all() and outs[0][0][0] > 0
+
+
 def test_two_processes_sharing_the_gpu_reproduce_single_handle():
     """The N>1 code path with real processes: two ranks (torch.distributed.run, gloo with host-staged
     collectives, because RCCL refuses two ranks on one device) each drive their partition through

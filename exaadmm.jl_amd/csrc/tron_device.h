@@ -120,16 +120,9 @@ EXA_HD double gpnorm(const double (&x)[N], const double (&xl)[N], const double (
     double r = 0.0;
     EXA_UNROLL
     for (int i = 0; i < N; i++) {
-        if (xl[i] != xu[i]) {
-            double v;
-            if (x[i] == xl[i])
-                v = fabs(fmin(g[i], 0.0));
-            else if (x[i] == xu[i])
-                v = fabs(fmax(g[i], 0.0));
-            else
-                v = fabs(g[i]);
-            r = fmax(r, v);
-        }
+        const double at_lo = fabs(fmin(g[i], 0.0)), at_hi = fabs(fmax(g[i], 0.0));
+        const double v = (x[i] == xl[i]) ? at_lo : ((x[i] == xu[i]) ? at_hi : fabs(g[i]));
+        r = (xl[i] != xu[i]) ? fmax(r, v) : r;
     }
     return r;
 }
@@ -151,22 +144,26 @@ EXA_HD bool norm_exceeds(const double (&a)[N], double delta)
 #endif
 }
 
+// Smallest and largest break point of the ray x + alpha w in the box (TRON dbreakpt); none -> 0, 0.
+// dl = xl - x, du = xu - x from the caller (x < xu exactly when du > 0).  Written without branches: every quotient is
+// formed (a division by w = 0 yields a value no selection ever takes), so the six divisions overlap instead of sitting one
+// after the other in six divergent regions -- ~330 clocks per call for a lone wavefront, same operands, same bits.
 template <int N>
-EXA_HD void breakpt(const double (&x)[N], const double (&xl)[N], const double (&xu)[N], const double (&w)[N],
-                    double& brptmin, double& brptmax)
+EXA_HD void breakpt(const double (&dl)[N], const double (&du)[N], const double (&w)[N], double& brptmin, double& brptmax)
 {
-    int nb = 0;
+    bool any = false;
     double bmin = 0.0, bmax = 0.0;
     EXA_UNROLL
     for (int i = 0; i < N; i++) {
-        bool up = (x[i] < xu[i]) && (w[i] > 0.0);
-        bool dn = (x[i] > xl[i]) && (w[i] < 0.0);
-        if (up || dn) {
-            double brpt = ((up ? xu[i] : xl[i]) - x[i]) / w[i];
-            bmin = (nb == 0) ? brpt : fmin(brpt, bmin);
-            bmax = (nb == 0) ? brpt : fmax(brpt, bmax);
-            nb++;
-        }
+        const bool up = (du[i] > 0.0) && (w[i] > 0.0);
+        const bool dn = (dl[i] < 0.0) && (w[i] < 0.0);
+        const bool mv = up || dn;
+        const double brpt = (up ? du[i] : dl[i]) / w[i];
+        const double lo = any ? fmin(brpt, bmin) : brpt;
+        const double hi = any ? fmax(brpt, bmax) : brpt;
+        bmin = mv ? lo : bmin;
+        bmax = mv ? hi : bmax;
+        any = any || mv;
     }
     brptmin = bmin;
     brptmax = bmax;
@@ -195,9 +192,19 @@ EXA_HD void gpstep_d(const double (&x)[N], const double (&xl)[N], const double (
     EXA_UNROLL
     for (int i = 0; i < N; i++) {
         const double aw = alpha * w[i];
+#if defined(EXA_EXACT_ORACLE_ARITH) || !defined(__HIP_DEVICE_COMPILE__)
         const double t = x[i] + aw;
         const double hi = (t > xu[i]) ? du[i] : aw;
         s[i] = (t < xl[i]) ? dl[i] : hi;
+#else
+        // fast device build: the same projection as a clamp of the step instead of a test of the point -- two instructions
+        // (v_min_f64, v_max_f64) where the form above needs an add, two compares and four 32-bit selects per component, ~6
+        // projections per model step.  The two forms pick different arms only when x + alpha w lands within a rounding
+        // error of a bound it does not sit on; the step then differs by an ulp of x (the point itself is clamped
+        // separately).  A variable that sits ON its bound (dl or du exactly 0) takes the same arm in both.
+        (void)x; (void)xl; (void)xu;
+        s[i] = fmax(dl[i], fmin(aw, du[i]));
+#endif
     }
 }
 
@@ -253,7 +260,7 @@ EXA_BIG void cauchy(const double (&x)[N], const double (&xl)[N], const double (&
         EXA_UNROLL
         for (int i = 0; i < N; i++) mg[i] = -g[i];
         double brptmin;
-        breakpt<N>(x, xl, xu, mg, brptmin, brptmax);
+        breakpt<N>(dl, du, mg, brptmin, brptmax);
     }
     double alphas = alpha;
     bool search = true;
@@ -488,9 +495,11 @@ EXA_HD double trqsol(const double (&x)[N], const double (&p)[N], double delta)
     double dsq = delta * delta;
     double rad = ptx * ptx + ptp * (dsq - xtx);
     rad = sqrt(fmax(rad, 0.0));
-    if (ptx > 0.0) return (dsq - xtx) / (ptx + rad);
-    if (rad > 0.0) return (rad - ptx) / ptp;
-    return 0.0;
+    // ONE division on selected operands instead of one division in each of two divergent branches (same operands, same
+    // quotient): a branch region costs a lone wavefront ~33 clocks of VALU -> SALU -> VALU hand-over before it does anything
+    const bool pos = (ptx > 0.0);
+    const double q = (pos ? (dsq - xtx) : (rad - ptx)) / (pos ? (ptx + rad) : ptp);
+    return (pos || rad > 0.0) ? q : 0.0;
 }
 
 // mask helper: zero the bound entries
@@ -548,7 +557,8 @@ EXA_BIG int trpcg_masked(unsigned fr, const MA& A, const double (&gf)[N], double
         trsol_n<N>(L, id, q);
 
         double ptq = dot<N>(p, q);
-        double alpha = (ptq > 0.0) ? rho / ptq : 0.0;
+        const double rq = rho / ptq;                    // (formed outside any branch, see trqsol; unused when ptq <= 0)
+        double alpha = (ptq > 0.0) ? rq : 0.0;
         double sigma = trqsol<N>(w, p, delta);
 
         if (ptq <= 0.0 || alpha >= sigma) {
@@ -612,16 +622,16 @@ EXA_BIG void prsrch_masked(unsigned fr, double (&x)[N], const double (&xl)[N], c
     const double mu0 = 0.01, interpf = 0.5;
     double wa1[N], wa2[N];
     double alpha = 1.0;
-    double brptmin, brptmax;
-    breakpt<N>(x, xl, xu, w, brptmin, brptmax);
-    EXA_CNT(CNT_PRSRCH);
-
     double dl[N], du[N];
     EXA_UNROLL
     for (int i = 0; i < N; i++) {
         dl[i] = xl[i] - x[i];
         du[i] = xu[i] - x[i];
     }
+    double brptmin, brptmax;
+    breakpt<N>(dl, du, w, brptmin, brptmax);
+    EXA_CNT(CNT_PRSRCH);
+
     bool search = true;
     bool wa1_current = false;   // wa1 = P[x + alpha w] - x for the CURRENT alpha (the accepted trial's step need not be projected twice)
     for (int guard = 0; search && alpha > brptmin && guard < 1100; guard++) {
@@ -782,21 +792,22 @@ EXA_HD bool tron_evaluate(TronState<N>& st, double ftrial, double (&x)[N], const
     if (st.iter == 1) delta = fmin(delta, snorm);
 
     const double g0 = st.gts;   // = dot(g, s): the products commute, the sum runs in the same order
-    double alpha;
-    if (f - fc - g0 <= 0.0)
-        alpha = sigma3;
-    else
-        alpha = fmax(sigma1, -0.5 * (g0 / (f - fc - g0)));
+    const double curv = f - fc - g0;
+    const double alpha = (curv <= 0.0) ? sigma3 : fmax(sigma1, -0.5 * (g0 / curv));   // (division outside any branch: see trqsol)
 
     const double prered = st.prered;
-    if (actred < eta0 * prered)
-        delta = fmin(fmax(alpha, sigma1) * snorm, sigma2 * delta);
-    else if (actred < eta1 * prered)
-        delta = fmax(sigma1 * delta, fmin(alpha * snorm, sigma2 * delta));
-    else if (actred < eta2 * prered)
-        delta = fmax(sigma1 * delta, fmin(alpha * snorm, sigma3 * delta));
-    else
-        delta = fmax(delta, fmin(alpha * snorm, sigma3 * delta));
+    {
+        // the four radius rules of dtron, all four formed and one selected (each is two or three operations; as nested
+        // branches every rule costs a lone wavefront a VALU -> SALU -> VALU hand-over before it starts)
+        const double as = alpha * snorm, s1d = sigma1 * delta, s2d = sigma2 * delta, s3d = sigma3 * delta;
+        const double d0 = fmin(fmax(alpha, sigma1) * snorm, s2d);
+        const double d1 = fmax(s1d, fmin(as, s2d));
+        const double d2 = fmax(s1d, fmin(as, s3d));
+        const double d3 = fmax(delta, fmin(as, s3d));
+        const double d23 = (actred < eta2 * prered) ? d2 : d3;
+        const double d123 = (actred < eta1 * prered) ? d1 : d23;
+        delta = (actred < eta0 * prered) ? d0 : d123;
+    }
     st.delta = delta;
 
     bool success = (actred > eta0 * prered);

@@ -540,12 +540,11 @@ def bench_main(args, rank, world, local_rank):
     params = B.CASE_PARAMS[args.case]
     g0, l0, b0 = syn.CASE_SIZES[args.case]
     sharded = (getattr(args, "scaling", "weak") == "strong")
-    gkw = dict(cost="market") if args.case == "case_ACTIVSg70k" else {}
     if sharded:
-        grid = syn.synthetic_grid(g0, l0, b0, seed=0, **gkw)
+        grid = syn.sized_like(args.case, seed=0)
         workload = "synthetic-%s-sized sharded %d ways" % (args.case, world)
     else:
-        grid = syn.synthetic_grid(world * g0, world * l0, world * b0, seed=0, **gkw)
+        grid = syn.sized_like(args.case, seed=0, areas=world)
         workload = "synthetic-%s-sized x %d areas" % (args.case, world)
     part = Partition(grid, world, rank)
     st = init_state(grid, params["rho_pq"], params["rho_va"])

@@ -223,6 +223,13 @@ def synthetic_grid(ngen, nline, nbus, seed=0, tight_factor=0.99, locality=64, fe
     return g
 
 
-def sized_like(case_name, seed=0, **kw):
+# generator options that belong to a named case (the README's rho for ACTIVSg70k, 3e4 / 3e5, is tuned to market-scale costs)
+CASE_KW = {"case_ACTIVSg70k": {"cost": "market"}}
+
+
+def sized_like(case_name, seed=0, areas=1, **kw):
+    """size-matched stand-in of a named case; areas = N: N areas of that size in one banded grid (weak scaling)"""
     ngen, nline, nbus = CASE_SIZES[case_name]
-    return synthetic_grid(ngen, nline, nbus, seed=seed, **kw)
+    opts = dict(CASE_KW.get(case_name, {}))
+    opts.update(kw)
+    return synthetic_grid(areas * ngen, areas * nline, areas * nbus, seed=seed, **opts)

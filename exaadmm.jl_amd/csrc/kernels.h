@@ -444,6 +444,11 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_branch_t(const Dev* __restrict_
     if (st.tl) {   // per-wave prologue / epilogue stamps (entries 123..127 of the timeline)
         unsigned long long t_stored;
         asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_stored) : : "memory");
+        {   // where the wavefront ran: HW_ID (wave / SIMD / CU / SH / SE) and the XCC -- scripts/diag_wave_starts.py pairs up successors on a SIMD
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
+            st.tl[121] = ((unsigned long long)xcc << 32) | hw;
+        }
         st.tl[122] = t_start;
         st.tl[123] = t_entry;
         st.tl[124] = t_loaded;

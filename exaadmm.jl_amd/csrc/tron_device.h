@@ -121,7 +121,9 @@ EXA_HD double gpnorm(const double (&x)[N], const double (&xl)[N], const double (
     EXA_UNROLL
     for (int i = 0; i < N; i++) {
         const double at_lo = fabs(fmin(g[i], 0.0)), at_hi = fabs(fmax(g[i], 0.0));
-        const double v = (x[i] == xl[i]) ? at_lo : ((x[i] == xu[i]) ? at_hi : fabs(g[i]));
+        double v = fabs(g[i]);
+        v = (x[i] == xu[i]) ? at_hi : v;
+        v = (x[i] == xl[i]) ? at_lo : v;
         r = (xl[i] != xu[i]) ? fmax(r, v) : r;
     }
     return r;
@@ -138,9 +140,10 @@ EXA_HD bool norm_exceeds(const double (&a)[N], double delta)
     return nrm2<N>(a) > delta;
 #else
     const double n2 = dot<N>(a, a), d2 = delta * delta;
-    if (n2 > d2 * (1.0 + 1e-14)) return true;
-    if (n2 < d2 * (1.0 - 1e-14)) return false;
-    return sqrt(n2) > delta;
+    const bool far_out = n2 > d2 * (1.0 + 1e-14), far_in = n2 < d2 * (1.0 - 1e-14);
+    bool out = far_out;
+    if (!(far_out || far_in)) out = sqrt(n2) > delta;
+    return out;
 #endif
 }
 
@@ -270,7 +273,7 @@ EXA_BIG void cauchy(const double (&x)[N], const double (&xl)[N], const double (&
         gpstep_d<N>(x, xl, xu, dl, du, -alpha, g, s);
         const bool inside = !norm_exceeds<N>(s, delta);
         double q = 0.0, gts = 0.0;
-        if (inside) quad_model<N>(A, g, s, q, gts, as);
+        if (inside) quad_model<N>(A, g, s, q, gts, as);   // (evaluating the model unconditionally measured 4 % slower: profiles/r03_branch_solver_steps.txt)
         if (inside) EXA_CNT(CNT_CAUCHY_TRIP_IN); else EXA_CNT(CNT_CAUCHY_TRIP_OUT);
         if (interp) {
             as_valid = inside;

@@ -1,20 +1,30 @@
 #!/bin/bash
 # GPU box: the measurements profiles/ is refreshed from (scripts/refresh_profiles.py).  usage: bash scripts/final_batch.sh OUTDIR
 O=${1:-gpurun_out/final}; mkdir -p $O
-python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.log 2>&1
-python bench.py > $O/bench_default.log 2>&1
-python bench.py --case case118 > $O/bench_case118.log 2>&1
-python bench.py --case case9 > $O/bench_case9.log 2>&1
-python bench.py --case case1354pegase --steps 100 --warmup 20 > $O/bench_case1354pegase.log 2>&1
-python bench.py --case case_ACTIVSg70k --steps 100 --warmup 20 --cpu-solve-budget 200 > $O/bench_case_ACTIVSg70k.log 2>&1
-python bench.py --case synthetic1M --steps 100 --warmup 20 --no-cpu-baseline > $O/bench_synthetic1M.log 2>&1
-python bench.py --force-dist --steps 200 --warmup 20 > $O/bench_dist1.log 2>&1
-python bench.py --periods 4 --steps 100 --warmup 20 > $O/bench_mp4.log 2>&1
+T="timeout 400"
+$T python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.log 2>&1
+$T python bench.py > $O/bench_default.log 2>&1
+$T python bench.py --case case118 > $O/bench_case118.log 2>&1
+$T python bench.py --case case9 > $O/bench_case9.log 2>&1
+$T python bench.py --case case1354pegase --steps 100 --warmup 20 > $O/bench_case1354pegase.log 2>&1
+$T python bench.py --case case_ACTIVSg70k --steps 100 --warmup 20 --cpu-solve-budget 200 > $O/bench_case_ACTIVSg70k.log 2>&1
+$T python bench.py --case synthetic1M --steps 100 --warmup 20 --no-cpu-baseline > $O/bench_synthetic1M.log 2>&1
+$T python bench.py --force-dist --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_dist1.log 2>&1
+$T python bench.py --force-dist --case case_ACTIVSg70k --steps 100 --warmup 20 --no-cpu-baseline > $O/bench_dist1_70k.log 2>&1
+$T python bench.py --periods 4 --steps 100 --warmup 20 > $O/bench_mp4.log 2>&1
 R=$PWD; cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/stats -- python3 $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline > $R/$O/stats_bench.log 2>&1
+for c in "" case1354pegase case_ACTIVSg70k synthetic1M; do
+  tag=${c:+_$c}; K=200; [ "$c" = "case_ACTIVSg70k" ] && K=100; [ "$c" = "synthetic1M" ] && K=50
+  $T rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/stats$tag -- python3 $R/bench.py ${c:+--case $c} --steps $K --warmup 20 --repeats 1 --no-cpu-baseline --no-full-solve > $R/$O/stats_bench$tag.log 2>&1
+  f=$(find $R/$O/stats$tag -name "*kernel_trace.csv" | head -1)
+  [ -n "$f" ] && python3 $R/scripts/kernel_trace_split.py $f $K 20 300 > $R/$O/split$tag.json && rm -f $f
+done
 cd $R
 bash scripts/collect_pmc.sh case13659pegase $O/pmc_case13659pegase 200 > $O/pmc1.log 2>&1
-bash scripts/collect_pmc.sh synthetic1M $O/pmc_synthetic1M 50 > $O/pmc2.log 2>&1
+bash scripts/collect_pmc.sh case1354pegase $O/pmc_case1354pegase 200 > $O/pmc2.log 2>&1
+bash scripts/collect_pmc.sh case_ACTIVSg70k $O/pmc_case_ACTIVSg70k 100 > $O/pmc3.log 2>&1
+bash scripts/collect_pmc.sh synthetic1M $O/pmc_synthetic1M 50 > $O/pmc4.log 2>&1
+find $O -name "*kernel_trace.csv" -delete
 for f in $O/bench_*.log; do echo "$f: $(python -c "
 import json
 for l in open('$f'):

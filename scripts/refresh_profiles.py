@@ -20,28 +20,39 @@ def line(f):
 
 
 names = {"bench_default": "bench", "bench_driver_cmd": "bench_driver_command_steps20", "bench_case1354pegase": "bench_case1354pegase",
-         "bench_case_ACTIVSg70k": "bench_case_ACTIVSg70k", "bench_synthetic1M": "bench_synthetic1M", "bench_dist1": "bench_force_dist_one_rank",
+         "bench_case_ACTIVSg70k": "bench_case_ACTIVSg70k", "bench_synthetic1M": "bench_synthetic1M", "bench_dist1": "bench_force_dist_one_rank", "bench_dist1_70k": "bench_force_dist_one_rank_case_ACTIVSg70k",
          "bench_mp4": "bench_mp_4_periods", "bench_case118": "bench_case118_real_file", "bench_case9": "bench_case9_real_file"}
 for k, v in names.items():
     f = os.path.join(src, k + ".log")
     if os.path.exists(f):
         json.dump(line(f), open(os.path.join(ROOT, "profiles", "%s_%s.json" % (rnd, v)), "w"), indent=1)
-st = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))
-if st:
-    shutil.copy(st[0], os.path.join(ROOT, "profiles", "%s_kernel_stats.csv" % rnd))
+for case, tag in (("", ""), ("case1354pegase", "_case1354pegase"), ("case_ACTIVSg70k", "_case_ACTIVSg70k"), ("synthetic1M", "_synthetic1M")):
+    st = glob.glob(os.path.join(src, "stats" + tag, "*", "*kernel_stats.csv"))
+    if st:
+        shutil.copy(st[0], os.path.join(ROOT, "profiles", "%s_kernel_stats%s.csv" % (rnd, tag)))
+    sp = os.path.join(src, "split%s.json" % tag)
+    if os.path.exists(sp):
+        shutil.copy(sp, os.path.join(ROOT, "profiles", "%s_kernel_trace_split%s.json" % (rnd, tag)))
 out_p = os.path.join(ROOT, "profiles", "%s_pmc_summary.json" % rnd)
-old = json.load(open(out_p)) if os.path.exists(out_p) else {}
-out = {"_note": old.get("_note", ""), "build": build}
-if "previous_build_r02_a" in old:
-    out["previous_build_r02_a"] = old["previous_build_r02_a"]
-for d, wl, steps, G, L in (("pmc_case13659pegase", "synthetic-case13659pegase-sized", 200, 4092, 20467), ("pmc_synthetic1M", "synthetic-synthetic1M-sized", 50, 50000, 1000000)):
+bench_line = line(os.path.join(src, "bench_default.log"))
+out = {"_note": "rocprofv3 --kernel-trace --pmc <group> passes (scripts/collect_pmc.sh, one counter group per run), per-launch averages over the timed "
+                "region of bench.py --repeats 1 (scripts/summarize_pmc.py).  FETCH_SIZE / WRITE_SIZE in KB; FETCH_SIZE counts requests in units of 64 B "
+                "(profiles/r03_fetch_size_counter_check.txt): x 2 for the plane-contiguous readers, both bounds for the bus kernel.  SQ_* cycle counters in "
+                "quad-cycles summed over waves; shader clock = GRBM_GUI_ACTIVE / 8 / kernel time.",
+       "build": build, "library_version": bench_line["roofline"]["library_version"],
+       "commit": subprocess.check_output(["git", "-C", ROOT, "rev-parse", "HEAD"], text=True).strip()}
+SIZES = {"case13659pegase": (4092, 20467), "case1354pegase": (260, 1991), "case_ACTIVSg70k": (10390, 88207), "synthetic1M": (50000, 1000000)}
+for case, steps in (("case13659pegase", 200), ("case1354pegase", 200), ("case_ACTIVSg70k", 100), ("synthetic1M", 50)):
+    d, wl = "pmc_" + case, "synthetic-%s-sized" % case
+    G, L = SIZES[case]
     p = os.path.join(src, d)
     if not os.path.isdir(p):
         continue
     out.update(json.loads(subprocess.check_output([sys.executable, os.path.join(ROOT, "scripts", "summarize_pmc.py"), p, wl, str(steps)])))
-    fused = True   # the z/l pass rides in the branch launch at every size (since the load-first prologue)
-    out[wl]["k_branch"]["algorithmic_bytes"] = int(824.0 * L + 192.0 * G) if fused else int(568.0 * L)
-    out[wl]["k_branch"]["algorithmic_bytes_note"] = ("fused launch: 568 B per branch + 128 B per generator + the unshared part of the z/l pass (32 B per vector element) = 824 L + 192 G"
-                                                     if fused else "568 B per branch")
+    out[wl]["k_branch"]["algorithmic_bytes"] = int(824.0 * L + 192.0 * G)
+    out[wl]["k_branch"]["algorithmic_bytes_note"] = ("fused launch: 568 B per branch + 128 B per generator + the unshared part of the z/l pass (32 B per vector element) "
+                                                     "= 824 L + 192 G.  On top of that the launch writes the bus records it pushes (128 B per branch, 48 B per generator) "
+                                                     "and reads their slot indices (8 B / 4 B): design traffic, not algorithmic -- it replaces 256 B of gathers per branch in the bus launch")
+    out[wl]["k_bus_group"]["algorithmic_bytes"] = None
 json.dump(out, open(out_p, "w"), indent=1)
 print("profiles refreshed from", src)

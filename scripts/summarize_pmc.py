@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Per-kernel, per-launch averages of rocprofv3 --pmc passes (scripts/collect_pmc.sh) over the TIMED region of
-bench.py (the last `steps` launches of each kernel), with the gfx950 corrections of MI355X_MICROARCH.md:
-FETCH_SIZE is reported in KB and counts a coalesced 128-B request as 64 B -> read bytes = 2 x FETCH_SIZE x 1024;
+bench.py (with --repeats 1: the last 2 x `steps` launches of each kernel are the timed region and the event-bracketed
+pass that follows it; the last `steps` are used), with the gfx950 corrections of MI355X_MICROARCH.md:
+FETCH_SIZE is reported in KB and counts REQUESTS in units of 64 B (profiles/r03_fetch_size_counter_check.txt): a coalesced
+128-B request counts as 64 B -> read bytes = 2 x FETCH_SIZE x 1024 for plane-contiguous readers (branch kernel, elementwise
+passes); requests of one 64-B sector or less (gathers, the 64-B bus records) are counted at their true size, so for the
+bus kernel both bounds are reported: traffic_bytes (x 2, upper bound) and traffic_bytes_sector_reads (x 1);
 WRITE_SIZE (KB) is exact for streaming stores; SQ_* cycle counters are in quad-cycles summed over waves;
 GRBM_GUI_ACTIVE is summed over the 8 XCDs -> shader clock = GRBM_GUI_ACTIVE / 8 / kernel wall time.
 usage: summarize_pmc.py OUTDIR workload-name [steps] -> JSON on stdout"""
@@ -35,6 +39,9 @@ for name, c in acc.items():
     e = {k: round(v, 3) for k, v in c.items()}
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         e["traffic_bytes"] = int(2 * c["FETCH_SIZE"] * 1024 + c["WRITE_SIZE"] * 1024)
+        e["read_factor_applied"] = 2
+        if name == "k_bus_group":
+            e["traffic_bytes_sector_reads"] = int(c["FETCH_SIZE"] * 1024 + c["WRITE_SIZE"] * 1024)
     if "SQ_ACTIVE_INST_VALU" in c and "SQ_WAVE_CYCLES" in c:
         e["valu_busy"] = round(c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"], 4)      # both in quad-cycles
     if "SQ_INSTS_VALU" in c and "SQ_WAVE_CYCLES" in c:

@@ -12,8 +12,11 @@ L = pkg.library()
 L.exaadmm_debug_wave_timeline.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int64]
 case = sys.argv[1] if len(sys.argv) > 1 else "case13659pegase"
 g = syn.sized_like(case, seed=0)
-env = pkg.AdmmEnv("syn", 5e1, 5e3, verbose=0, grid=g)
+rho = {"case_ACTIVSg70k": (3e4, 3e5)}.get(case, (5e1, 5e3))
+env = pkg.AdmmEnv("syn", rho[0], rho[1], verbose=0, grid=g)
 mod = pkg.ModelAcopf(env)
+env.params.scale = 1e-5 if case == "case_ACTIVSg70k" else 1e-4
+mod.sync_params()
 nwarm = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 mod.run_fixed(nwarm, first_major_iter=1, beta=1e3)
 Lp = ((g["nline"] + 63) // 64) * 64

@@ -188,3 +188,24 @@ def test_default_partition_keeps_the_cut_small_whatever_the_bus_numbering():
     # every branch is native on exactly one rank, every cut branch is a ghost on exactly one other
     parts = [dm.Partition(h, world, r) for r in range(world)]
     assert sum(p.n_native for p in parts) == 2000 and sum(p.n_ghost for p in parts) == cut_bfs
+
+
+def test_weak_scaling_workload_is_n_areas_with_few_tie_lines():
+    """bench.py --gpus N (--scaling weak): ONE banded grid of N areas of the case's size, cut N ways along a breadth-first bus
+    order -- every rank gets about one area, the cut branches are the tie lines (north_star's target configuration is this
+    with --case case_ACTIVSg70k; here at 1 354-bus size, 4 areas)."""
+    dm = exaadmm_loader.load_submodule("distributed")
+    syn = exaadmm_loader.load_submodule("synthetic")
+    g1, l1, b1 = syn.CASE_SIZES["case1354pegase"]
+    world = 4
+    grid = syn.sized_like("case1354pegase", seed=0, areas=world)
+    assert (grid["ngen"], grid["nline"], grid["nbus"]) == (world * g1, world * l1, world * b1)
+    parts = [dm.Partition(grid, world, r) for r in range(world)]
+    assert sum(p.n_native for p in parts) == world * l1
+    for p in parts:
+        assert abs(p.Bl - b1) <= 1 and abs(p.n_native - l1) <= 0.1 * l1            # one area's worth of work per rank
+        assert p.grid["nline_owned"] == p.n_native and p.Ll == p.n_native + p.n_ghost
+    cut = sum(p.n_cut for p in parts)
+    assert 0 < cut <= 0.03 * world * l1, cut                                        # tie lines only
+    # the ACTIVSg70k-sized case carries its own generator options (market-scale costs, which the README's rho is tuned to)
+    assert syn.CASE_KW["case_ACTIVSg70k"] == {"cost": "market"}

@@ -31,9 +31,13 @@ import ctypes as C
 world = %(world)d
 case = %(case)r
 fixed_only = False
+NFIX = 60
 if case == "activsg70k":                  # BASELINE config 4's size (88 207 branches), fixed-count mode only
     g = syn.sized_like("case_ACTIVSg70k", seed=0)
     rho, par_over, fixed_only = (3e4, 3e5), {}, True
+elif case == "synthetic1M":               # BASELINE config 5's size (1M branches, 500 000 buses), fixed-count mode only
+    g = syn.sized_like("synthetic1M", seed=0)
+    rho, par_over, fixed_only, NFIX = (5e1, 5e3), {}, True, 20
 elif case:
     g = pkg.opf_loaddata(case)            # the reference's 118-bus anchor case, cut into `world` partitions
     rho, par_over = (4e2, 4e4), dict(outer_iterlim=25, outer_eps=2e-5)
@@ -70,9 +74,10 @@ class Stub:
         Stub.barrier.wait()
         t[0] = v
 
-bes = [dm.HipBackend(pkg, p, rho[0], rho[1], device_index=0) for p in parts]
 par = dict(dm.DEFAULT_PAR); par.update(par_over)
-models = [dm.DistributedAcopf(p, be, Stub(r), st, par) for r, (p, be) in enumerate(zip(parts, bes))]
+if not fixed_only:
+    bes = [dm.HipBackend(pkg, p, rho[0], rho[1], device_index=0) for p in parts]
+    models = [dm.DistributedAcopf(p, be, Stub(r), st, par) for r, (p, be) in enumerate(zip(parts, bes))]
 infos, errs = [None] * world, [None] * world
 def run(r):
     try:
@@ -104,7 +109,6 @@ bes2 = [dm.HipBackend(pkg, p, rho[0], rho[1], device_index=0) for p in parts]
 for p, be in zip(parts, bes2):
     for name in ("v_curr", "rho"):
         be.upload(name, p.slice_global(st[name]))
-NFIX = 60
 errs = [None] * world
 exch = [None] * world
 def run2(r):
@@ -119,11 +123,12 @@ def run2(r):
     except BaseException as ex:
         errs[r] = repr(ex)
 ths = [threading.Thread(target=run2, args=(r,)) for r in range(world)]
-[t.start() for t in ths]; [t.join(180) for t in ths]
+[t.start() for t in ths]; [t.join(400) for t in ths]
 assert not any(t.is_alive() for t in ths), "a rank hung"
 assert not any(errs), errs
 out["shim_counts_after"] = shim_counts()
 out["exchanges_in_60_iterations"] = exch
+out["nfix"] = NFIX
 env3 = pkg.AdmmEnv("single", rho[0], rho[1], verbose=0, grid=g)
 m3 = pkg.ModelAcopf(env3)
 m3.run_fixed(NFIX, first_major_iter=1, beta=1e3)
@@ -156,7 +161,7 @@ def _run_worker(world, case):
         pytest.skip("the in-library loop of a partition with peers IS the two-launch speculative loop; this A/B switch turns that loop off")
     env = dict(os.environ, EXAADMM_RCCL_LIB=_shim())
     r = subprocess.run([sys.executable, "-c", WORKER % {"root": ROOT, "world": world, "case": case}], env=env,
-                       capture_output=True, text=True, timeout=480)
+                       capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     return json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
 
@@ -197,6 +202,19 @@ def test_activsg70k_sized_grid_sharded_four_ways_is_bitwise_the_single_handle_lo
     assert all(n == 0 for n in out["fixed_nonzero_differences"].values()), out
     assert out["n_replica_entries"] == 8 * out["cut"] and all(n == 0 for n in out["replica_differences"].values()), out
     assert out["exchanges_in_60_iterations"] == [61] * 4, out
+
+
+def test_1M_branch_grid_sharded_eight_ways_is_bitwise_the_single_handle_loop():
+    """BASELINE config 5 at its own size and at the node's rank count: the 1M-branch / 500 000-bus grid cut into 8 partitions (125 000
+    branches each, what one GPU of the node sees), 20 fixed-count iterations of the in-library loop over the RCCL stand-in: u, v, z, l bit for
+    bit the single-handle loop, replicas bit-identical on both owners, one exchange per iteration with 7 peers each."""
+    out = _run_worker(8, "synthetic1M")
+    assert out["cut"] > 0 and out["nfix"] == 20
+    assert all(n == 0 for n in out["fixed_nonzero_differences"].values()), out
+    assert out["n_replica_entries"] == 8 * out["cut"] and all(n == 0 for n in out["replica_differences"].values()), out
+    assert out["exchanges_in_60_iterations"] == [21] * 8, out
+    groups, sends, recvs = (a - b for a, b in zip(out["shim_counts_after"], out["shim_counts_before"]))
+    assert groups == 21 * 8 and sends == recvs == 21 * 8 * 7, out
 
 
 def test_bench_under_the_launcher_one_rank_dist_path():

@@ -92,7 +92,7 @@ struct exaadmm_handle {
     std::vector<double> stage;       // host staging, N doubles
     std::vector<double> rateA_h;
     // device position of reference branch b.  Branches are stored sorted by the bus they are
-    // gathered from (from-bus for own branches, to-bus for ghosts) so that the bus kernel's
+    // gathered from (from-bus for own branches, to-bus for a partition's replicas of a peer's cut branches) so that the bus kernel's
     // gathers of consecutive buses hit consecutive elements of the planes.
     std::vector<int> perm;
     // per reference branch: 0 = both ends on this handle's buses, 1 = only the from-end, 2 = only the to-end (a partition's
@@ -102,7 +102,7 @@ struct exaadmm_handle {
     double* d_busc = nullptr;   // rho-only constants of the bus update (k_bus_const); recomputed when rho changes
     bool busc_dirty = true;
     // hipGraph of one batch of fused inner iterations (exaadmm_run_inner); rebuilt when anything
-    // baked into its kernel arguments changes (parameters, active counts, masks, lane order)
+    // baked into its kernel arguments changes (parameters, attach / detach of a partition)
     hipGraphExec_t batch_graph = nullptr;
     bool use_graph = true;
     HaloSlot halo[8];
@@ -527,7 +527,7 @@ extern "C" int exaadmm_create(const exaadmm_grid* g, const exaadmm_params* p, in
             TRY(upload_vec(h, dec, ec));
             d.EndStart = des;
             d.EndCode = dec;
-            // slot layout of the first chunk of every bus (k_bus_group)
+            // slot layout of the first chunk of every bus (k_bus_group_t)
             std::vector<int> slot((size_t)h->B * BUS_W, 0), cnt(h->B, 0);
             for (int I = 0; I < h->B; I++) {
                 cnt[I] = es[I + 1] - es[I];

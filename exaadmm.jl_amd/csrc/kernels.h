@@ -16,7 +16,7 @@ namespace exa {
 
 // loop control shared by the kernels of a fused inner loop (lives in device memory)
 struct Ctrl {
-    int done;         // set by the reduction (k_final_reduce / k_bus_group `red` / k_halo_unpack) when the inner loop must stop
+    int done;         // set by the reduction (k_final_reduce / k_bus_group_t `red` / k_halo_unpack) when the inner loop must stop
     int inner;        // completed inner iterations
     int max_inner;
     int check_every;  // 1 = reference semantics
@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(64) k_gen_ramp(Dev d, BranchOptions o, double 
 // loads u, v, z, l, rho of its own 8 (generator lanes: 2) elements, so the pass costs 8 more loads (lz) and
 // its arithmetic instead of a kernel of its own (6 reads + 3 writes per element and a launch); per-block
 // partial sums of the four residual norms go to partials_br, the bus launch that follows reduces them
-// (k_bus_group, `red`).  The launch is speculative: it does not wait for the loop test of the previous
+// (k_bus_group_t, `red`).  The launch is speculative: it does not wait for the loop test of the previous
 // iteration; it reads the previous iterate (u_in, v_in, ls*_in) and writes the other buffer set, so a stop
 // detected one launch later leaves the iterate of the stopping iteration -- including the z, l this prologue
 // has just completed for it -- intact.
@@ -588,7 +588,8 @@ __global__ void k_bus(Dev d, double baseMVA, const Ctrl* ctrl)
 // Buses with more than BUS_W incident components are processed in chunks.
 constexpr int BUS_W = 8;         // measured at 13 659 buses (kernel-trace average): 8 -> 12.8, 16 -> 13.5, 32 -> 15.5 us
 constexpr int BUS_BLOCK = 256;   // measured at 13 659 buses: 64 -> 15.1, 128 -> 14.5, 256 -> 12.4, 512 -> 11.9, 1024 -> 13.2 us; 512 loses 5 % of the non-branch time at 1M branches
-static_assert(BUS_BLOCK == EW_BLOCK, "the reduction block of k_bus_group uses block_reduce4, which is laid out for EW_BLOCK threads");
+static_assert(BUS_W == 8, "k_bus_group_t reads its group's byte of a wavefront ballot and unrolls the leader's sums over 8 slots");
+static_assert(BUS_BLOCK == EW_BLOCK, "the reduction block of k_bus_group_t uses block_reduce4, which is laid out for EW_BLOCK threads");
 constexpr int BUS_REC = 16;  // doubles per record: (u,z,l,rho) x (p,q,w,theta) or (u,z,l,rho) x (pg,qg)
 enum { END_GEN = 0, END_FROM = 1, END_TO = 2 };
 constexpr int END_CUT = 1 << 30;        // component code flag: the branch is shared with a peer partition (its v entries go into the halo message)
@@ -726,9 +727,14 @@ __device__ __forceinline__ void bus_end_index(const Dev& d, int code, int (&idx)
 template <bool REC>
 __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group_t(Dev d, double baseMVA, const Ctrl* ctrl, Ctrl* red)
 {
-    constexpr int T_W = 0, T_T = 1, T_P = 2, T_Q = 3, NTERM = 4;
+    // Terms a lane hands to its group leader.  The leader adds them in the reference's order -- generators, then -Pd, then the
+    // branch ends -- WITHOUT looking at what kind of component a slot holds: a slot contributes a neutral element to the
+    // sums it does not belong to (-0.0 where the leader adds, +0.0 where it subtracts: x + (-0) = x and x - (+0) = x for
+    // every x, signed zeros included), and so do the slots past the bus's last component.  Same effective operations in
+    // the same order as the component-by-component loop, hence the same bits; no branch and no dependent LDS read in the
+    // leader's chain (3.3 k -> ~1.5 k clocks per block, scripts/bus_stamps.py).
+    constexpr int T_W = 0, T_T = 1, T_PG = 2, T_QG = 3, T_PE = 4, T_QE = 5, NTERM = 6;
     __shared__ double term[BUS_BLOCK / BUS_W][NTERM][BUS_W];
-    __shared__ int kinds[BUS_BLOCK / BUS_W][BUS_W];
     __shared__ double res[BUS_BLOCK / BUS_W][4];
     if (red != nullptr && blockIdx.x == gridDim.x - 1) {   // the reduction block (whole block takes this path)
         if (red->done || !red->pending) return;
@@ -801,41 +807,63 @@ __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group_t(Dev d, double baseMVA
 #if defined(EXA_PROFILE_PHASES)
             asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb2) : "v"(r[0]) : "memory");
 #endif
-            kinds[grp][lane] = kind;
+            double tp, tq, tw = -0.0, tt = -0.0;
             if (REC) {   // record: (u+z, l, rho) of p / pg, the same of q / qg, the w term, the theta term
-                term[grp][T_P][lane] = r[0] + (r[1] / r[2]);
-                term[grp][T_Q][lane] = r[3] + (r[4] / r[5]);
-                term[grp][T_W][lane] = r[6];
-                term[grp][T_T][lane] = r[7];
+                tp = r[0] + (r[1] / r[2]);
+                tq = r[3] + (r[4] / r[5]);
+                if (kind != END_GEN) {
+                    tw = r[6];
+                    tt = r[7];
+                }
             } else {
                 if (idx[2] <= -2)  // generator with a ramp partner (mpacopf_bus_kernel_cpu.jl:53-62)
-                    term[grp][T_P][lane] = ((r[2] + r[3] * (r[0] + r[1])) + (r[10] + r[11] * (r[8] + r[9]))) / (r[3] + r[11]);
+                    tp = ((r[2] + r[3] * (r[0] + r[1])) + (r[10] + r[11] * (r[8] + r[9]))) / (r[3] + r[11]);
                 else
-                    term[grp][T_P][lane] = (r[0] + r[1]) + (r[2] / r[3]);
-                term[grp][T_Q][lane] = (r[4] + r[5]) + (r[6] / r[7]);
-                term[grp][T_W][lane] = r[10] + r[11] * (r[8] + r[9]);
-                term[grp][T_T][lane] = r[14] + r[15] * (r[12] + r[13]);
+                    tp = (r[0] + r[1]) + (r[2] / r[3]);
+                tq = (r[4] + r[5]) + (r[6] / r[7]);
+                if (kind != END_GEN) {
+                    tw = r[10] + r[11] * (r[8] + r[9]);
+                    tt = r[14] + r[15] * (r[12] + r[13]);
+                }
             }
+            const bool gen = (kind == END_GEN);
+            term[grp][T_PG][lane] = gen ? tp : -0.0;
+            term[grp][T_QG][lane] = gen ? tq : -0.0;
+            term[grp][T_PE][lane] = gen ? 0.0 : tp;
+            term[grp][T_QE][lane] = gen ? 0.0 : tq;
+            term[grp][T_W][lane] = tw;
+            term[grp][T_T][lane] = tt;
+        } else {   // no component in this slot: neutral elements
+            term[grp][T_PG][lane] = -0.0;
+            term[grp][T_QG][lane] = -0.0;
+            term[grp][T_PE][lane] = 0.0;
+            term[grp][T_QE][lane] = 0.0;
+            term[grp][T_W][lane] = -0.0;
+            term[grp][T_T][lane] = -0.0;
         }
+        // does this chunk hold a branch end?  (the load is subtracted once, in front of the first one)
+        const unsigned long long ends = __ballot(lane < m && kind != END_GEN);
+        const bool has_end = ((ends >> (8 * ((threadIdx.x & 63) / BUS_W))) & 0xffull) != 0ull;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (lane == 0) {
-            for (int k = 0; k < m; k++) {
-                if (kinds[grp][k] == END_GEN) {
-                    rhs1 += term[grp][T_P][k];
-                    rhs2 += term[grp][T_Q][k];
-                } else {
-                    if (!load_subtracted) {
-                        rhs1 -= pd;
-                        rhs2 -= qd;
-                        load_subtracted = true;
-                    }
-                    common_wi += term[grp][T_W][k];
-                    common_ti += term[grp][T_T][k];
-                    rhs1 -= term[grp][T_P][k];
-                    rhs2 -= term[grp][T_Q][k];
-                }
+#pragma unroll
+            for (int k = 0; k < BUS_W; k++) {
+                rhs1 += term[grp][T_PG][k];
+                rhs2 += term[grp][T_QG][k];
+            }
+            if (has_end && !load_subtracted) {
+                rhs1 -= pd;
+                rhs2 -= qd;
+                load_subtracted = true;
+            }
+#pragma unroll
+            for (int k = 0; k < BUS_W; k++) {
+                common_wi += term[grp][T_W][k];
+                common_ti += term[grp][T_T][k];
+                rhs1 -= term[grp][T_PE][k];
+                rhs2 -= term[grp][T_QE][k];
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -1,17 +1,9 @@
 #!/bin/bash
-# GPU box: the measurements profiles/ is refreshed from (scripts/refresh_profiles.py).  usage: bash scripts/final_batch.sh OUTDIR
+# GPU box: the measurements profiles/ is refreshed from.  Order matters: kernel traces and PMC passes first, then
+# scripts/refresh_profiles.py writes profiles/r03_pmc_summary.json (with the version string of THIS build), then the bench lines --
+# which read `traffic` / `valu_busy` from that summary and refuse it for any other build.  usage: bash scripts/final_batch.sh OUTDIR
 O=${1:-gpurun_out/final}; mkdir -p $O
-T="timeout 400"
-$T python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.log 2>&1
-$T python bench.py > $O/bench_default.log 2>&1
-$T python bench.py --case case118 > $O/bench_case118.log 2>&1
-$T python bench.py --case case9 > $O/bench_case9.log 2>&1
-$T python bench.py --case case1354pegase --steps 100 --warmup 20 > $O/bench_case1354pegase.log 2>&1
-$T python bench.py --case case_ACTIVSg70k --steps 100 --warmup 20 --cpu-solve-budget 200 > $O/bench_case_ACTIVSg70k.log 2>&1
-$T python bench.py --case synthetic1M --steps 100 --warmup 20 --no-cpu-baseline > $O/bench_synthetic1M.log 2>&1
-$T python bench.py --force-dist --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_dist1.log 2>&1
-$T python bench.py --force-dist --case case_ACTIVSg70k --steps 100 --warmup 20 --no-cpu-baseline > $O/bench_dist1_70k.log 2>&1
-$T python bench.py --periods 4 --steps 100 --warmup 20 > $O/bench_mp4.log 2>&1
+T="timeout 500"
 R=$PWD; cd /tmp; export TMPDIR=/tmp
 for c in "" case1354pegase case_ACTIVSg70k synthetic1M; do
   tag=${c:+_$c}; K=200; [ "$c" = "case_ACTIVSg70k" ] && K=100; [ "$c" = "synthetic1M" ] && K=50
@@ -25,9 +17,21 @@ bash scripts/collect_pmc.sh case1354pegase $O/pmc_case1354pegase 200 > $O/pmc2.l
 bash scripts/collect_pmc.sh case_ACTIVSg70k $O/pmc_case_ACTIVSg70k 100 > $O/pmc3.log 2>&1
 bash scripts/collect_pmc.sh synthetic1M $O/pmc_synthetic1M 50 > $O/pmc4.log 2>&1
 find $O -name "*kernel_trace.csv" -delete
+python scripts/refresh_profiles.py $O r03 "${BUILD_NOTE:-round 3 final build}" > $O/refresh1.log 2>&1
+cp profiles/r03_pmc_summary.json $O/r03_pmc_summary.json
+$T python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.log 2>&1
+$T python bench.py > $O/bench_default.log 2>&1
+$T python bench.py --case case118 > $O/bench_case118.log 2>&1
+$T python bench.py --case case9 > $O/bench_case9.log 2>&1
+$T python bench.py --case case1354pegase --steps 100 --warmup 20 > $O/bench_case1354pegase.log 2>&1
+$T python bench.py --case case_ACTIVSg70k --steps 100 --warmup 20 --cpu-solve-budget 200 > $O/bench_case_ACTIVSg70k.log 2>&1
+$T python bench.py --case synthetic1M --steps 100 --warmup 20 --no-cpu-baseline > $O/bench_synthetic1M.log 2>&1
+$T python bench.py --force-dist --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_dist1.log 2>&1
+$T python bench.py --force-dist --case case_ACTIVSg70k --steps 100 --warmup 20 --no-cpu-baseline > $O/bench_dist1_70k.log 2>&1
+$T python bench.py --periods 4 --steps 100 --warmup 20 > $O/bench_mp4.log 2>&1
 for f in $O/bench_*.log; do echo "$f: $(python -c "
 import json
 for l in open('$f'):
     if l.startswith('{'):
-        d=json.loads(l); fs=d.get('full_solve',{}); print('%.1f it/s  ms/step %.4f | full solve %s' % (d['value'], d['ms_per_step'], (fs.get('status'), fs.get('outer'), fs.get('cumul'), fs.get('iterations_per_s'), fs.get('speedup_vs_cpu_port'))))
+        d=json.loads(l); fs=d.get('full_solve',{}); print('%.1f it/s  ms/step %.4f traffic %s | full solve %s' % (d['value'], d['ms_per_step'], d['roofline'].get('traffic'), (fs.get('status'), fs.get('outer'), fs.get('cumul'), fs.get('iterations_per_s'), fs.get('speedup_vs_cpu_port'))))
 ")"; done

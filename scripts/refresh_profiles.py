@@ -34,13 +34,20 @@ for case, tag in (("", ""), ("case1354pegase", "_case1354pegase"), ("case_ACTIVS
     if os.path.exists(sp):
         shutil.copy(sp, os.path.join(ROOT, "profiles", "%s_kernel_trace_split%s.json" % (rnd, tag)))
 out_p = os.path.join(ROOT, "profiles", "%s_pmc_summary.json" % rnd)
-bench_line = line(os.path.join(src, "bench_default.log"))
+try:
+    commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "HEAD"], text=True, stderr=subprocess.DEVNULL).strip()
+except Exception:
+    commit = "(taken on the GPU box from a snapshot without .git; see `git log` of this file)"
+import ctypes
+_lib = ctypes.CDLL(os.path.join(ROOT, "exaadmm.jl_amd", "libexaadmm_hip.so"))
+_lib.exaadmm_version.restype = ctypes.c_char_p
+library_version = _lib.exaadmm_version().decode()      # (the build the passes were taken from: the batch runs from this tree)
 out = {"_note": "rocprofv3 --kernel-trace --pmc <group> passes (scripts/collect_pmc.sh, one counter group per run), per-launch averages over the timed "
                 "region of bench.py --repeats 1 (scripts/summarize_pmc.py).  FETCH_SIZE / WRITE_SIZE in KB; FETCH_SIZE counts requests in units of 64 B "
                 "(profiles/r03_fetch_size_counter_check.txt): x 2 for the plane-contiguous readers, both bounds for the bus kernel.  SQ_* cycle counters in "
                 "quad-cycles summed over waves; shader clock = GRBM_GUI_ACTIVE / 8 / kernel time.",
-       "build": build, "library_version": bench_line["roofline"]["library_version"],
-       "commit": subprocess.check_output(["git", "-C", ROOT, "rev-parse", "HEAD"], text=True).strip()}
+       "build": build, "library_version": library_version,
+       "commit": commit}
 SIZES = {"case13659pegase": (4092, 20467), "case1354pegase": (260, 1991), "case_ACTIVSg70k": (10390, 88207), "synthetic1M": (50000, 1000000)}
 for case, steps in (("case13659pegase", 200), ("case1354pegase", 200), ("case_ACTIVSg70k", 100), ("synthetic1M", 50)):
     d, wl = "pmc_" + case, "synthetic-%s-sized" % case

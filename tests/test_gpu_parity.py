@@ -418,6 +418,29 @@ def test_pushed_bus_records_leave_every_bit_where_the_gathers_leave_it(pkg, syn,
     assert np.isfinite(outs[0][0]).all() and outs[0][0][0] > 0
 
 
+@pytest.mark.parametrize("case,rho,iters", [("case1354pegase", (1e1, 1e3), 30), ("case_ACTIVSg70k", (3e4, 3e5), 8)])
+def test_lane_group_bus_kernels_equal_the_reference_order_twin_bit_for_bit(pkg, syn, case, rho, iters):
+    """k_bus (one lane per bus, the reference's loops and summation order written out; EXAADMM_BUS_KERNEL=lane, which also selects the plain
+    four-launch loop) against the default path (eight lanes per bus, the leader adding neutral-element-padded terms; records pushed by the
+    branch launch; two-launch loop): u, v, z, l and the line-limit multipliers bit for bit -- also on the 88 207-branch grid whose hub buses
+    take several chunks."""
+    g = syn.sized_like(case, seed=0)
+    outs = []
+    for lane in (False, True):
+        if lane:
+            os.environ["EXAADMM_BUS_KERNEL"] = "lane"
+        try:
+            env = pkg.AdmmEnv("syn", rho[0], rho[1], verbose=0, grid=g)
+            mod = pkg.ModelAcopf(env)
+        finally:
+            os.environ.pop("EXAADMM_BUS_KERNEL", None)
+        mod.run_fixed(iters, first_major_iter=1, beta=1e3)
+        outs.append((mod.solution.u_curr, mod.solution.v_curr, mod.solution.z_curr, mod.solution.l_curr, mod.membuf))
+        mod.close()
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)
+
+
 def test_two_processes_sharing_the_gpu_reproduce_single_handle():
     """The N>1 code path with real processes: two ranks (torch.distributed.run, gloo with host-staged
     collectives, because RCCL refuses two ranks on one device) each drive their partition through

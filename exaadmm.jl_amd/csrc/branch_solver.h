@@ -18,6 +18,7 @@
 // the 3 variables (vi, vj, th) from 6 weighted rank-1 terms plus the curvature
 // of the flows, and expanded to (vi, vj, ti, tj) with d/dtj = -d/dti.
 #pragma once
+#include <cstring>
 #include "tron_device.h"
 
 namespace exa {
@@ -92,11 +93,18 @@ struct MuPowTable {
     double pow10[8], pow01[8], pow09[8];
 };
 
+// The entry is found from mu's binary exponent -- 10^1 .. 10^8 have the exponents 3, 6, 9, 13, 16, 19, 23, 26, so
+// k = (3 e + 9) / 10 -- and confirmed by comparing pow10[k - 1] with mu: one indexed read instead of a chain of eight
+// comparisons.  (On the device the chain kept all 24 table values in SGPRs, which spilled: 64 v_readlane / compare pairs in
+// the branch kernel.  The kernel passes a copy of the table in LDS: an indexed read there costs a lone wavefront ~100 clocks.)
 EXA_HD double mu_pow(const MuPowTable& t, double mu, bool nine)
 {
-    EXA_UNROLL
-    for (int k = 0; k < 8; k++)
-        if (mu == t.pow10[k]) return nine ? t.pow09[k] : t.pow01[k];
+    long long bits;
+    memcpy(&bits, &mu, sizeof(bits));
+    const int e = (int)((bits >> 52) & 0x7ff) - 1023;
+    int k = (3 * e + 9) / 10;
+    k = k < 1 ? 1 : (k > 8 ? 8 : k);
+    if (mu == t.pow10[k - 1]) return nine ? t.pow09[k - 1] : t.pow01[k - 1];
     return pow(mu, nine ? 0.9 : 0.1);
 }
 
@@ -116,9 +124,29 @@ struct FlowTrig {
 // sin / cos of the angle difference: the only transcendental of the branch model.  Evaluated once
 // per point (together with the flows) and carried with the point: g and H at an accepted trial
 // point reuse the values its objective evaluation produced.
+// Fast device build: angle differences of a power grid are small -- for |t| <= pi/4 the two kernel polynomials of every libm
+// (the minimax coefficients of fdlibm's __kernel_sin / __kernel_cos, < 1 ulp on that interval) need no argument reduction:
+// ~20 multiply-adds instead of the library call (441 clocks for a lone wavefront, scripts/microbench/valu_latency.hip).
+// Larger angles take the library call.
 EXA_HD void angle_sincos(const double (&x)[6], double& sn, double& cs)
 {
-    sincos(x[2] - x[3], &sn, &cs);
+    const double t = x[2] - x[3];
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(EXA_EXACT_ORACLE_ARITH)
+    if (fabs(t) <= 0.78539816339744830962) {
+#pragma clang fp contract(off)   // every instantiation of the kernels must round this the same way: the fusions are written out
+        const double z = t * t;
+        const double rs = fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08), 2.75573137070700676789e-06),
+                                     -1.98412698298579493134e-04), 8.33333333332248946124e-03);
+        sn = fma(z * t, fma(z, rs, -1.66666666666666324348e-01), t);
+        const double rc = z * fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07),
+                                                  2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+        const double hz = 0.5 * z;
+        const double w = 1.0 - hz;
+        cs = w + fma(z, rc, (1.0 - w) - hz);
+        return;
+    }
+#endif
+    sincos(t, &sn, &cs);
 }
 
 template <class D>

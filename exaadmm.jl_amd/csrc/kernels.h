@@ -296,6 +296,10 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_branch_t(const Dev* __restrict_
             generator_update(d, baseMVA, gi);
         return;
     }
+    // mu^0.1, mu^0.9 table: the lanes index it (branch_solver.h mu_pow).  Filled before any lane leaves (the last block
+    // of the step-wise launch has fewer than 64 lanes).
+    __shared__ MuPowTable pw_lds;
+    if (threadIdx.x < 24) reinterpret_cast<double*>(&pw_lds)[threadIdx.x] = reinterpret_cast<const double*>(&c_mupow)[threadIdx.x];
     const int slot = blockIdx.x * BR_BLOCK + threadIdx.x;
     const bool lane_on = slot < d.L;
     if (!ZL && !lane_on) return;
@@ -396,7 +400,7 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_branch_t(const Dev* __restrict_
     unsigned long long t_loaded;
     asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_loaded) : "v"(x[0]) : "memory");
 #endif
-    branch_solve(bd, o, c_mupow, x, xl, xu, A, L, phi, st, park_lds + threadIdx.x);
+    branch_solve(bd, o, pw_lds, x, xl, xu, A, L, phi, st, park_lds + threadIdx.x);
 #if defined(EXA_PROFILE_PHASES)
     const unsigned long long t_solved = __builtin_amdgcn_s_memtime();
 #endif

@@ -62,6 +62,25 @@
 
 namespace exa {
 
+// a / b in the TRON algebra (break points, trust-region root, CG step lengths, ratio-test curvature).  Exact build and host:
+// the IEEE quotient.  Fast device build: v_rcp_f64 (relative error ~2^-23), one Newton step on the reciprocal, the quotient,
+// one correction step on the quotient -- 6 dependent instructions, within an ulp of a / b for operands in the normal range --
+// instead of the compiler's correctly rounded sequence (2 scalings, reciprocal, two Newton steps, quotient, correction,
+// fix-up: 14 instructions, 78 clocks for a lone wavefront: scripts/microbench/valu_latency.hip).  A solver trip makes ~25
+// divisions.  b = 0 or non-finite gives NaN where IEEE gives an infinity or zero: every call site discards such a quotient
+// by selection (see there).
+EXA_HD double exa_div(double a, double b)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(EXA_EXACT_ORACLE_ARITH)
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(fma(-b, r, 1.0), r, r);
+    const double q = a * r;
+    return fma(fma(-b, q, a), r, q);
+#else
+    return a / b;
+#endif
+}
+
 // task / termination codes (numbering of acopf_tron_linelimit_kernel.jl)
 enum { TRON_RUN = 0, TRON_CONV = 4, TRON_WARN = 10, TRON_MAXMINOR = 20, TRON_MAXFEVAL = 21 };
 
@@ -161,7 +180,7 @@ EXA_HD void breakpt(const double (&dl)[N], const double (&du)[N], const double (
         const bool up = (du[i] > 0.0) && (w[i] > 0.0);
         const bool dn = (dl[i] < 0.0) && (w[i] < 0.0);
         const bool mv = up || dn;
-        const double brpt = (up ? du[i] : dl[i]) / w[i];
+        const double brpt = exa_div(up ? du[i] : dl[i], w[i]);   // (w = 0: mv is false, the quotient is never selected)
         const double lo = any ? fmin(brpt, bmin) : brpt;
         const double hi = any ? fmax(brpt, bmax) : brpt;
         bmin = mv ? lo : bmin;
@@ -501,7 +520,7 @@ EXA_HD double trqsol(const double (&x)[N], const double (&p)[N], double delta)
     // ONE division on selected operands instead of one division in each of two divergent branches (same operands, same
     // quotient): a branch region costs a lone wavefront ~33 clocks of VALU -> SALU -> VALU hand-over before it does anything
     const bool pos = (ptx > 0.0);
-    const double q = (pos ? (dsq - xtx) : (rad - ptx)) / (pos ? (ptx + rad) : ptp);
+    const double q = exa_div(pos ? (dsq - xtx) : (rad - ptx), pos ? (ptx + rad) : ptp);   // (p = 0 and ptx <= 0: rad = 0, q unused)
     return (pos || rad > 0.0) ? q : 0.0;
 }
 
@@ -560,7 +579,7 @@ EXA_BIG int trpcg_masked(unsigned fr, const MA& A, const double (&gf)[N], double
         trsol_n<N>(L, id, q);
 
         double ptq = dot<N>(p, q);
-        const double rq = rho / ptq;                    // (formed outside any branch, see trqsol; unused when ptq <= 0)
+        const double rq = exa_div(rho, ptq);            // (formed outside any branch, see trqsol; unused when ptq <= 0)
         double alpha = (ptq > 0.0) ? rq : 0.0;
         double sigma = trqsol<N>(w, p, delta);
 
@@ -608,7 +627,7 @@ EXA_BIG int trpcg_masked(unsigned fr, const MA& A, const double (&gf)[N], double
             return 2;
         }
 #endif
-        double beta = rtr / rho;
+        double beta = exa_div(rtr, rho);   // (rho > stol2 >= 0 here: the loop has returned otherwise)
         EXA_UNROLL
         for (int i = 0; i < N; i++) p[i] = EXA_FMA(beta, p[i], r[i]);
         rho = rtr;
@@ -796,7 +815,7 @@ EXA_HD bool tron_evaluate(TronState<N>& st, double ftrial, double (&x)[N], const
 
     const double g0 = st.gts;   // = dot(g, s): the products commute, the sum runs in the same order
     const double curv = f - fc - g0;
-    const double alpha = (curv <= 0.0) ? sigma3 : fmax(sigma1, -0.5 * (g0 / curv));   // (division outside any branch: see trqsol)
+    const double alpha = (curv <= 0.0) ? sigma3 : fmax(sigma1, -0.5 * exa_div(g0, curv));   // (division outside any branch: see trqsol)
 
     const double prered = st.prered;
     {

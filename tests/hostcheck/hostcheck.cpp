@@ -57,6 +57,22 @@ extern "C" double hostcheck_f(const double* x_, const double* param, const doubl
     return branch_f(d, x, phi, sc);
 }
 
+// mu^0.1 (nine = 0) / mu^0.9 (nine = 1) through the table look-up of the lane code; *from_table = 1 when the table entry was used
+extern "C" double hostcheck_mu_pow(double mu, int nine, int* from_table)
+{
+    MuPowTable pw;
+    double p = 1.0;
+    for (int k = 0; k < 8; k++) {
+        p *= 10.0;
+        pw.pow10[k] = p;
+        pw.pow01[k] = -(double)(k + 1);          // markers: a table hit is recognisable
+        pw.pow09[k] = -(double)(k + 1) - 100.0;
+    }
+    const double r = mu_pow(pw, mu, nine != 0);
+    *from_table = r < 0.0;
+    return r;
+}
+
 // same contract as oracle_branch_solve
 extern "C" int hostcheck_branch_solve(double* x_, const double* xl_, const double* xu_, double* param,
                                       const double* Y, double scale, int max_auglag, double mu_max,

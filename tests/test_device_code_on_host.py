@@ -256,3 +256,24 @@ def test_exact_arith_build_is_bitwise_the_oracle_on_ramp_subproblems(hc_exact, o
         hc_exact.hostcheck_genramp_solve(_p(xh), _p(xl), _p(xu), _p(ph), c2, c1, c0, M, 50, 1e8, C.byref(ith), C.byref(mih))
         assert (ith.value, mih.value) == (ito.value, mio.value)
         assert np.array_equal(xh, xo) and np.array_equal(ph, po)
+
+
+def test_penalty_power_lookup_by_exponent(hc):
+    """mu_pow (branch_solver.h): the table entry of mu = 10^k, k = 1..8, is found from mu's binary exponent and confirmed by
+    comparison; every other mu -- neighbours of the powers of ten in the same binade, other binades, 10^0, 10^9, tiny, huge,
+    zero, infinities -- must take pow()."""
+    hc.hostcheck_mu_pow.restype = C.c_double
+    hc.hostcheck_mu_pow.argtypes = [C.c_double, C.c_int, ip]
+    hit = C.c_int()
+    for k in range(1, 9):
+        mu = float(10 ** k)
+        assert hc.hostcheck_mu_pow(mu, 0, C.byref(hit)) == -float(k) and hit.value == 1
+        assert hc.hostcheck_mu_pow(mu, 1, C.byref(hit)) == -float(k) - 100.0 and hit.value == 1
+        for other in (np.nextafter(mu, 0.0), np.nextafter(mu, np.inf), mu * 1.5, mu * 0.75, 2.0 ** np.floor(np.log2(mu))):
+            for nine in (0, 1):
+                r = hc.hostcheck_mu_pow(float(other), nine, C.byref(hit))
+                assert hit.value == 0 and r == float(other) ** (0.9 if nine else 0.1)
+    for other in (1.0, 1e9, 1e-3, 5e-324, 1e300, 0.0, np.inf, 3.0, 2.0 ** 27, 2.0 ** 2):
+        for nine in (0, 1):
+            r = hc.hostcheck_mu_pow(float(other), nine, C.byref(hit))
+            assert hit.value == 0 and r == float(other) ** (0.9 if nine else 0.1)

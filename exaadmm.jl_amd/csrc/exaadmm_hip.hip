@@ -1045,9 +1045,9 @@ static void launch_branch(exaadmm_handle* h, int major_iter, const Ctrl* c, bool
     const int nb = branch_blocks(h);
     const int ng = with_generators ? gen_blocks(h) : 0;
     if (h->T > 1)
-        hipLaunchKernelGGL((k_branch_t<true>), dim3(nb + ng), dim3(BR_BLOCK), 0, h->stream, h->d_dev, h->bo, h->par.scale, major_iter, const_cast<Ctrl*>(c), ng, h->baseMVA, -1);
+        hipLaunchKernelGGL((k_branch_t<true>), dim3(nb + ng), dim3(BR_BLOCK), 0, h->stream, h->d_dev, h->bo, h->par.scale, major_iter, const_cast<Ctrl*>(c), ng, -1, h->baseMVA);
     else
-        hipLaunchKernelGGL((k_branch_t<false>), dim3(nb + ng), dim3(BR_BLOCK), 0, h->stream, h->d_dev, h->bo, h->par.scale, major_iter, const_cast<Ctrl*>(c), ng, h->baseMVA, -1);
+        hipLaunchKernelGGL((k_branch_t<false>), dim3(nb + ng), dim3(BR_BLOCK), 0, h->stream, h->d_dev, h->bo, h->par.scale, major_iter, const_cast<Ctrl*>(c), ng, -1, h->baseMVA);
 }
 static void launch_bus(exaadmm_handle* h, const Ctrl* c)
 {
@@ -1055,7 +1055,8 @@ static void launch_bus(exaadmm_handle* h, const Ctrl* c)
         hipLaunchKernelGGL(k_bus, grid_for(h->B, 64), dim3(64), 0, h->stream, h->d, h->baseMVA, c);
     else {
         flush_bus_const(h);
-        hipLaunchKernelGGL((k_bus_group_t<false>), grid_for(h->B, BUS_BLOCK / BUS_W), dim3(BUS_BLOCK), 0, h->stream, h->d, h->baseMVA, c, (Ctrl*)nullptr);
+        hipLaunchKernelGGL((k_bus_group_t<false>), grid_for(h->B, BUS_BLOCK / BUS_W), dim3(BUS_BLOCK), 0, h->stream, c, (Ctrl*)nullptr, (const double*)h->d.rec,
+                           h->d.EndCount, h->d.SlotCode, h->d.busc, h->d.B, h->d, h->baseMVA);
     }
 }
 static void launch_fused_zl(exaadmm_handle* h, double beta, const Ctrl* c)
@@ -1397,13 +1398,15 @@ static int enqueue_iteration_spec(exaadmm_handle* h, Ctrl* c, int j, bool sample
     if (sample) (void)hipEventRecord(h->tev[0], h->stream);
     if (bev) (void)hipEventRecord(bev[0], h->stream);
     hipLaunchKernelGGL((k_branch_t<false, true>), dim3(nb + ng), dim3(BR_BLOCK), 0, h->stream, h->d_dspec[par], h->bo, h->par.scale, 0, c,
-                       ng, h->baseMVA, j);
+                       ng, j, h->baseMVA);
     if (bev) (void)hipEventRecord(bev[1], h->stream);
     if (sample) (void)hipEventRecord(h->tev[1], h->stream);
     if (dv.rec != nullptr)   // the branch launch has pushed the bus records
-        hipLaunchKernelGGL((k_bus_group_t<true>), dim3(grid_for(h->B, BUS_BLOCK / BUS_W).x + 1), dim3(BUS_BLOCK), 0, h->stream, dv, h->baseMVA, c, c);
+        hipLaunchKernelGGL((k_bus_group_t<true>), dim3(grid_for(h->B, BUS_BLOCK / BUS_W).x + 1), dim3(BUS_BLOCK), 0, h->stream, (const Ctrl*)c, c, (const double*)dv.rec, dv.EndCount, dv.SlotCode,
+                           dv.busc, dv.B, dv, h->baseMVA);
     else
-        hipLaunchKernelGGL((k_bus_group_t<false>), dim3(grid_for(h->B, BUS_BLOCK / BUS_W).x + 1), dim3(BUS_BLOCK), 0, h->stream, dv, h->baseMVA, c, c);
+        hipLaunchKernelGGL((k_bus_group_t<false>), dim3(grid_for(h->B, BUS_BLOCK / BUS_W).x + 1), dim3(BUS_BLOCK), 0, h->stream, (const Ctrl*)c, c, (const double*)dv.rec, dv.EndCount, dv.SlotCode,
+                           dv.busc, dv.B, dv, h->baseMVA);
     if (dist_has_peers(h)) {
         int rc = dist_exchange(h, dv, true, c, nullptr, 1);
         if (rc) return rc;

@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(64) k_gen_ramp(Dev d, BranchOptions o, double 
 // both owners): branches at or past d.Lown run the same prologue and solve, but add nothing to the residual sums.
 template <bool MP, bool ZL = false>
 __global__ void __launch_bounds__(BR_BLOCK, 1) k_branch_t(const Dev* __restrict__ dp, BranchOptions o, double scale, int major_iter, Ctrl* ctrl,
-                                                           int gen_blocks, double baseMVA, int spec_j)
+                                                           int gen_blocks, int spec_j, double baseMVA)   // (all inside the 16 preloaded SGPRs)
 {
 #if defined(EXA_PROFILE_PHASES)
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();   // first instruction of the wave
@@ -728,8 +728,13 @@ __device__ __forceinline__ void bus_end_index(const Dev& d, int code, int (&idx)
 // needs into d.rec at the slot this lane owns (see Dev::rec) -- the launch starts with ONE round of loads whose addresses
 // all follow from the thread id, instead of an index load followed by 16 dependent gathers per lane spread over 16
 // cache lines; same terms, same order, same bits.
+// Parameter order: what a wavefront needs for its FIRST loads -- loop control, record / slot tables, the bus constants --
+// leads, inside the 16 SGPRs the firmware preloads at wavefront launch (Makefile KERNARG_PRELOAD); the Dev block by value
+// follows and is read from the kernarg segment while those loads are in flight.  hot_* repeat d.rec, d.EndCount, d.SlotCode, d.busc.
 template <bool REC>
-__global__ void __launch_bounds__(BUS_BLOCK) k_bus_group_t(Dev d, double baseMVA, const Ctrl* ctrl, Ctrl* red)
+__global__ void __launch_bounds__(BUS_BLOCK) k_bus_group_t(const Ctrl* ctrl, Ctrl* red, const double* __restrict__ hot_rec,
+                                                            const int* __restrict__ hot_count, const int* __restrict__ hot_slot,
+                                                            const double* __restrict__ hot_busc, int hot_B, Dev d, double baseMVA)
 {
     // Terms a lane hands to its group leader.  The leader adds them in the reference's order -- generators, then -Pd, then the
     // branch ends -- WITHOUT looking at what kind of component a slot holds: a slot contributes a neutral element to the
@@ -768,15 +773,15 @@ __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group_t(Dev d, double baseMVA
 #if defined(EXA_PROFILE_PHASES)
     unsigned long long tb0 = __builtin_amdgcn_s_memtime(), tb1 = 0, tb2 = 0, tb3 = 0, tb4 = 0;
 #endif
-    if (I >= d.B) return;   // whole groups leave together
-    const int n = d.EndCount[I];
-    const int code0 = d.SlotCode[I * BUS_W + lane];
+    if (I >= hot_B) return;   // whole groups leave together
+    const int n = hot_count[I];
+    const int code0 = hot_slot[I * BUS_W + lane];
     const int e0 = (n > BUS_W) ? d.EndStart[I] : 0;   // (only the rare large buses need the CSR offset)
     // REC: the first chunk's records, fetched with everything else (a lane past the bus's component count reads its own,
     // unused, slot: no branch in front of the loads)
     double r[BUS_REC];
     if (REC) {
-        const double* q = d.rec + 8 * (size_t)(I * BUS_W + lane);
+        const double* q = hot_rec + 8 * (size_t)(I * BUS_W + lane);
 #pragma unroll
         for (int k = 0; k < 8; k++) r[k] = q[k];
     }
@@ -790,8 +795,8 @@ __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group_t(Dev d, double baseMVA
     const double pd = d.Pd[I] / baseMVA, qd = d.Qd[I] / baseMVA;
     const double ysr = d.YshR[I], ysi = d.YshI[I];
     // the bus's rho-only constants (k_bus_const), fetched with everything else ahead of the wavefront fences
-    const double A11 = d.busc[BUSC_A11 * d.B + I], A12 = d.busc[BUSC_A12 * d.B + I], r21 = d.busc[BUSC_R21 * d.B + I];
-    const double piv = d.busc[BUSC_PIV * d.B + I], rhosum_w = d.busc[BUSC_RW * d.B + I], rhosum_t = d.busc[BUSC_RT * d.B + I];
+    const double A11 = hot_busc[BUSC_A11 * hot_B + I], A12 = hot_busc[BUSC_A12 * hot_B + I], r21 = hot_busc[BUSC_R21 * hot_B + I];
+    const double piv = hot_busc[BUSC_PIV * hot_B + I], rhosum_w = hot_busc[BUSC_RW * hot_B + I], rhosum_t = hot_busc[BUSC_RT * hot_B + I];
 
     int idx[4], kind = -1, code = 0;
     for (int c0 = 0; c0 < n; c0 += BUS_W) {

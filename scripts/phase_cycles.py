@@ -10,9 +10,13 @@ pkg = exaadmm_loader.load_package()
 syn = exaadmm_loader.load_submodule("synthetic")
 L = pkg.library()
 L.exaadmm_debug_phase_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int64]
-g = syn.sized_like("case13659pegase", seed=0)
-env = pkg.AdmmEnv("syn", 5e1, 5e3, verbose=0, grid=g)
+case = sys.argv[2] if len(sys.argv) > 2 else "case13659pegase"   # usage: phase_cycles.py [warm iterations] [case]
+rho, scale = {"case_ACTIVSg70k": ((3e4, 3e5), 1e-5)}.get(case, ((5e1, 5e3), 1e-4))
+g = syn.sized_like(case, seed=0)
+env = pkg.AdmmEnv("syn", rho[0], rho[1], verbose=0, grid=g)
 mod = pkg.ModelAcopf(env)
+env.params.scale = scale
+mod.sync_params()
 nwarm = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 mod.run_fixed(nwarm, first_major_iter=1, beta=1e3)
 for rep in range(2):

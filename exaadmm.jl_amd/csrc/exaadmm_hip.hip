@@ -734,6 +734,7 @@ extern "C" int exaadmm_set_load(exaadmm_handle* h, const double* Pd, const doubl
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(const_cast<double*>(h->d.Pd), Pd, (size_t)h->B * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(const_cast<double*>(h->d.Qd), Qd, (size_t)h->B * sizeof(double), hipMemcpyHostToDevice));
+    h->busc_dirty = true;   // (the per-unit load sits among the bus constants)
     return EXAADMM_OK;
 }
 
@@ -1030,11 +1031,12 @@ static void flush_dev(exaadmm_handle* h)
         h->dev_dirty = false;
     }
 }
-// rho-only constants of the bus update: recomputed after rho changed (never inside a stream capture: callers flush first)
+// per-bus constants of the bus update (rho sums, pivots; per-unit load and shunt): recomputed after rho or the load changed
+// (never inside a stream capture: callers flush first)
 static void flush_bus_const(exaadmm_handle* h)
 {
     if (h->busc_dirty) {
-        hipLaunchKernelGGL(k_bus_const, grid_for(h->B, 256), dim3(256), 0, h->stream, h->d, h->d_busc);
+        hipLaunchKernelGGL(k_bus_const, grid_for(h->B, 256), dim3(256), 0, h->stream, h->d, h->d_busc, h->baseMVA);
         h->busc_dirty = false;
     }
 }

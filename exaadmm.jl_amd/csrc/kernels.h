@@ -318,6 +318,7 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_branch_t(const Dev* __restrict_
     double ub[8], bnd[8];
     BranchData bd;
     double rate_0;
+    int rec_from = -1, rec_to = -1;
     if (ZL) {
         // Every load of the prologue first, every store after them.  As far as the compiler knows the planes may alias,
         // so a store between two loads is a full memory round trip: with the z/l pass written element by element
@@ -340,6 +341,10 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_branch_t(const Dev* __restrict_
         bd.ls2 = (d.ls2_in ? d.ls2_in : d.ls2)[b];
         const double mu_0 = (d.mu_in ? d.mu_in : d.mu)[b];
         rate_0 = d.rateA[b];
+        if (d.rec != nullptr) {   // where this branch's two bus records go: asked for now, not behind the solve (a memory round
+            rec_from = d.rec_br[2 * b];       // trip in front of the stores of the launch's slowest wavefront)
+            rec_to = d.rec_br[2 * b + 1];
+        }
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             if (do_zl && lane_on) {
@@ -421,7 +426,7 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_branch_t(const Dev* __restrict_
 #pragma unroll
         for (int k = 0; k < 8; k++) zz[k] = park_lds[(32 + k) * BR_BLOCK + threadIdx.x];
         const double un[8] = {phi[0], phi[1], phi[2], phi[3], x[0] * x[0], x[1] * x[1], x[2], x[3]};
-        const int rf = d.rec_br[2 * b], rt = d.rec_br[2 * b + 1];
+        const int rf = rec_from, rt = rec_to;
         if (rf >= 0) {
             double* q = d.rec + 8 * (size_t)rf;
             q[0] = un[0] + zz[0];  q[1] = bd.lam_[0];  q[2] = bd.rho_[0];
@@ -598,7 +603,10 @@ constexpr int BUS_REC = 16;  // doubles per record: (u,z,l,rho) x (p,q,w,theta) 
 enum { END_GEN = 0, END_FROM = 1, END_TO = 2 };
 constexpr int END_CUT = 1 << 30;        // component code flag: the branch is shared with a peer partition (its v entries go into the halo message)
 constexpr int END_INDEX = 0x0fffffff;
-constexpr int BUSC_A11 = 0, BUSC_A12 = 1, BUSC_R21 = 2, BUSC_PIV = 3, BUSC_RW = 4, BUSC_RT = 5, BUSC_N = 6;   // planes of Dev::busc
+// planes of Dev::busc: the rho / shunt constants, then the per-unit load and the shunt themselves (so that everything a bus
+// lane needs beside the records comes from ONE array whose address is among the preloaded kernel arguments)
+constexpr int BUSC_A11 = 0, BUSC_A12 = 1, BUSC_R21 = 2, BUSC_PIV = 3, BUSC_RW = 4, BUSC_RT = 5, BUSC_PD = 6, BUSC_QD = 7, BUSC_YSR = 8,
+              BUSC_YSI = 9, BUSC_N = 10;
 
 __device__ __forceinline__ void bus_load_end(const Dev& d, int code, double (&r)[BUS_REC], int (&idx)[4])
 {
@@ -640,7 +648,7 @@ __device__ __forceinline__ void bus_load_end(const Dev& d, int code, double (&r)
 
 // The rho-only part of the bus update, one lane per bus, in the order k_bus adds things up: rerun whenever rho changes
 // (upload of rho, init_solution).  busc: BUSC_N planes of B doubles.
-__global__ void k_bus_const(Dev d, double* busc)
+__global__ void k_bus_const(Dev d, double* busc, double baseMVA)
 {
     const int I = blockIdx.x * blockDim.x + threadIdx.x;
     if (I >= d.B) return;
@@ -682,6 +690,10 @@ __global__ void k_bus_const(Dev d, double* busc)
     busc[BUSC_PIV * d.B + I] = A22 - r21 * A12;
     busc[BUSC_RW * d.B + I] = rhosum_w;
     busc[BUSC_RT * d.B + I] = rhosum_t;
+    busc[BUSC_PD * d.B + I] = d.Pd[I] / baseMVA;   // (the quotients the bus kernels form: same operands, same bits)
+    busc[BUSC_QD * d.B + I] = d.Qd[I] / baseMVA;
+    busc[BUSC_YSR * d.B + I] = ysr;
+    busc[BUSC_YSI * d.B + I] = ysi;
 }
 
 __device__ __forceinline__ void block_reduce4(double (&s)[4]);   // (defined with the elementwise kernels below)
@@ -745,7 +757,8 @@ __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group_t(const Ctrl* ctrl, Ctr
     constexpr int T_W = 0, T_T = 1, T_PG = 2, T_QG = 3, T_PE = 4, T_QE = 5, NTERM = 6;
     __shared__ double term[BUS_BLOCK / BUS_W][NTERM][BUS_W];
     __shared__ double res[BUS_BLOCK / BUS_W][4];
-    if (red != nullptr && blockIdx.x == gridDim.x - 1) {   // the reduction block (whole block takes this path)
+    // (the reduction block is block 0: dispatched first, it runs beside the bus blocks instead of behind the last of them)
+    if (red != nullptr && blockIdx.x == 0) {   // the reduction block (whole block takes this path)
         if (red->done || !red->pending) return;
         double s4[4] = {0.0, 0.0, 0.0, 0.0};
         for (int bq = threadIdx.x; bq < d.npartials_br; bq += BUS_BLOCK) {
@@ -769,7 +782,8 @@ __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group_t(const Ctrl* ctrl, Ctr
     }
     if (loop_done(ctrl)) return;
     const int grp = threadIdx.x / BUS_W, lane = threadIdx.x % BUS_W;
-    const int I = blockIdx.x * (BUS_BLOCK / BUS_W) + grp;
+    const int bus_block = (int)blockIdx.x - (red != nullptr ? 1 : 0);
+    const int I = bus_block * (BUS_BLOCK / BUS_W) + grp;
 #if defined(EXA_PROFILE_PHASES)
     unsigned long long tb0 = __builtin_amdgcn_s_memtime(), tb1 = 0, tb2 = 0, tb3 = 0, tb4 = 0;
 #endif
@@ -792,8 +806,8 @@ __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group_t(const Ctrl* ctrl, Ctr
     // leader state (meaningful in lane 0 only)
     double common_wi = 0.0, common_ti = 0.0, rhs1 = 0.0, rhs2 = 0.0;
     bool load_subtracted = false;
-    const double pd = d.Pd[I] / baseMVA, qd = d.Qd[I] / baseMVA;
-    const double ysr = d.YshR[I], ysi = d.YshI[I];
+    const double pd = hot_busc[BUSC_PD * hot_B + I], qd = hot_busc[BUSC_QD * hot_B + I];
+    const double ysr = hot_busc[BUSC_YSR * hot_B + I], ysi = hot_busc[BUSC_YSI * hot_B + I];
     // the bus's rho-only constants (k_bus_const), fetched with everything else ahead of the wavefront fences
     const double A11 = hot_busc[BUSC_A11 * hot_B + I], A12 = hot_busc[BUSC_A12 * hot_B + I], r21 = hot_busc[BUSC_R21 * hot_B + I];
     const double piv = hot_busc[BUSC_PIV * hot_B + I], rhosum_w = hot_busc[BUSC_RW * hot_B + I], rhosum_t = hot_busc[BUSC_RT * hot_B + I];
@@ -944,8 +958,8 @@ __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group_t(const Ctrl* ctrl, Ctr
     }
 #if defined(EXA_PROFILE_PHASES)
     asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb4) : : "memory");
-    if (d.st_tl && threadIdx.x == 0 && blockIdx.x < 256) {   // per block: entry, CSR landed, gathers landed, leader done, stores landed
-        unsigned long long* q = d.st_tl + (size_t)blockIdx.x * 8;
+    if (d.st_tl && threadIdx.x == 0 && bus_block < 256) {   // per block: entry, CSR landed, gathers landed, leader done, stores landed
+        unsigned long long* q = d.st_tl + (size_t)bus_block * 8;
         q[0] = tb0; q[1] = tb1; q[2] = tb2; q[3] = tb3; q[4] = tb4;
     }
 #endif

@@ -123,6 +123,8 @@ def test_argument_errors_are_reported_not_thrown(pkg):
     # the code-generation flags travel in the version string: the branch kernel is only known to compile
     # correctly with the basic SGPR allocator and without FP contraction (csrc/Makefile pins both)
     assert "-mllvm -sgpr-regalloc=basic" in ver and "-ffp-contract=off" in ver, ver
+    # (the measured build also preloads the kernel arguments into SGPRs; kernels keep an entry for firmware that does not)
+    assert "-amdgpu-kernarg-preload-count=16" in ver and "src:" in ver, ver
     # multi-period entry points: same convention
     assert L.exaadmm_mp_create(C.byref(g), C.byref(p), 3, None, None, 0.02, 0, C.byref(h)) == -1
     assert b"null argument" in L.exaadmm_last_error()

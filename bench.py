@@ -25,7 +25,8 @@ solve_acopf with the README settings (outer 20 x inner 1000, early breaks on), w
 solve (whole solve when it fits 30 s, else its first iterations -- said in `cpu_port.sample`).  `value` stays the
 fixed-count figure the K / W contract defines.
 
-Prints ONE JSON line (rank 0).  `roofline` refers to the dominant kernel (k_branch):
+Prints ONE JSON line (rank 0).  `roofline` refers to the dominant kernel (k_resident, the resident loop's one launch per
+batch of iterations, where every wavefront of the grid fits the chip; k_branch of the two-launch loop otherwise):
 achieved = algorithmic bytes per launch / mean launch duration from HIP events on the launch
 stream.  `cpu_baseline` = the C oracle (serial port of the reference CPU path) timed on a
 bounded sample of the same workload on this box's host cores.
@@ -275,12 +276,15 @@ def main():
     # cannot collect counters), summarised per workload in profiles/r03_pmc_summary.json together with the version string
     # of the library they were taken from.  An entry taken from other code than the library loaded now is refused.
     traffic = valu_busy = None
+    # which loop ran: 2 = the resident loop (ONE launch for the K steps of a region: branch solves, bus updates by the last lane
+    # to arrive, residual sums and stop test inside; the figures below are per ITERATION of that launch), 1 = two launches per iteration
+    resident = (T == 1 and hasattr(mod, "loop_kind") and mod.loop_kind() == 2)
     lib_version = pkg.library().exaadmm_version().decode()
     pmc_file = os.path.join("profiles", "r03_pmc_summary.json")
     traffic_source = "none: %s has no entry for this workload" % pmc_file
     try:
         pmc = json.load(open(os.path.join(ROOT, pmc_file)))
-        kb = pmc.get(workload, {}).get("k_branch", {})
+        kb = pmc.get(workload, {}).get("k_resident" if resident else "k_branch", {})
         if kb and pmc.get("library_version") != lib_version:
             traffic_source = "refused: %s was collected with %r, the loaded library is %r" % (pmc_file, pmc.get("library_version"), lib_version)
         elif kb:
@@ -296,6 +300,8 @@ def main():
         # iteration; of the latter only what the branch loads do not already bring counts: lz read + z, z_prev, l writes
         # = 32 B per vector element (64 B minimal + 8 B z_prev, minus the 40 B of shared reads)
         branch_bytes = 824.0 * L + 192.0 * G
+    if resident:
+        branch_bytes = float(BYTES_PER_ITER(G, L, B))   # the launch does whole iterations
     achieved = branch_bytes / (ms_branch * 1e-3) / 1e9
     out = {
         "metric": "ADMM inner iterations/sec", "value": its, "unit": "iterations/s",
@@ -313,10 +319,13 @@ def main():
                    "rho_va": params["rho_va"], "scale": params["scale"], "tight_factor": tight,
                    "mode": "fixed-count inner iterations, no early break", "parallelism": "1 GPU",
                    "state": "ADMM state after %d untimed preparation iterations from init_solution! (outer 1, beta %.0f)" % (args.prep, beta)},
-        "roofline": {"bound": "hbm", "kernel": "k_branch" + (" (with the fused z/l prologue)" if fused_zl else ""), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"bound": "hbm", "kernel": ("k_resident (one launch = the K iterations of a region; figures per iteration)" if resident else
+                                                "k_branch" + (" (with the fused z/l prologue)" if fused_zl else "")), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": branch_bytes, "kernel_ms": ms_branch,
-                     "kernel_ms_measured_over": "HIP events around each k_branch launch of the %d steps following the timed region" % args.steps,
+                     "kernel_ms_measured_over": ("HIP events around the k_resident launch of the %d steps following the timed region, divided by %d" % (args.steps, args.steps)) if resident
+                                                else "HIP events around each k_branch launch of the %d steps following the timed region" % args.steps,
+                     "loop": "resident (one launch per batch of iterations)" if resident else "two launches per iteration",
                      "iteration_bytes": BYTES_PER_ITER(G, L, B),
                      "iteration_frac": BYTES_PER_ITER(G, L, B) * its / 1e9 / HBM_PEAK_GBS,
                      # HBM is the wrong roof at the named sizes (state is Infinity-Cache resident, the kernel is the FP64

@@ -170,6 +170,7 @@ def library():
     L.exaadmm_download_branch_counters.argtypes = [H, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                                    C.POINTER(C.c_int32), C.c_int64]
     L.exaadmm_branch_kernel_occupancy.argtypes = [H, C.POINTER(C.c_int)]
+    L.exaadmm_loop_kind.argtypes = [H, C.POINTER(C.c_int)]
     L.exaadmm_run_inner.argtypes = [H, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int), c_double_p]
     L.exaadmm_solve_two_level.argtypes = [H, C.POINTER(Info)]
     L.exaadmm_run_fixed.argtypes = [H, C.c_int, C.c_int, C.c_double, c_double_p, c_double_p, c_double_p]
@@ -393,6 +394,12 @@ class ModelAcopf:
         _check(library().exaadmm_download_branch_counters(self._h, a.ctypes.data_as(ip), m.ctypes.data_as(ip),
                                                           t.ctypes.data_as(ip), self.nline), "branch counters")
         return a, m, t
+
+    def loop_kind(self):
+        """0 = four launches per iteration, 1 = two (speculative loop), 2 = resident loop (one launch per batch of iterations)"""
+        k = C.c_int()
+        _check(library().exaadmm_loop_kind(self._h, C.byref(k)), "exaadmm_loop_kind")
+        return k.value
 
     def branch_kernel_occupancy(self):
         """resident wavefronts per SIMD allowed by the branch kernel's register footprint"""

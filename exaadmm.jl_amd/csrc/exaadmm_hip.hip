@@ -117,6 +117,10 @@ struct exaadmm_handle {
     int *st_alt[3] = {nullptr, nullptr, nullptr};   // per-branch counters of the alternate set (auglag, minor, ticks)
     // (the z/l pass of an iteration rides in the NEXT branch launch's prologue: alternate v, per-block partial sums)
     double *v_alt = nullptr, *partials_br = nullptr;
+    // resident loop (kernels.h k_resident; experiment, EXAADMM_RESIDENT=1, fixed-count runs on one GPU)
+    bool resident_ok = false;
+    size_t nrec_slots = 0;
+    ResidentSync rsync = {};
     Dev dspec[2];
     Dev* d_dspec[2] = {nullptr, nullptr};
     int* h_base = nullptr;
@@ -565,6 +569,35 @@ extern "C" int exaadmm_create(const exaadmm_grid* g, const exaadmm_params* p, in
                 d.rec_br = drb;
                 d.rec_gen = drg;
                 d.rec = drec;
+                // resident loop: per branch (SoA index) its two buses and their counts, per generator its bus
+                std::vector<int> bb4(4 * (size_t)h->Lp, 0), gb2(2 * (size_t)h->Gp, 0);
+                bool all_local = true;
+                for (int I = 0; I < h->B; I++) {
+                    int ngen = 0;
+                    for (int k = 0; k < cnt[I]; k++) ngen += (((ec[(size_t)es[I] + k] >> 28) & 3) == END_GEN);
+                    const int packed = (ngen << 16) | cnt[I];
+                    if (cnt[I] > 0xffff) all_local = false;
+                    for (int k = 0; k < cnt[I]; k++) {
+                        const int code = ec[(size_t)es[I] + k], kind = (code >> 28) & 3, c = code & END_INDEX;
+                        if (kind == END_GEN) {
+                            gb2[2 * (size_t)c] = I;
+                            gb2[2 * (size_t)c + 1] = packed;
+                        } else {
+                            bb4[4 * (size_t)c + (kind == END_FROM ? 0 : 2)] = I;
+                            bb4[4 * (size_t)c + (kind == END_FROM ? 1 : 3)] = packed;
+                        }
+                    }
+                }
+                for (int b = 0; b < h->L; b++) all_local = all_local && h->cut_side[b] == 0;
+                int *dbb, *dgb;
+                TRY(dev_alloc(h, &dbb, bb4.size()));
+                TRY(dev_alloc(h, &dgb, gb2.size()));
+                TRY(upload_vec(h, dbb, bb4));
+                TRY(upload_vec(h, dgb, gb2));
+                d.br_bus4 = dbb;
+                d.gen_bus2 = dgb;
+                h->nrec_slots = (size_t)BUS_W * h->B + ec.size();
+                h->resident_ok = all_local && h->T == 1;
             }
         }
     }
@@ -1336,6 +1369,70 @@ extern "C" int exaadmm_debug_wave_timeline(exaadmm_handle* h, unsigned long long
 // double-buffered by iteration parity so that the stopping iteration's state survives its speculative successor.
 static bool spec_eligible(const exaadmm_handle* h) { return h->spec_on && h->T == 1 && !h->ctrl_mode; }
 
+// resident loop: every wavefront of the launch must hold a SIMD for the whole launch (one wavefront per SIMD)
+static int resident_capacity(const exaadmm_handle* h)
+{
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, h->device) != hipSuccess || prop.multiProcessorCount <= 0) return 0;
+    return 4 * prop.multiProcessorCount - 8;
+}
+
+static int resident_prepare(exaadmm_handle* h)
+{
+    ResidentSync& r = h->rsync;
+    int rc;
+    if (!r.arrive) {
+        // arrive[B] | ready[B] | contrib, decided, stop, fail: ONE int buffer, reset with one memset per launch
+        int* ints = nullptr;
+        if ((rc = dev_alloc(h, &ints, 2 * (size_t)h->B + 4))) return rc;
+        r.arrive = ints;
+        r.ready = ints + h->B;
+        r.contrib = ints + 2 * (size_t)h->B;
+        r.decided = r.contrib + 1;
+        r.stop = r.contrib + 2;
+        r.fail = r.contrib + 3;
+        const size_t nwork = (size_t)branch_blocks(h) + gen_blocks(h);
+        for (int q = 0; q < 2; q++) {
+            if ((rc = dev_alloc(h, &r.terms[q], 4 * h->nrec_slots))) return rc;
+            if ((rc = dev_alloc(h, &r.busres[q], 4 * (size_t)h->B))) return rc;
+            if ((rc = dev_alloc(h, &r.partials[q], 4 * nwork))) return rc;
+            HIPCHK(hipMemsetAsync(r.terms[q], 0, 4 * h->nrec_slots * sizeof(double), h->stream));
+        }
+    }
+    return 0;
+}
+
+// one launch = `n` iterations of the loop (the batch); the loop control is read and advanced inside (k_resident)
+static int enqueue_resident(exaadmm_handle* h, int n)
+{
+    const int nb = branch_blocks(h), ng = gen_blocks(h);
+    HIPCHK(hipMemsetAsync(h->rsync.arrive, 0, (2 * (size_t)h->B + 4) * sizeof(int), h->stream));
+    hipLaunchKernelGGL(k_resident, dim3(nb + ng + 1), dim3(BR_BLOCK), 0, h->stream, h->d_dspec[0], h->d_dspec[1], h->bo, h->par.scale, h->d_ctrl, ng,
+                       h->baseMVA, n, h->rsync);
+    return 0;
+}
+
+static bool resident_eligible(exaadmm_handle* h)
+{
+    // default: on whenever every wavefront of the launch can be resident (EXAADMM_NO_RESIDENT=1 / EXAADMM_RESIDENT=0: the two-launch loop, A/B)
+#if defined(EXA_PROFILE_PHASES)
+    return false;   // (the diagnostic build's per-wavefront timelines and phase counters belong to k_branch_t)
+#endif
+    if (getenv("EXAADMM_NO_RESIDENT") != nullptr) return false;
+    if (const char* e = getenv("EXAADMM_RESIDENT"))
+        if (atoi(e) == 0) return false;
+    return h->resident_ok && spec_eligible(h) && !dist_has_peers(h) && h->stream == h->own_stream &&
+           branch_blocks(h) + gen_blocks(h) + 1 <= resident_capacity(h);
+}
+
+static int resident_check(exaadmm_handle* h)
+{
+    int failed = 0;
+    HIPCHK(hipMemcpy(&failed, h->rsync.fail, sizeof(int), hipMemcpyDeviceToHost));
+    REQUIRE(failed == 0, "resident loop: a wait ran into its cap (a wavefront of the launch was not resident?)");
+    return 0;
+}
+
 static int spec_prepare(exaadmm_handle* h)
 {
     if (!h->u_alt) {
@@ -1463,11 +1560,24 @@ static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
     float ms_sample[3] = {0.f, 0.f, 0.f};
     int enq = 0;
     bool first = true;
+    const bool resident = resident_eligible(h);
+    if (resident && (rc = resident_prepare(h))) return rc;
     while (enq < max_inner) {
-        const int nb = std::min(batch, max_inner - enq);
+        const int nb = std::min(resident ? 4 * batch : batch, max_inner - enq);
         *h->h_base = enq;   // the stream is idle here (synchronised at the end of every batch)
         HIPCHK(hipMemcpyAsync(&h->d_ctrl->base, h->h_base, sizeof(int), hipMemcpyHostToDevice, h->stream));
-        if (!first && graph_ok && nb == batch) {
+        if (resident) {
+            // one launch per batch; a batch that meets the stop ends inside the kernel, at the reference's iteration.  (The three
+            // step timers of the reference cannot be told apart inside one launch: the sampled time of the first batch goes to
+            // time_x_update.)
+            if (first) (void)hipEventRecord(h->tev[0], h->stream);
+            if ((rc = enqueue_resident(h, nb))) return rc;
+            if (first) {
+                (void)hipEventRecord(h->tev[1], h->stream);
+                (void)hipEventRecord(h->tev[2], h->stream);
+                (void)hipEventRecord(h->tev[3], h->stream);
+            }
+        } else if (!first && graph_ok && nb == batch) {
             if (!h->spec_graph) {
                 hipGraph_t g = nullptr;
                 HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
@@ -1491,6 +1601,7 @@ static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
         if (first) {
             for (int q = 0; q < 3; q++)
                 if (hipEventElapsedTime(&ms_sample[q], h->tev[q], h->tev[q + 1]) != hipSuccess) ms_sample[q] = 0.f;
+            if (resident) ms_sample[0] /= (float)std::max(1, std::min(nb, std::max(1, hc->inner)));   // per iteration of the sampled batch
             first = false;
         }
         if (hc->done) break;   // (a partition: every rank sees the same sums, added in the same order -> the same decision)
@@ -1498,9 +1609,17 @@ static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
     if ((rc = spec_complete_last(h, enq))) return rc;
     HIPCHK(hipMemcpyAsync(hc, h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
     if ((rc = sync_check(h, true))) return rc;
+    if (resident && (rc = resident_check(h))) return rc;
     if ((rc = spec_finish(h, hc->inner))) return rc;
     for (int q = 0; q < 3; q++) h->acc_ms[q] += (double)ms_sample[q] * hc->inner;
     return 0;
+}
+
+extern "C" int exaadmm_loop_kind(exaadmm_handle* h, int* kind)
+{
+    REQUIRE(h && kind, "null argument");
+    *kind = !spec_eligible(h) ? 0 : (resident_eligible(h) ? 2 : 1);
+    return EXAADMM_OK;
 }
 
 // ------------------------------------------------------------------ fused loops
@@ -1685,20 +1804,32 @@ extern "C" int exaadmm_run_fixed(exaadmm_handle* h, int iters, int first_major_i
         hc->first_iter = first_major_iter;
         HIPCHK(hipMemcpyAsync(h->d_ctrl, hc, sizeof(Ctrl), hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
+        const bool resident = resident_eligible(h);
+        if (resident && (rc = resident_prepare(h))) return rc;
         HIPCHK(hipEventRecord(h->ev[0], h->stream));
-        for (int i = 0; i < iters; i++)
-            if ((rc = enqueue_iteration_spec(h, h->d_ctrl, i, false, time_branch ? &h->ev[2 + 2 * i] : nullptr))) return rc;
+        if (resident) {
+            // ONE launch for all `iters` iterations: every wavefront stays resident, a bus is updated by the last lane to arrive at it
+            if (time_branch) HIPCHK(hipEventRecord(h->ev[2], h->stream));
+            if ((rc = enqueue_resident(h, iters))) return rc;
+            if (time_branch) HIPCHK(hipEventRecord(h->ev[3], h->stream));   // (one launch: its time / iters is reported)
+        } else
+            for (int i = 0; i < iters; i++)
+                if ((rc = enqueue_iteration_spec(h, h->d_ctrl, i, false, time_branch ? &h->ev[2 + 2 * i] : nullptr))) return rc;
         if ((rc = spec_complete_last(h, iters))) return rc;
         HIPCHK(hipEventRecord(h->ev[1], h->stream));
         if ((rc = spec_finish(h, iters))) return rc;
         double s[4];
         if ((rc = fetch_sums(h, s, true))) return rc;
+        if (resident && (rc = resident_check(h))) return rc;
         if (out)
             for (int j = 0; j < 4; j++) out[j] = s[j];
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
         if (ms_total) *ms_total = ms;
-        if (time_branch) {
+        if (time_branch && resident) {
+            HIPCHK(hipEventElapsedTime(&ms, h->ev[2], h->ev[3]));
+            *ms_branch = (double)ms / iters;
+        } else if (time_branch) {
             double acc = 0.0;
             for (int i = 0; i < iters; i++) {
                 HIPCHK(hipEventElapsedTime(&ms, h->ev[2 + 2 * i], h->ev[3 + 2 * i]));

@@ -61,6 +61,9 @@ struct Dev {
     // rec_br[2 * branch + {0 from, 1 to}], rec_gen[generator] = slot or -1 (that end's bus belongs to a peer).
     double* rec;
     const int *rec_br, *rec_gen;
+    // resident loop (k_resident): per branch (from-bus, its counts, to-bus, its counts), per generator (bus, counts);
+    // counts = generators << 16 | components
+    const int *br_bus4, *gen_bus2;
     int *st_auglag, *st_minor, *st_ticks;
     unsigned long long* st_cyc;  // diagnostic build (EXA_PROFILE_PHASES): 13 x Lp phase cycle counters
     unsigned long long* st_tl;   // diagnostic build: 128 timeline entries per wavefront (2 x Lp)
@@ -963,6 +966,447 @@ __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group_t(const Ctrl* ctrl, Ctr
         q[0] = tb0; q[1] = tb1; q[2] = tb2; q[3] = tb3; q[4] = tb4;
     }
 #endif
+}
+
+// ---------------------------------------------------------------- resident loop
+// The inner loop of grids whose wavefronts all fit the chip at once (one wavefront per SIMD: branch + generator
+// wavefronts + 1 <= 4 x CUs - 8; 13 659 buses: 385 of 1 024).  ALL wavefronts stay resident for a batch of iterations;
+// nothing is launched between them (exaadmm_hip.hip enqueue_resident; EXAADMM_NO_RESIDENT=1 selects the two-launch loop).  What the bus
+// launch did for everybody, the last lane to ARRIVE at a bus does for that bus:
+//   * a lane that has finished its solve of iteration j pushes the four sum terms of its two ends (tp, tq, tw, tt as the
+//     bus kernels form them) to its slots of terms[j & 1], fences, and counts itself in at both buses (arrive[I] += 1);
+//   * the lane whose arrival completes bus I (arrive[I] == components x j) reads the bus's terms, makes the bus update in
+//     the reference's order (bus_from_rec4: same bits as k_bus) and publishes (mu1, mu2, w, theta) in busres[j & 1][I],
+//     then ready[I] = j (release);
+//   * a lane starts iteration j + 1 when both its buses are ready for j (acquire), forms the v entries of its own
+//     elements, runs the z / l pass and the solve exactly as k_branch_t<false, true> does.
+// The launch's slowest branch is the last to arrive at its own buses: it goes from one solve to the next without waiting
+// for anybody (scripts/microbench/flag_chain.hip: ~1.5 us per hand-over), where the two-launch loop puts two kernel
+// boundaries, the bus launch and two rounds of loads: 57.8 -> 52 us per iteration at 13 659 buses, whole solve 7.5 k -> 9.5 k it/s.
+// Same arithmetic per lane, same order in every sum: bitwise the two-launch loop (tests/test_gpu_resident.py).
+// Every wait is capped: a wavefront that cannot become resident (the GPU shared with other work) ends the launch with
+// rs.fail set and the call with an error instead of a hang.
+// What wavefronts hand to each other -- sum terms, bus results, counters, flags -- is written and read with agent-scope
+// (sc1) accesses: they go to the coherence point themselves, so no L2 write-back / invalidate (agent-scope fence) is needed
+// inside the loop; s_waitcnt vmcnt(0) between the data and the flag / counter that announces them orders them.  With agent-scope fences the loop ran at 84 us per
+// iteration at 13 659 buses: ~1 900 L2 write-backs per iteration queue up behind each other.
+// everything this wavefront has stored is performed (for sc1 stores: at the coherence point) before what follows is issued.
+// (A workgroup-scope fence compiles to NOTHING on gfx950 -- checked -- and left the flag free to overtake the data.)
+__device__ __forceinline__ void resident_order_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void st_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+struct ResidentSync {
+    int* arrive;       // [B] arrivals so far (monotonic over the launch)
+    int* ready;        // [B] last iteration whose bus update is published
+    double* terms[2];  // [slots][4], slot numbering of Dev::rec
+    double* busres[2]; // [B][4]
+    double* partials[2];   // [work blocks][4] residual terms of the z / l pass of index parity
+    int* contrib;      // contributions to the residual terms so far (monotonic over the launch)
+    int* decided;      // decisions published so far
+    int* stop;         // the last decision said stop
+    int* fail;
+};
+
+__device__ __forceinline__ void bus_from_rec4(const Dev& d, const double* __restrict__ rec4, int I, int cnt, double& mu1, double& mu2,
+                                              double& wi, double& ti)
+{
+    const int n = cnt & 0xffff, ngen = cnt >> 16;
+    const int B = d.B;
+    const double* const c = d.busc + I;
+    const double A11 = c[BUSC_A11 * B], A12 = c[BUSC_A12 * B], r21 = c[BUSC_R21 * B], piv = c[BUSC_PIV * B];
+    const double rhosum_w = c[BUSC_RW * B], rhosum_t = c[BUSC_RT * B];
+    const double pd = c[BUSC_PD * B], qd = c[BUSC_QD * B], ysr = c[BUSC_YSR * B], ysi = c[BUSC_YSI * B];
+    double t[BUS_W][4];
+#pragma unroll
+    for (int k = 0; k < BUS_W; k++) {
+        if (k < n) {
+            const double* q = rec4 + 4 * (size_t)(I * BUS_W + k);
+#pragma unroll
+            for (int m = 0; m < 4; m++) t[k][m] = ld_agent(q + m);
+        }
+    }
+    double rhs1 = 0.0, rhs2 = 0.0, cw = 0.0, ct = 0.0;
+    bool sub = false;
+#pragma unroll
+    for (int k = 0; k < BUS_W; k++) {
+        if (k < n) {
+            if (k < ngen) {
+                rhs1 += t[k][0];
+                rhs2 += t[k][1];
+            } else {
+                if (!sub) {
+                    rhs1 -= pd;
+                    rhs2 -= qd;
+                    sub = true;
+                }
+                cw += t[k][2];
+                ct += t[k][3];
+                rhs1 -= t[k][0];
+                rhs2 -= t[k][1];
+            }
+        }
+    }
+    if (n > BUS_W) {   // the rare large bus
+        const int e0 = d.EndStart[I];
+        for (int k = BUS_W; k < n; k++) {
+            const double* q = rec4 + 4 * (size_t)(BUS_W * B + e0 + k);
+            const double a = ld_agent(q), b = ld_agent(q + 1), w = ld_agent(q + 2), th = ld_agent(q + 3);
+            if (k < ngen) {
+                rhs1 += a;
+                rhs2 += b;
+            } else {
+                if (!sub) {
+                    rhs1 -= pd;
+                    rhs2 -= qd;
+                    sub = true;
+                }
+                cw += w;
+                ct += th;
+                rhs1 -= a;
+                rhs2 -= b;
+            }
+        }
+    }
+    if (!sub) {
+        rhs1 -= pd;
+        rhs2 -= qd;
+    }
+    cw /= rhosum_w;
+    rhs1 -= ysr * cw;
+    rhs2 += ysi * cw;
+    mu2 = (rhs2 - r21 * rhs1) / piv;
+    mu1 = (rhs1 - A12 * mu2) / A11;
+    wi = cw + ((ysr * mu1 - ysi * mu2) / rhosum_w);
+    ti = ct / rhosum_t;
+}
+
+__device__ __forceinline__ bool resident_wait(const int* flag, int want, int* fail)
+{
+    // polls are RELAXED loads (an acquire poll invalidates the XCD's L2 for everybody, hundreds of waiting wavefronts at a
+    // time: the working wavefronts slowed down 2.6 x); ONE acquire fence once the flag is seen
+    int spins = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        if (++spins > (1 << 20)) {
+            *fail = 1;
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(24);
+    }
+    asm volatile("" ::: "memory");
+    return true;
+}
+
+// after the lane's terms of iteration j (1-based) are pushed and fenced
+__device__ __forceinline__ void resident_arrive(const Dev& d, const ResidentSync& rs, int I, int cnt, int j)
+{
+    const int n = cnt & 0xffff;
+    const int old = __hip_atomic_fetch_add(rs.arrive + I, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + 1 == n * j) {
+        asm volatile("" ::: "memory");
+        double mu1, mu2, wi, ti;
+        bus_from_rec4(d, rs.terms[j & 1], I, cnt, mu1, mu2, wi, ti);
+        double* q = rs.busres[j & 1] + 4 * (size_t)I;
+        st_agent(q, mu1);
+        st_agent(q + 1, mu2);
+        st_agent(q + 2, wi);
+        st_agent(q + 3, ti);
+        resident_order_stores();
+        __hip_atomic_store(rs.ready + I, j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// Loop control of the resident launch.  Index i of the launch = iteration ctrl->base + i + 1.  The z / l pass of iteration m - 1
+// runs in the prologue of index i (m = base + i + 1) unless m is the loop's first iteration; its residual terms decide whether
+// the loop stops AFTER iteration m - 1.  The decision is made by the control wavefront (the launch's last block) once every
+// other wavefront has contributed its terms of that pass (contrib counter), in the reduction order of the bus launch's
+// reduction block (same bits), and published through `decided`; a wavefront reads it before the z / l pass of the NEXT index
+// overwrites the iterate that would be final -- exactly the one-launch speculation of the two-launch loop.
+__device__ __forceinline__ int resident_passes(const Ctrl* ctrl, int i) { return (i + 1) - ((ctrl->base + 1 == ctrl->first_iter) ? 1 : 0); }
+
+__device__ __forceinline__ void resident_contribute(const Dev& d, const ResidentSync& rs, int parity, const double (&zs)[4])
+{
+    // (lane 0 of a wavefront, after the wave reduction of its terms)
+    double* q = rs.partials[parity] + 4 * (size_t)blockIdx.x;
+#pragma unroll
+    for (int j = 0; j < 4; j++) st_agent(q + j, zs[j]);
+    resident_order_stores();
+    __hip_atomic_fetch_add(rs.contrib, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// returns false when the loop has stopped (or a wait failed)
+__device__ __forceinline__ bool resident_go_on(const ResidentSync& rs, int passes_needed)
+{
+    if (passes_needed <= 0) return true;
+    if (!resident_wait(rs.decided, passes_needed, rs.fail)) return false;
+    return __hip_atomic_load(rs.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+}
+
+__global__ void __launch_bounds__(BR_BLOCK, 1) k_resident(const Dev* __restrict__ dp0, const Dev* __restrict__ dp1, BranchOptions o, double scale,
+                                                           Ctrl* ctrl, int gen_blocks, double baseMVA, int iters, ResidentSync rs)
+{
+    if (ctrl->done) return;
+    const int base_iter = ctrl->base;
+    const double zl_beta = ctrl->beta;
+    const bool first_has_zl = (base_iter + 1 != ctrl->first_iter);
+    const int nwork = gridDim.x - 1;             // the last block is the control wavefront
+    const int nbr_blocks = nwork - gen_blocks;
+    const int lane = threadIdx.x;
+    if ((int)blockIdx.x == nwork) {
+        // ---------------- control wavefront: one decision per z / l pass
+        const int npass = resident_passes(ctrl, iters - 1);
+        for (int p = 1; p <= npass; p++) {
+            if (!resident_wait(rs.contrib, p * nwork, rs.fail)) return;
+            const int i = p - (first_has_zl ? 1 : 0);     // index whose prologue made pass p
+            const double* part = rs.partials[i & 1];
+            double tot[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int vw = 0; vw < EW_BLOCK / 64; vw++) {   // the reduction block of the bus launch has EW_BLOCK threads: same order
+                double sj[4] = {0.0, 0.0, 0.0, 0.0};
+                for (int bq = vw * 64 + lane; bq < nwork; bq += EW_BLOCK) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) sj[j] += ld_agent(part + 4 * (size_t)bq + j);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) sj[j] += __shfl_down(sj[j], off, 64);
+                    tot[j] += sj[j];   // (lane 0: 0 + wave 0 + wave 1 + ... as block_reduce4 adds them)
+                }
+            }
+            int stop = 0;
+            if (lane == 0) {
+                ctrl_advance(ctrl, tot);
+                stop = ctrl->done;
+                __hip_atomic_store(rs.stop, stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                resident_order_stores();
+                __hip_atomic_store(rs.decided, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            stop = __shfl(stop, 0, 64);
+            if (stop) return;
+        }
+        return;
+    }
+    if ((int)blockIdx.x >= nbr_blocks) {
+        // ---------------- generator lanes
+        const int gi = ((int)blockIdx.x - nbr_blocks) * BR_BLOCK + lane;
+        const bool on = gi < dp0->G;
+        const int g = on ? gi : 0;
+        const int I = dp0->gen_bus2[2 * g], cnt = dp0->gen_bus2[2 * g + 1];
+        int i = 0;
+        for (; i < iters; i++) {
+            if (i > 0 && !resident_go_on(rs, resident_passes(ctrl, i - 1))) return;   // (wave-uniform)
+            const Dev& d = (i & 1) ? *dp1 : *dp0;
+            const bool do_zl = (i > 0) || first_has_zl;
+            double zs[4] = {0.0, 0.0, 0.0, 0.0};
+            if (on) {
+                const double* const uin = d.u_in ? d.u_in : d.u;
+                double* const vbuf = const_cast<double*>(d.v_in ? d.v_in : d.v);
+                const int pg = g, qg = d.Gp + g;
+                const double rho_p = d.rho[pg], rho_q = d.rho[qg];
+                double lp = d.l[pg], lq = d.l[qg], zp = d.z[pg], zq = d.z[qg];
+                if (do_zl) {
+                    const double up0 = uin[pg], uq0 = uin[qg];
+                    double vp, vq;
+                    if (i > 0) {
+                        if (!resident_wait(rs.ready + I, i, rs.fail)) return;
+                        const double* r = rs.busres[i & 1] + 4 * (size_t)I;
+                        vp = (up0 + zp) + (lp - ld_agent(r)) / rho_p;
+                        vq = (uq0 + zq) + (lq - ld_agent(r + 1)) / rho_q;
+                        vbuf[pg] = vp;
+                        vbuf[qg] = vq;
+                    } else {   // first index of a later batch: the previous launch left v in memory
+                        vp = vbuf[pg];
+                        vq = vbuf[qg];
+                    }
+                    zl_element(d, pg, up0, vp, rho_p, zl_beta, zs, lp, zp);
+                    zl_element(d, qg, uq0, vq, rho_q, zl_beta, zs, lq, zq);
+                }
+                double up, uq;
+                generator_update(d, baseMVA, g, vbuf, up, uq);
+                double* q = rs.terms[(i + 1) & 1] + 4 * (size_t)d.rec_gen[g];
+                st_agent(q, (up + zp) + (lp / rho_p));
+                st_agent(q + 1, (uq + zq) + (lq / rho_q));
+            }
+            if (do_zl) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) zs[j] += __shfl_down(zs[j], off, 64);
+                }
+                if (lane == 0) resident_contribute(d, rs, i & 1, zs);
+            }
+            resident_order_stores();
+            if (on) resident_arrive(d, rs, I, cnt, i + 1);
+        }
+        if (on) {   // v of the last index (what its bus launch would have written)
+            const Dev& d = ((iters - 1) & 1) ? *dp1 : *dp0;
+            if (!resident_wait(rs.ready + I, iters, rs.fail)) return;
+            const double* r = rs.busres[iters & 1] + 4 * (size_t)I;
+            const int pg = g, qg = d.Gp + g;
+            d.v[pg] = (d.u[pg] + d.z[pg]) + (d.l[pg] - ld_agent(r)) / d.rho[pg];
+            d.v[qg] = (d.u[qg] + d.z[qg]) + (d.l[qg] - ld_agent(r + 1)) / d.rho[qg];
+        }
+        return;
+    }
+    // ---------------- branch lanes
+    __shared__ MuPowTable pw_lds;
+    if (lane < 24) reinterpret_cast<double*>(&pw_lds)[lane] = reinterpret_cast<const double*>(&c_mupow)[lane];
+    __shared__ double park_lds[40 * BR_BLOCK];
+    const int slot = blockIdx.x * BR_BLOCK + lane;
+    const bool lane_on = slot < dp0->L;
+    const int b = lane_on ? slot : 0;
+    const int Lp = dp0->Lp;
+    const int base = 2 * dp0->Gp + b;
+    for (int i = 0; i < iters; i++) {
+        if (i > 0 && !resident_go_on(rs, resident_passes(ctrl, i - 1))) return;   // (wave-uniform: the loop has stopped)
+        const Dev& d = (i & 1) ? *dp1 : *dp0;
+        const int4 bus4 = reinterpret_cast<const int4*>(d.br_bus4)[b];
+        const int rec_from = d.rec_br[2 * b], rec_to = d.rec_br[2 * b + 1];
+        const int major_iter = base_iter + i + 1;
+        const bool do_zl = (i > 0) || first_has_zl;
+        const bool v_from_bus = (i > 0);
+        const double* const uin = d.u_in ? d.u_in : d.u;
+        double* const vbuf = const_cast<double*>(d.v_in ? d.v_in : d.v);
+        double zs[4] = {0.0, 0.0, 0.0, 0.0};
+        double ub[8], bnd[8], vv[8], zo[8], lo[8], lzv[8];
+        BranchData bd;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int e = base + k * Lp;
+            ub[k] = uin[e];
+            bd.rho_[k] = d.rho[e];
+            zo[k] = d.z[e];
+            lo[k] = d.l[e];
+            lzv[k] = do_zl ? d.lz[e] : 0.0;
+            vv[k] = v_from_bus ? 0.0 : vbuf[e];
+            bd.Y_[k] = d.Y[b + k * Lp];
+            bnd[k] = d.bnd[b + k * Lp];
+        }
+        bd.ls1 = (d.ls1_in ? d.ls1_in : d.ls1)[b];
+        bd.ls2 = (d.ls2_in ? d.ls2_in : d.ls2)[b];
+        const double mu_0 = (d.mu_in ? d.mu_in : d.mu)[b];
+        const double rate_0 = d.rateA[b];
+        if (v_from_bus && lane_on) {
+            if (!resident_wait(rs.ready + bus4.x, i, rs.fail)) return;
+            if (!resident_wait(rs.ready + bus4.z, i, rs.fail)) return;
+            const double* pf = rs.busres[i & 1] + 4 * (size_t)bus4.x;
+            const double* pt = rs.busres[i & 1] + 4 * (size_t)bus4.z;
+            const double rf[4] = {ld_agent(pf), ld_agent(pf + 1), ld_agent(pf + 2), ld_agent(pf + 3)};
+            const double rt[4] = {ld_agent(pt), ld_agent(pt + 1), ld_agent(pt + 2), ld_agent(pt + 3)};
+            vv[0] = (ub[0] + zo[0]) + (lo[0] + rf[0]) / bd.rho_[0];
+            vv[1] = (ub[1] + zo[1]) + (lo[1] + rf[1]) / bd.rho_[1];
+            vv[4] = rf[2];
+            vv[6] = rf[3];
+            vv[2] = (ub[2] + zo[2]) + (lo[2] + rt[0]) / bd.rho_[2];
+            vv[3] = (ub[3] + zo[3]) + (lo[3] + rt[1]) / bd.rho_[3];
+            vv[5] = rt[2];
+            vv[7] = rt[3];
+#pragma unroll
+            for (int k = 0; k < 8; k++) vbuf[base + k * Lp] = vv[k];   // (what the bus launch of the previous index would have written)
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (do_zl && lane_on) {
+                const int e = base + k * Lp;
+                double zn;
+                zl_values(ub[k], vv[k], bd.rho_[k], zl_beta, lzv[k], zo[k], lo[k], zs, bd.lam_[k], zn);
+                d.zp[e] = zo[k];
+                d.z[e] = zn;
+                d.l[e] = bd.lam_[k];
+                bd.xt_[k] = vv[k] - zn;
+                zo[k] = zn;
+            } else {
+                bd.lam_[k] = lo[k];
+                bd.xt_[k] = vv[k] - zo[k];
+            }
+            park_lds[(32 + k) * BR_BLOCK + lane] = zo[k];
+        }
+        if (do_zl) {
+            const bool counts = lane_on && (b < d.Lown);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (!counts) zs[j] = 0.0;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) zs[j] += __shfl_down(zs[j], off, 64);
+            }
+            if (lane == 0) resident_contribute(d, rs, i & 1, zs);
+        }
+        if (lane_on) {
+            bd.mu = (major_iter == 1) ? 10.0 : mu_0;
+            bd.scale = scale;
+            SymMat<6> A, L;
+            double x[6], xl[6], xu[6], phi[4];
+            branch_start(ub, bnd, rate_0, x, xl, xu);
+            BranchStats st;
+            st.tl = nullptr;
+            branch_solve(bd, o, pw_lds, x, xl, xu, A, L, phi, st, park_lds + lane);
+            d.u[base] = phi[0];
+            d.u[base + Lp] = phi[1];
+            d.u[base + 2 * Lp] = phi[2];
+            d.u[base + 3 * Lp] = phi[3];
+            d.u[base + 4 * Lp] = x[0] * x[0];
+            d.u[base + 5 * Lp] = x[1] * x[1];
+            d.u[base + 6 * Lp] = x[2];
+            d.u[base + 7 * Lp] = x[3];
+            double zz[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) zz[k] = park_lds[(32 + k) * BR_BLOCK + lane];
+            const double un[8] = {phi[0], phi[1], phi[2], phi[3], x[0] * x[0], x[1] * x[1], x[2], x[3]};
+            double* const tm = rs.terms[(i + 1) & 1];
+            {
+                double* q = tm + 4 * (size_t)rec_from;
+                st_agent(q, (un[0] + zz[0]) + (bd.lam_[0] / bd.rho_[0]));
+                st_agent(q + 1, (un[1] + zz[1]) + (bd.lam_[1] / bd.rho_[1]));
+                st_agent(q + 2, bd.lam_[4] + bd.rho_[4] * (un[4] + zz[4]));
+                st_agent(q + 3, bd.lam_[6] + bd.rho_[6] * (un[6] + zz[6]));
+            }
+            {
+                double* q = tm + 4 * (size_t)rec_to;
+                st_agent(q, (un[2] + zz[2]) + (bd.lam_[2] / bd.rho_[2]));
+                st_agent(q + 1, (un[3] + zz[3]) + (bd.lam_[3] / bd.rho_[3]));
+                st_agent(q + 2, bd.lam_[5] + bd.rho_[5] * (un[5] + zz[5]));
+                st_agent(q + 3, bd.lam_[7] + bd.rho_[7] * (un[7] + zz[7]));
+            }
+            d.ls1[b] = bd.ls1;
+            d.ls2[b] = bd.ls2;
+            d.mu[b] = bd.mu;
+            d.st_auglag[b] = st.auglag_it;
+            d.st_minor[b] = st.minor_it;
+            d.st_ticks[b] = st.ticks;
+        }
+        resident_order_stores();
+        if (lane_on) {
+            resident_arrive(d, rs, bus4.x, bus4.y, i + 1);
+            resident_arrive(d, rs, bus4.z, bus4.w, i + 1);
+        }
+    }
+    if (lane_on) {   // v of the last index (what its bus launch would have written)
+        const Dev& d = ((iters - 1) & 1) ? *dp1 : *dp0;
+        const int4 bus4 = reinterpret_cast<const int4*>(d.br_bus4)[b];
+        if (!resident_wait(rs.ready + bus4.x, iters, rs.fail)) return;
+        if (!resident_wait(rs.ready + bus4.z, iters, rs.fail)) return;
+        const double* pf = rs.busres[iters & 1] + 4 * (size_t)bus4.x;
+        const double* pt = rs.busres[iters & 1] + 4 * (size_t)bus4.z;
+        const double rf[4] = {ld_agent(pf), ld_agent(pf + 1), ld_agent(pf + 2), ld_agent(pf + 3)};
+        const double rt[4] = {ld_agent(pt), ld_agent(pt + 1), ld_agent(pt + 2), ld_agent(pt + 3)};
+        double uu[8], zz[8], ll[8], rr[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int e = base + k * Lp;
+            uu[k] = d.u[e];
+            zz[k] = d.z[e];
+            ll[k] = d.l[e];
+            rr[k] = d.rho[e];
+        }
+        d.v[base] = (uu[0] + zz[0]) + (ll[0] + rf[0]) / rr[0];
+        d.v[base + Lp] = (uu[1] + zz[1]) + (ll[1] + rf[1]) / rr[1];
+        d.v[base + 2 * Lp] = (uu[2] + zz[2]) + (ll[2] + rt[0]) / rr[2];
+        d.v[base + 3 * Lp] = (uu[3] + zz[3]) + (ll[3] + rt[1]) / rr[3];
+        d.v[base + 4 * Lp] = rf[2];
+        d.v[base + 5 * Lp] = rt[2];
+        d.v[base + 6 * Lp] = rf[3];
+        d.v[base + 7 * Lp] = rt[3];
+    }
 }
 
 // The receiving half of a partition's one exchange per iteration (dist_native.h), after the grouped ncclSend / ncclRecv:

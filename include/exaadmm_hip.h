@@ -153,6 +153,10 @@ int exaadmm_branch_stats(exaadmm_handle *h, double *avg_auglag_it, double *avg_m
 int exaadmm_download_branch_counters(exaadmm_handle *h, int32_t *auglag_it, int32_t *minor_it, int32_t *ticks, int64_t nline);
 /* resident wavefronts per SIMD that the branch kernel's register / LDS footprint allows (occupancy API) */
 int exaadmm_branch_kernel_occupancy(exaadmm_handle *h, int *waves_per_simd);
+/* which form of the inner loop exaadmm_run_inner / _run_fixed / _solve_two_level use on this handle (diagnostic):
+ * 0 = four launches per iteration, 1 = two launches per iteration (speculative loop), 2 = resident loop (one launch per
+ * batch of iterations, every wavefront resident; EXAADMM_NO_RESIDENT=1 selects 1) */
+int exaadmm_loop_kind(exaadmm_handle *h, int *kind);
 
 /* ---- fused: control stays on the device side ---- */
 /* Inner while-loop of admm_two_level (admm_two_level.jl:34-63) for outer iteration `outer`:

@@ -17,10 +17,18 @@ rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 out = {"trace": f, "phases": "preparation %d | warm-up %d | timed region %d | event-bracketed pass %d | whole solves (rest)" % (P, W, K, K)}
 for key, tag in (("k_branch", "k_branch"), ("k_bus", "k_bus_group")):
     d = np.array([(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if key in r["Kernel_Name"]])
+    if len(d) == 0:
+        continue
     cuts = [0, P, P + W, P + W + K, P + W + 2 * K, len(d)]
     names = ["preparation", "warm_up", "timed_region", "event_bracketed_pass", "whole_solves"]
     out[tag] = {"launches": int(len(d)), "average_us_all": float(d.mean())}
     for n, a, b in zip(names, cuts[:-1], cuts[1:]):
         if b > a:
             out[tag][n] = {"launches": int(b - a), "average_us": float(d[a:b].mean()), "min_us": float(d[a:b].min()), "max_us": float(d[a:b].max())}
+# resident loop: one k_resident launch per phase (preparation, warm-up, timed region, event-bracketed pass), `its` iterations each
+res = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if "k_resident" in r["Kernel_Name"]]
+if res:
+    out["k_resident"] = {"launches": len(res)}
+    for n, its, d in zip(["preparation", "warm_up", "timed_region", "event_bracketed_pass"], [P, W, K, K], res):
+        out["k_resident"][n] = {"iterations": its, "launch_us": float(d), "us_per_iteration": float(d / max(its, 1))}
 print(json.dumps(out, indent=1))

@@ -18,7 +18,9 @@ from collections import defaultdict
 
 out_dir, workload = sys.argv[1], sys.argv[2]
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 200
-short = {"k_branch_t": "k_branch", "k_bus_group": "k_bus_group", "k_fused_zl": "k_fused_zl"}
+short = {"k_branch_t": "k_branch", "k_bus_group": "k_bus_group", "k_fused_zl": "k_fused_zl", "k_resident": "k_resident"}
+# k_resident (resident loop): ONE launch does the `steps` iterations of a region; its last launch is the event-bracketed pass;
+# counters and duration are divided by `steps` -> per ITERATION figures
 acc = defaultdict(dict)
 dur = {}
 for f in glob.glob(os.path.join(out_dir, "*", "*", "*counter_collection.csv")):
@@ -31,6 +33,11 @@ for f in glob.glob(os.path.join(out_dir, "*", "*", "*counter_collection.csv")):
     for name, cs in per.items():
         for cname, vals in cs.items():
             vals.sort()
+            if name == "k_resident":
+                tail = vals[-1:]
+                acc[name][cname] = tail[0][1] / steps
+                dur.setdefault(name, {})[cname] = tail[0][2] / steps * 1e-3
+                continue
             tail = vals[-steps:]
             acc[name][cname] = sum(v for _, v, _ in tail) / len(tail)
             dur.setdefault(name, {})[cname] = sum(d for _, _, d in tail) / len(tail) * 1e-3   # us, under the profiler
@@ -52,5 +59,7 @@ for name, c in acc.items():
         us = dur[name]["GRBM_GUI_ACTIVE"]
         e["kernel_us_in_that_pass"] = round(us, 2)
         e["shader_clock_mhz"] = round(c["GRBM_GUI_ACTIVE"] / 8 / us, 1)
+    if name == "k_resident":
+        e["per"] = "iteration (one launch = %d iterations)" % steps
     res[name] = e
 print(json.dumps({workload: res}, indent=1))

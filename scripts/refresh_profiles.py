@@ -21,7 +21,7 @@ def line(f):
 
 names = {"bench_default": "bench", "bench_driver_cmd": "bench_driver_command_steps20", "bench_case1354pegase": "bench_case1354pegase",
          "bench_case_ACTIVSg70k": "bench_case_ACTIVSg70k", "bench_synthetic1M": "bench_synthetic1M", "bench_dist1": "bench_force_dist_one_rank", "bench_dist1_70k": "bench_force_dist_one_rank_case_ACTIVSg70k",
-         "bench_mp4": "bench_mp_4_periods", "bench_case118": "bench_case118_real_file", "bench_case9": "bench_case9_real_file"}
+         "bench_mp4": "bench_mp_4_periods", "bench_two_launch_loop": "bench_two_launch_loop_EXAADMM_NO_RESIDENT", "bench_case118": "bench_case118_real_file", "bench_case9": "bench_case9_real_file"}
 for k, v in names.items():
     f = os.path.join(src, k + ".log")
     if os.path.exists(f):
@@ -56,10 +56,16 @@ for case, steps in (("case13659pegase", 200), ("case1354pegase", 200), ("case_AC
     if not os.path.isdir(p):
         continue
     out.update(json.loads(subprocess.check_output([sys.executable, os.path.join(ROOT, "scripts", "summarize_pmc.py"), p, wl, str(steps)])))
-    out[wl]["k_branch"]["algorithmic_bytes"] = int(824.0 * L + 192.0 * G)
-    out[wl]["k_branch"]["algorithmic_bytes_note"] = ("fused launch: 568 B per branch + 128 B per generator + the unshared part of the z/l pass (32 B per vector element) "
-                                                     "= 824 L + 192 G.  On top of that the launch writes the bus records it pushes (128 B per branch, 48 B per generator) "
-                                                     "and reads their slot indices (8 B / 4 B): design traffic, not algorithmic -- it replaces 256 B of gathers per branch in the bus launch")
-    out[wl]["k_bus_group"]["algorithmic_bytes"] = None
+    if "k_resident" in out[wl]:   # resident loop: one launch does whole iterations; figures per iteration
+        out[wl]["k_resident"]["algorithmic_bytes"] = None
+        out[wl]["k_resident"]["algorithmic_bytes_note"] = ("per iteration of the resident launch: the whole iteration's algorithmic bytes (bench.py BYTES_PER_ITER, SURVEY.md 8d); "
+                                                           "on top of them the sum terms / bus results / flags the wavefronts hand to each other (sc1 accesses)")
+    if "k_branch" in out[wl]:
+        out[wl]["k_branch"]["algorithmic_bytes"] = int(824.0 * L + 192.0 * G)
+        out[wl]["k_branch"]["algorithmic_bytes_note"] = ("fused launch: 568 B per branch + 128 B per generator + the unshared part of the z/l pass (32 B per vector element) "
+                                                         "= 824 L + 192 G.  On top of that the launch writes the bus records it pushes (128 B per branch, 48 B per generator) "
+                                                         "and reads their slot indices (8 B / 4 B): design traffic, not algorithmic -- it replaces 256 B of gathers per branch in the bus launch")
+    if "k_bus_group" in out[wl]:
+        out[wl]["k_bus_group"]["algorithmic_bytes"] = None
 json.dump(out, open(out_p, "w"), indent=1)
 print("profiles refreshed from", src)

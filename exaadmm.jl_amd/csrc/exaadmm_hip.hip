@@ -1372,9 +1372,16 @@ static bool spec_eligible(const exaadmm_handle* h) { return h->spec_on && h->T =
 // resident loop: every wavefront of the launch must hold a SIMD for the whole launch (one wavefront per SIMD)
 static int resident_capacity(const exaadmm_handle* h)
 {
+    // what the occupancy calculator says the chip holds of THIS kernel (registers: one wavefront per SIMD; LDS: 20 KB per block),
+    // minus a margin of 8
+    static int per_cu = -1;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, h->device) != hipSuccess || prop.multiProcessorCount <= 0) return 0;
-    return 4 * prop.multiProcessorCount - 8;
+    if (per_cu < 0) {
+        int blocks = 0;
+        per_cu = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_resident, BR_BLOCK, 0) == hipSuccess) ? std::min(blocks, 4) : 0;
+    }
+    return per_cu * prop.multiProcessorCount - 8;
 }
 
 static int resident_prepare(exaadmm_handle* h)
@@ -1429,7 +1436,10 @@ static int resident_check(exaadmm_handle* h)
 {
     int failed = 0;
     HIPCHK(hipMemcpy(&failed, h->rsync.fail, sizeof(int), hipMemcpyDeviceToHost));
-    REQUIRE(failed == 0, "resident loop: a wait ran into its cap (a wavefront of the launch was not resident?)");
+    if (failed != 0) {
+        set_err("resident loop: a wait ran into its cap (a wavefront of the launch was not resident: is the GPU shared?); EXAADMM_NO_RESIDENT=1 selects the two-launch loop");
+        return EXAADMM_ERR_HIP;
+    }
     return 0;
 }
 

@@ -29,6 +29,7 @@ $T python bench.py --case synthetic1M --steps 100 --warmup 20 --no-cpu-baseline 
 $T python bench.py --force-dist --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_dist1.log 2>&1
 $T python bench.py --force-dist --case case_ACTIVSg70k --steps 100 --warmup 20 --no-cpu-baseline > $O/bench_dist1_70k.log 2>&1
 $T python bench.py --periods 4 --steps 100 --warmup 20 > $O/bench_mp4.log 2>&1
+EXAADMM_NO_RESIDENT=1 $T python bench.py --no-cpu-baseline > $O/bench_two_launch_loop.log 2>&1
 for f in $O/bench_*.log; do echo "$f: $(python -c "
 import json
 for l in open('$f'):

@@ -1432,10 +1432,16 @@ static bool resident_eligible(exaadmm_handle* h)
            branch_blocks(h) + gen_blocks(h) + 1 <= resident_capacity(h);
 }
 
+// the failure flag of the resident launches travels with the download that ends the call (no round trip of its own):
+// resident_check_enqueue before that download's synchronisation, resident_check after it
+static int resident_check_enqueue(exaadmm_handle* h)
+{
+    HIPCHK(hipMemcpyAsync(h->h_base, h->rsync.fail, sizeof(int), hipMemcpyDeviceToHost, h->stream));   // (h_base: pinned, idle here)
+    return 0;
+}
 static int resident_check(exaadmm_handle* h)
 {
-    int failed = 0;
-    HIPCHK(hipMemcpy(&failed, h->rsync.fail, sizeof(int), hipMemcpyDeviceToHost));
+    const int failed = *h->h_base;
     if (failed != 0) {
         set_err("resident loop: a wait ran into its cap (a wavefront of the launch was not resident: is the GPU shared?); EXAADMM_NO_RESIDENT=1 selects the two-launch loop");
         return EXAADMM_ERR_HIP;
@@ -1573,7 +1579,7 @@ static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
     const bool resident = resident_eligible(h);
     if (resident && (rc = resident_prepare(h))) return rc;
     while (enq < max_inner) {
-        const int nb = std::min(resident ? 4 * batch : batch, max_inner - enq);
+        const int nb = std::min(resident ? 8 * batch : batch, max_inner - enq);   // (resident: one launch and one host round trip per 64 iterations)
         *h->h_base = enq;   // the stream is idle here (synchronised at the end of every batch)
         HIPCHK(hipMemcpyAsync(&h->d_ctrl->base, h->h_base, sizeof(int), hipMemcpyHostToDevice, h->stream));
         if (resident) {
@@ -1618,6 +1624,7 @@ static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
     }
     if ((rc = spec_complete_last(h, enq))) return rc;
     HIPCHK(hipMemcpyAsync(hc, h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
+    if (resident && (rc = resident_check_enqueue(h))) return rc;
     if ((rc = sync_check(h, true))) return rc;
     if (resident && (rc = resident_check(h))) return rc;
     if ((rc = spec_finish(h, hc->inner))) return rc;
@@ -1812,8 +1819,7 @@ extern "C" int exaadmm_run_fixed(exaadmm_handle* h, int iters, int first_major_i
         hc->beta = beta;
         hc->base = first_major_iter - 1;
         hc->first_iter = first_major_iter;
-        HIPCHK(hipMemcpyAsync(h->d_ctrl, hc, sizeof(Ctrl), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_ctrl, hc, sizeof(Ctrl), hipMemcpyHostToDevice, h->stream));   // (hc is pinned and not written again before the call's final synchronisation)
         const bool resident = resident_eligible(h);
         if (resident && (rc = resident_prepare(h))) return rc;
         HIPCHK(hipEventRecord(h->ev[0], h->stream));
@@ -1829,6 +1835,7 @@ extern "C" int exaadmm_run_fixed(exaadmm_handle* h, int iters, int first_major_i
         HIPCHK(hipEventRecord(h->ev[1], h->stream));
         if ((rc = spec_finish(h, iters))) return rc;
         double s[4];
+        if (resident && (rc = resident_check_enqueue(h))) return rc;
         if ((rc = fetch_sums(h, s, true))) return rc;
         if (resident && (rc = resident_check(h))) return rc;
         if (out)

@@ -171,6 +171,7 @@ def library():
                                                    C.POINTER(C.c_int32), C.c_int64]
     L.exaadmm_branch_kernel_occupancy.argtypes = [H, C.POINTER(C.c_int)]
     L.exaadmm_loop_kind.argtypes = [H, C.POINTER(C.c_int)]
+    L.exaadmm_loop_downgrades.argtypes = [H, C.POINTER(C.c_int)]
     L.exaadmm_run_inner.argtypes = [H, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int), c_double_p]
     L.exaadmm_solve_two_level.argtypes = [H, C.POINTER(Info)]
     L.exaadmm_run_fixed.argtypes = [H, C.c_int, C.c_int, C.c_double, c_double_p, c_double_p, c_double_p]
@@ -399,6 +400,13 @@ class ModelAcopf:
         """0 = four launches per iteration, 1 = two (speculative loop), 2 = resident loop (one launch per batch of iterations)"""
         k = C.c_int()
         _check(library().exaadmm_loop_kind(self._h, C.byref(k)), "exaadmm_loop_kind")
+        return k.value
+
+    def loop_downgrades(self):
+        """how often a resident batch of this handle was found not co-resident (shared GPU), restored and repeated with the
+        two-launch loop (the handle then keeps that loop)"""
+        k = C.c_int()
+        _check(library().exaadmm_loop_downgrades(self._h, C.byref(k)), "exaadmm_loop_downgrades")
         return k.value
 
     def branch_kernel_occupancy(self):

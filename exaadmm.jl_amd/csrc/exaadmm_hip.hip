@@ -117,8 +117,16 @@ struct exaadmm_handle {
     int *st_alt[3] = {nullptr, nullptr, nullptr};   // per-branch counters of the alternate set (auglag, minor, ticks)
     // (the z/l pass of an iteration rides in the NEXT branch launch's prologue: alternate v, per-block partial sums)
     double *v_alt = nullptr, *partials_br = nullptr;
-    // resident loop (kernels.h k_resident; experiment, EXAADMM_RESIDENT=1, fixed-count runs on one GPU)
+    // resident loop (kernels.h k_resident): the default loop of a single-period grid without peers whose wavefronts all fit
+    // the chip at once (EXAADMM_NO_RESIDENT=1: A/B switch).  resident_cap = wavefronts of k_resident this device holds
+    // at once (computed once per handle); resident_downgrades = batches that ran into a wait cap (the GPU was shared):
+    // the iterate was restored from `guard` and the batch repeated with the two-launch loop, which the handle then keeps.
     bool resident_ok = false;
+    int resident_cap = -1;
+    int resident_downgrades = 0;
+    int resident_launches = 0;
+    bool resident_coop = false;
+    std::vector<void*> guard;
     size_t nrec_slots = 0;
     ResidentSync rsync = {};
     Dev dspec[2];
@@ -1370,18 +1378,77 @@ extern "C" int exaadmm_debug_wave_timeline(exaadmm_handle* h, unsigned long long
 static bool spec_eligible(const exaadmm_handle* h) { return h->spec_on && h->T == 1 && !h->ctrl_mode; }
 
 // resident loop: every wavefront of the launch must hold a SIMD for the whole launch (one wavefront per SIMD)
-static int resident_capacity(const exaadmm_handle* h)
+static int resident_capacity(exaadmm_handle* h)
 {
-    // what the occupancy calculator says the chip holds of THIS kernel (registers: one wavefront per SIMD; LDS: 20 KB per block),
-    // minus a margin of 8
-    static int per_cu = -1;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, h->device) != hipSuccess || prop.multiProcessorCount <= 0) return 0;
-    if (per_cu < 0) {
+    // what the occupancy calculator says THIS device holds of THIS kernel (registers: one wavefront per SIMD; LDS: 20 KB per
+    // block), minus a margin of 8; computed once per handle.  A process that runs under a CU mask does not own the CUs the
+    // device properties report: no resident loop there.
+    if (h->resident_cap < 0) {
+        h->resident_cap = 0;
+        hipDeviceProp_t prop;
         int blocks = 0;
-        per_cu = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_resident, BR_BLOCK, 0) == hipSuccess) ? std::min(blocks, 4) : 0;
+        const bool masked = getenv("HSA_CU_MASK") != nullptr || getenv("ROC_GLOBAL_CU_MASK") != nullptr;
+        if (!masked && hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0 &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_resident, BR_BLOCK, 0) == hipSuccess)
+            h->resident_cap = std::max(0, std::min(blocks, 4) * prop.multiProcessorCount - 8);
+        (void)hipGetLastError();
+        // a cooperative launch makes the runtime check co-residency against its own occupancy figure and refuse what does
+        // not fit (A/B switch EXAADMM_RESIDENT_COOP=0: plain launch; measured in profiles/r04_resident_hardening.txt)
+        int coop = 0;
+        const char* e = getenv("EXAADMM_RESIDENT_COOP");
+        h->resident_coop = (e == nullptr || atoi(e) != 0) &&
+                           hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, h->device) == hipSuccess && coop != 0;
+        (void)hipGetLastError();
     }
-    return per_cu * prop.multiProcessorCount - 8;
+    return h->resident_cap;
+}
+
+// 8-byte-word copies of several buffers in one launch (the resident loop's guard snapshot: one kernel, no host loop of memcpys)
+struct CopyList {
+    const unsigned long long* src[12];
+    unsigned long long* dst[12];
+    unsigned int words[12];
+    int n;
+};
+__global__ void k_copy_list(CopyList c)
+{
+    for (int q = 0; q < c.n; q++)
+        for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < c.words[q]; i += gridDim.x * blockDim.x) c.dst[q][i] = c.src[q][i];
+}
+
+// everything an inner loop changes that lives in the PRIMARY buffers (where every loop starts and ends): u, v, z, z_prev, l,
+// the line-limit multipliers and penalty, the per-branch counters
+static int resident_guard(exaadmm_handle* h, bool restore)
+{
+    int rc;
+    if (h->guard.empty()) {
+        for (int q = 0; q < 5; q++) {
+            double* p = nullptr;
+            if ((rc = dev_alloc(h, &p, (size_t)h->N))) return rc;
+            h->guard.push_back(p);
+        }
+        for (int q = 0; q < 3; q++) {
+            double* p = nullptr;
+            if ((rc = dev_alloc(h, &p, (size_t)h->Lp))) return rc;
+            h->guard.push_back(p);
+        }
+        for (int q = 0; q < 3; q++) {
+            int* p = nullptr;
+            if ((rc = dev_alloc(h, &p, (size_t)h->Lp))) return rc;   // (Lp is a multiple of 64: whole 8-byte words)
+            h->guard.push_back(p);
+        }
+    }
+    void* prim[11] = {h->d.u, h->d.v, h->d.z, h->d.zp, h->d.l, h->d.ls1, h->d.ls2, h->d.mu, h->d.st_auglag, h->d.st_minor, h->d.st_ticks};
+    CopyList c;
+    c.n = 11;
+    for (int q = 0; q < 11; q++) {
+        c.src[q] = (const unsigned long long*)(restore ? h->guard[q] : prim[q]);
+        c.dst[q] = (unsigned long long*)(restore ? prim[q] : h->guard[q]);
+        c.words[q] = (unsigned int)(q < 5 ? h->N : (q < 8 ? h->Lp : h->Lp / 2));
+    }
+    hipLaunchKernelGGL(k_copy_list, dim3(std::min(1024, std::max(1, h->N / 256))), dim3(256), 0, h->stream, c);
+    HIPCHK(hipGetLastError());
+    return 0;
 }
 
 static int resident_prepare(exaadmm_handle* h)
@@ -1389,7 +1456,8 @@ static int resident_prepare(exaadmm_handle* h)
     ResidentSync& r = h->rsync;
     int rc;
     if (!r.arrive) {
-        // arrive[B] | ready[B] | contrib, decided, stop, fail: ONE int buffer, reset with one memset per launch
+        // arrive[B] | ready[B] | contrib, decided, stop | fail: ONE int buffer; everything but `fail` is reset in front of every
+        // launch, `fail` once per call (a later launch's reset must not erase what an earlier one reported)
         int* ints = nullptr;
         if ((rc = dev_alloc(h, &ints, 2 * (size_t)h->B + 4))) return rc;
         r.arrive = ints;
@@ -1406,16 +1474,32 @@ static int resident_prepare(exaadmm_handle* h)
             HIPCHK(hipMemsetAsync(r.terms[q], 0, 4 * h->nrec_slots * sizeof(double), h->stream));
         }
     }
-    return 0;
+    HIPCHK(hipMemsetAsync(r.fail, 0, sizeof(int), h->stream));
+    h->h_base[1] = 0;
+    return resident_guard(h, false);   // the iterate the call starts from: what a failed batch falls back to
 }
 
 // one launch = `n` iterations of the loop (the batch); the loop control is read and advanced inside (k_resident)
 static int enqueue_resident(exaadmm_handle* h, int n)
 {
     const int nb = branch_blocks(h), ng = gen_blocks(h);
-    HIPCHK(hipMemsetAsync(h->rsync.arrive, 0, (2 * (size_t)h->B + 4) * sizeof(int), h->stream));
+    HIPCHK(hipMemsetAsync(h->rsync.arrive, 0, (2 * (size_t)h->B + 3) * sizeof(int), h->stream));
+    h->resident_launches += 1;
+    if (const char* e = getenv("EXAADMM_RESIDENT_TEST_FAIL"))   // tests: the n-th resident launch of a handle reports a failed wait
+        if (atoi(e) == h->resident_launches) HIPCHK(hipMemsetAsync(h->rsync.fail, 0x01, 1, h->stream));
+    if (h->resident_coop) {
+        const Dev *d0 = h->d_dspec[0], *d1 = h->d_dspec[1];
+        double scale = h->par.scale, base = h->baseMVA;
+        void* args[] = {(void*)&d0, (void*)&d1, (void*)&h->bo, (void*)&scale, (void*)&h->d_ctrl, (void*)&ng, (void*)&base, (void*)&n, (void*)&h->rsync};
+        const hipError_t e = hipLaunchCooperativeKernel((const void*)k_resident, dim3(nb + ng + 1), dim3(BR_BLOCK), args, 0, h->stream);
+        if (e == hipSuccess) return 0;
+        (void)hipGetLastError();
+        if (e != hipErrorCooperativeLaunchTooLarge) h->resident_coop = false;   // (not offered after all: plain launches from here on)
+        else return 1;   // the runtime says the grid is not co-resident: the caller takes the two-launch loop
+    }
     hipLaunchKernelGGL(k_resident, dim3(nb + ng + 1), dim3(BR_BLOCK), 0, h->stream, h->d_dspec[0], h->d_dspec[1], h->bo, h->par.scale, h->d_ctrl, ng,
                        h->baseMVA, n, h->rsync);
+    HIPCHK(hipGetLastError());
     return 0;
 }
 
@@ -1428,25 +1512,31 @@ static bool resident_eligible(exaadmm_handle* h)
     if (getenv("EXAADMM_NO_RESIDENT") != nullptr) return false;
     if (const char* e = getenv("EXAADMM_RESIDENT"))
         if (atoi(e) == 0) return false;
-    return h->resident_ok && spec_eligible(h) && !dist_has_peers(h) && h->stream == h->own_stream &&
+    return h->resident_ok && h->resident_downgrades == 0 && spec_eligible(h) && !dist_has_peers(h) && h->stream == h->own_stream &&
            branch_blocks(h) + gen_blocks(h) + 1 <= resident_capacity(h);
 }
 
-// the failure flag of the resident launches travels with the download that ends the call (no round trip of its own):
-// resident_check_enqueue before that download's synchronisation, resident_check after it
+// The failure flag of the resident launches travels with the download that ends a batch (no round trip of its own):
+// resident_check_enqueue before that download's synchronisation, resident_failed after it.
 static int resident_check_enqueue(exaadmm_handle* h)
 {
-    HIPCHK(hipMemcpyAsync(h->h_base, h->rsync.fail, sizeof(int), hipMemcpyDeviceToHost, h->stream));   // (h_base: pinned, idle here)
+    HIPCHK(hipMemcpyAsync(&h->h_base[1], h->rsync.fail, sizeof(int), hipMemcpyDeviceToHost, h->stream));   // (pinned)
     return 0;
 }
-static int resident_check(exaadmm_handle* h)
+static bool resident_failed(const exaadmm_handle* h) { return h->h_base[1] != 0; }
+
+// A resident batch ran into a wait cap (a wavefront of the launch was not resident: the GPU is shared with other work), or
+// the runtime refused the cooperative launch: bring the iterate the call started from back and keep the two-launch loop on
+// this handle from here on.  The caller then repeats its loop; the call returns what it would have returned.
+static int resident_downgrade(exaadmm_handle* h)
 {
-    const int failed = *h->h_base;
-    if (failed != 0) {
-        set_err("resident loop: a wait ran into its cap (a wavefront of the launch was not resident: is the GPU shared?); EXAADMM_NO_RESIDENT=1 selects the two-launch loop");
-        return EXAADMM_ERR_HIP;
-    }
-    return 0;
+    int rc;
+    if ((rc = sync_check(h, true))) return rc;
+    if ((rc = resident_guard(h, true))) return rc;
+    h->resident_downgrades += 1;
+    if (getenv("EXAADMM_VERBOSE") != nullptr)
+        fprintf(stderr, "exaadmm: resident loop not co-resident on device %d (shared GPU?): batch repeated with the two-launch loop\n", h->device);
+    return sync_check(h, true);
 }
 
 static int spec_prepare(exaadmm_handle* h)
@@ -1466,7 +1556,7 @@ static int spec_prepare(exaadmm_handle* h)
         HIPCHK(hipMemcpyAsync(h->v_alt, h->d.v, (size_t)h->N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         if ((rc = dev_alloc(h, &h->d_dspec[0], 1))) return rc;
         if ((rc = dev_alloc(h, &h->d_dspec[1], 1))) return rc;
-        if (hipHostMalloc((void**)&h->h_base, sizeof(int), hipHostMallocDefault) != hipSuccess) {
+        if (hipHostMalloc((void**)&h->h_base, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess) {   // [0] batch base, [1] resident failure flag
             set_err("hipHostMalloc failed");
             return EXAADMM_ERR_HIP;
         }
@@ -1570,6 +1660,7 @@ static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
 {
     int rc = spec_prepare(h);
     if (rc) return rc;
+    const Ctrl ctrl0 = *hc;   // what exaadmm_run_inner has just uploaded (a downgraded resident call starts over from it)
     const int batch = 8;
     // RCCL calls are not captured: a partition with peers enqueues every batch directly
     const bool graph_ok = h->use_graph && h->stream == h->own_stream && !dist_has_peers(h);
@@ -1578,6 +1669,7 @@ static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
     bool first = true;
     const bool resident = resident_eligible(h);
     if (resident && (rc = resident_prepare(h))) return rc;
+    bool downgrade = false;
     while (enq < max_inner) {
         const int nb = std::min(resident ? 8 * batch : batch, max_inner - enq);   // (resident: one launch and one host round trip per 64 iterations)
         *h->h_base = enq;   // the stream is idle here (synchronised at the end of every batch)
@@ -1587,12 +1679,17 @@ static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
             // step timers of the reference cannot be told apart inside one launch: the sampled time of the first batch goes to
             // time_x_update.)
             if (first) (void)hipEventRecord(h->tev[0], h->stream);
-            if ((rc = enqueue_resident(h, nb))) return rc;
+            if ((rc = enqueue_resident(h, nb)) < 0) return rc;
+            if (rc > 0) {   // the runtime refused the cooperative launch
+                downgrade = true;
+                break;
+            }
             if (first) {
                 (void)hipEventRecord(h->tev[1], h->stream);
                 (void)hipEventRecord(h->tev[2], h->stream);
                 (void)hipEventRecord(h->tev[3], h->stream);
             }
+            if ((rc = resident_check_enqueue(h))) return rc;
         } else if (!first && graph_ok && nb == batch) {
             if (!h->spec_graph) {
                 hipGraph_t g = nullptr;
@@ -1614,6 +1711,10 @@ static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
         enq += nb;
         HIPCHK(hipMemcpyAsync(hc, h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
         if ((rc = sync_check(h, true))) return rc;
+        if (resident && resident_failed(h)) {   // checked after EVERY batch: the iterate of a failed batch is not a state of the algorithm
+            downgrade = true;
+            break;
+        }
         if (first) {
             for (int q = 0; q < 3; q++)
                 if (hipEventElapsedTime(&ms_sample[q], h->tev[q], h->tev[q + 1]) != hipSuccess) ms_sample[q] = 0.f;
@@ -1622,11 +1723,18 @@ static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
         }
         if (hc->done) break;   // (a partition: every rank sees the same sums, added in the same order -> the same decision)
     }
+    if (downgrade) {
+        // the inner loop starts over from the iterate it was entered with, on the two-launch loop (same results, bit for bit:
+        // tests/test_gpu_resident.py); the handle keeps that loop
+        if ((rc = resident_downgrade(h))) return rc;
+        *hc = ctrl0;
+        HIPCHK(hipMemcpyAsync(h->d_ctrl, hc, sizeof(Ctrl), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        return run_inner_spec(h, max_inner, hc);
+    }
     if ((rc = spec_complete_last(h, enq))) return rc;
     HIPCHK(hipMemcpyAsync(hc, h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
-    if (resident && (rc = resident_check_enqueue(h))) return rc;
     if ((rc = sync_check(h, true))) return rc;
-    if (resident && (rc = resident_check(h))) return rc;
     if ((rc = spec_finish(h, hc->inner))) return rc;
     for (int q = 0; q < 3; q++) h->acc_ms[q] += (double)ms_sample[q] * hc->inner;
     return 0;
@@ -1636,6 +1744,15 @@ extern "C" int exaadmm_loop_kind(exaadmm_handle* h, int* kind)
 {
     REQUIRE(h && kind, "null argument");
     *kind = !spec_eligible(h) ? 0 : (resident_eligible(h) ? 2 : 1);
+    return EXAADMM_OK;
+}
+
+// how many times a resident batch of this handle was found not co-resident (the GPU shared with other work), restored and
+// repeated with the two-launch loop; after the first the handle stays on that loop (exaadmm_loop_kind says 1)
+extern "C" int exaadmm_loop_downgrades(exaadmm_handle* h, int* count)
+{
+    REQUIRE(h && count, "null argument");
+    *count = h->resident_downgrades;
     return EXAADMM_OK;
 }
 
@@ -1811,50 +1928,66 @@ extern "C" int exaadmm_run_fixed(exaadmm_handle* h, int iters, int first_major_i
         // same kernels as the fused loop, with a control block that never stops
         int rc = spec_prepare(h);
         if (rc) return rc;
-        Ctrl* hc = h->h_ctrl;
-        memset(hc, 0, sizeof(Ctrl));
-        hc->max_inner = 0x7fffffff;
-        hc->check_every = 1;
-        hc->eps_pri = -1.0;
-        hc->beta = beta;
-        hc->base = first_major_iter - 1;
-        hc->first_iter = first_major_iter;
-        HIPCHK(hipMemcpyAsync(h->d_ctrl, hc, sizeof(Ctrl), hipMemcpyHostToDevice, h->stream));   // (hc is pinned and not written again before the call's final synchronisation)
-        const bool resident = resident_eligible(h);
-        if (resident && (rc = resident_prepare(h))) return rc;
-        HIPCHK(hipEventRecord(h->ev[0], h->stream));
-        if (resident) {
-            // ONE launch for all `iters` iterations: every wavefront stays resident, a bus is updated by the last lane to arrive at it
-            if (time_branch) HIPCHK(hipEventRecord(h->ev[2], h->stream));
-            if ((rc = enqueue_resident(h, iters))) return rc;
-            if (time_branch) HIPCHK(hipEventRecord(h->ev[3], h->stream));   // (one launch: its time / iters is reported)
-        } else
-            for (int i = 0; i < iters; i++)
-                if ((rc = enqueue_iteration_spec(h, h->d_ctrl, i, false, time_branch ? &h->ev[2 + 2 * i] : nullptr))) return rc;
-        if ((rc = spec_complete_last(h, iters))) return rc;
-        HIPCHK(hipEventRecord(h->ev[1], h->stream));
-        if ((rc = spec_finish(h, iters))) return rc;
-        double s[4];
-        if (resident && (rc = resident_check_enqueue(h))) return rc;
-        if ((rc = fetch_sums(h, s, true))) return rc;
-        if (resident && (rc = resident_check(h))) return rc;
-        if (out)
-            for (int j = 0; j < 4; j++) out[j] = s[j];
-        float ms = 0.f;
-        HIPCHK(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
-        if (ms_total) *ms_total = ms;
-        if (time_branch && resident) {
-            HIPCHK(hipEventElapsedTime(&ms, h->ev[2], h->ev[3]));
-            *ms_branch = (double)ms / iters;
-        } else if (time_branch) {
-            double acc = 0.0;
-            for (int i = 0; i < iters; i++) {
-                HIPCHK(hipEventElapsedTime(&ms, h->ev[2 + 2 * i], h->ev[3 + 2 * i]));
-                acc += ms;
+        for (int attempt = 0; attempt < 2; attempt++) {
+            Ctrl* hc = h->h_ctrl;
+            memset(hc, 0, sizeof(Ctrl));
+            hc->max_inner = 0x7fffffff;
+            hc->check_every = 1;
+            hc->eps_pri = -1.0;
+            hc->beta = beta;
+            hc->base = first_major_iter - 1;
+            hc->first_iter = first_major_iter;
+            HIPCHK(hipMemcpyAsync(h->d_ctrl, hc, sizeof(Ctrl), hipMemcpyHostToDevice, h->stream));   // (hc is pinned and not written again before the call's final synchronisation)
+            const bool resident = resident_eligible(h);
+            if (resident && (rc = resident_prepare(h))) return rc;
+            HIPCHK(hipEventRecord(h->ev[0], h->stream));
+            bool refused = false;
+            if (resident) {
+                // ONE launch for all `iters` iterations: every wavefront stays resident, a bus is updated by the last lane to arrive at it
+                if (time_branch) HIPCHK(hipEventRecord(h->ev[2], h->stream));
+                if ((rc = enqueue_resident(h, iters)) < 0) return rc;
+                refused = rc > 0;
+                if (time_branch) HIPCHK(hipEventRecord(h->ev[3], h->stream));   // (one launch: its time / iters is reported)
+            } else
+                for (int i = 0; i < iters; i++)
+                    if ((rc = enqueue_iteration_spec(h, h->d_ctrl, i, false, time_branch ? &h->ev[2 + 2 * i] : nullptr))) return rc;
+            if (resident) {
+                // a batch that was not co-resident is not a state of the algorithm: back to the iterate the call was entered
+                // with, and once more with the two-launch loop (resident_eligible is false from here on)
+                if (!refused) {
+                    if ((rc = resident_check_enqueue(h))) return rc;
+                    if ((rc = sync_check(h, true))) return rc;
+                }
+                if (refused || resident_failed(h)) {
+                    if ((rc = resident_downgrade(h))) return rc;
+                    continue;
+                }
             }
-            *ms_branch = acc / iters;
+            if ((rc = spec_complete_last(h, iters))) return rc;
+            HIPCHK(hipEventRecord(h->ev[1], h->stream));
+            if ((rc = spec_finish(h, iters))) return rc;
+            double s[4];
+            if ((rc = fetch_sums(h, s, true))) return rc;
+            if (out)
+                for (int j = 0; j < 4; j++) out[j] = s[j];
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+            if (ms_total) *ms_total = ms;
+            if (time_branch && resident) {
+                HIPCHK(hipEventElapsedTime(&ms, h->ev[2], h->ev[3]));
+                *ms_branch = (double)ms / iters;
+            } else if (time_branch) {
+                double acc = 0.0;
+                for (int i = 0; i < iters; i++) {
+                    HIPCHK(hipEventElapsedTime(&ms, h->ev[2 + 2 * i], h->ev[3 + 2 * i]));
+                    acc += ms;
+                }
+                *ms_branch = acc / iters;
+            }
+            return EXAADMM_OK;
         }
-        return EXAADMM_OK;
+        set_err("internal: the two-launch loop was not selected after a resident downgrade");
+        return EXAADMM_ERR_HIP;
     }
     HIPCHK(hipEventRecord(h->ev[0], h->stream));
     for (int i = 0; i < iters; i++) {

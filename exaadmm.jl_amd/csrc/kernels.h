@@ -985,7 +985,8 @@ __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group_t(const Ctrl* ctrl, Ctr
 // boundaries, the bus launch and two rounds of loads: 57.8 -> 52 us per iteration at 13 659 buses, whole solve 7.5 k -> 9.5 k it/s.
 // Same arithmetic per lane, same order in every sum: bitwise the two-launch loop (tests/test_gpu_resident.py).
 // Every wait is capped: a wavefront that cannot become resident (the GPU shared with other work) ends the launch with
-// rs.fail set and the call with an error instead of a hang.
+// rs.fail set; the host then restores the iterate the call started from and repeats the loop with two launches per iteration
+// (exaadmm_hip.hip resident_downgrade) -- the call does not fail and does not hang.
 // What wavefronts hand to each other -- sum terms, bus results, counters, flags -- is written and read with agent-scope
 // (sc1) accesses: they go to the coherence point themselves, so no L2 write-back / invalidate (agent-scope fence) is needed
 // inside the loop; s_waitcnt vmcnt(0) between the data and the flag / counter that announces them orders them.  With agent-scope fences the loop ran at 84 us per
@@ -1083,12 +1084,19 @@ __device__ __forceinline__ void bus_from_rec4(const Dev& d, const double* __rest
 
 __device__ __forceinline__ bool resident_wait(const int* flag, int want, int* fail)
 {
-    // polls are RELAXED loads (an acquire poll invalidates the XCD's L2 for everybody, hundreds of waiting wavefronts at a
-    // time: the working wavefronts slowed down 2.6 x); ONE acquire fence once the flag is seen
+    // Polls are RELAXED agent-scope loads (an acquire poll invalidates the XCD's L2 for everybody, hundreds of waiting
+    // wavefronts at a time: the working wavefronts slowed down 2.6 x).  There is NO fence behind the poll, only a compiler
+    // barrier: the invariant of the loop is that EVERY word one wavefront hands to another -- terms, bus results, residual
+    // terms, counters, flags -- is written with st_agent / an agent-scope atomic and read with ld_agent, i.e. performed at the
+    // device's coherence point and never served from a per-XCD L2 line; the writer's s_waitcnt vmcnt(0) between data and
+    // flag makes the flag the later event there.  A plain load of hand-over data would be a bug (stale L2 across XCDs).
+    // The wait is capped, and a wavefront that sees another one's failure gives up at once (one failed wait would otherwise
+    // cost every waiter its own cap): the launch ends with rs.fail set and the host repeats the batch with the two-launch loop.
     int spins = 0;
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-        if (++spins > (1 << 20)) {
-            *fail = 1;
+        ++spins;
+        if (spins > (1 << 20) || ((spins & 255) == 0 && __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return false;
         }
         __builtin_amdgcn_s_sleep(24);
@@ -1122,7 +1130,9 @@ __device__ __forceinline__ void resident_arrive(const Dev& d, const ResidentSync
 // other wavefront has contributed its terms of that pass (contrib counter), in the reduction order of the bus launch's
 // reduction block (same bits), and published through `decided`; a wavefront reads it before the z / l pass of the NEXT index
 // overwrites the iterate that would be final -- exactly the one-launch speculation of the two-launch loop.
-__device__ __forceinline__ int resident_passes(const Ctrl* ctrl, int i) { return (i + 1) - ((ctrl->base + 1 == ctrl->first_iter) ? 1 : 0); }
+// (first_has_zl is read from the control block ONCE, at kernel entry: the control wavefront rewrites that cache line with
+//  plain stores while the launch runs)
+__device__ __forceinline__ int resident_passes(bool first_has_zl, int i) { return (i + 1) - (first_has_zl ? 0 : 1); }
 
 __device__ __forceinline__ void resident_contribute(const Dev& d, const ResidentSync& rs, int parity, const double (&zs)[4])
 {
@@ -1154,7 +1164,7 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident(const Dev* __restrict_
     const int lane = threadIdx.x;
     if ((int)blockIdx.x == nwork) {
         // ---------------- control wavefront: one decision per z / l pass
-        const int npass = resident_passes(ctrl, iters - 1);
+        const int npass = resident_passes(first_has_zl, iters - 1);
         for (int p = 1; p <= npass; p++) {
             if (!resident_wait(rs.contrib, p * nwork, rs.fail)) return;
             const int i = p - (first_has_zl ? 1 : 0);     // index whose prologue made pass p
@@ -1194,7 +1204,7 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident(const Dev* __restrict_
         const int I = dp0->gen_bus2[2 * g], cnt = dp0->gen_bus2[2 * g + 1];
         int i = 0;
         for (; i < iters; i++) {
-            if (i > 0 && !resident_go_on(rs, resident_passes(ctrl, i - 1))) return;   // (wave-uniform)
+            if (i > 0 && !resident_go_on(rs, resident_passes(first_has_zl, i - 1))) return;   // (wave-uniform)
             const Dev& d = (i & 1) ? *dp1 : *dp0;
             const bool do_zl = (i > 0) || first_has_zl;
             double zs[4] = {0.0, 0.0, 0.0, 0.0};
@@ -1258,7 +1268,7 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident(const Dev* __restrict_
     const int Lp = dp0->Lp;
     const int base = 2 * dp0->Gp + b;
     for (int i = 0; i < iters; i++) {
-        if (i > 0 && !resident_go_on(rs, resident_passes(ctrl, i - 1))) return;   // (wave-uniform: the loop has stopped)
+        if (i > 0 && !resident_go_on(rs, resident_passes(first_has_zl, i - 1))) return;   // (wave-uniform: the loop has stopped)
         const Dev& d = (i & 1) ? *dp1 : *dp0;
         const int4 bus4 = reinterpret_cast<const int4*>(d.br_bus4)[b];
         const int rec_from = d.rec_br[2 * b], rec_to = d.rec_br[2 * b + 1];

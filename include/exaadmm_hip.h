@@ -157,6 +157,12 @@ int exaadmm_branch_kernel_occupancy(exaadmm_handle *h, int *waves_per_simd);
  * 0 = four launches per iteration, 1 = two launches per iteration (speculative loop), 2 = resident loop (one launch per
  * batch of iterations, every wavefront resident; EXAADMM_NO_RESIDENT=1 selects 1) */
 int exaadmm_loop_kind(exaadmm_handle *h, int *kind);
+/* The resident loop needs every wavefront of its launch on the chip at once.  When that turns out not to hold (the GPU is
+ * shared with other work: a capped wait inside the launch reports it, or the runtime refuses the cooperative launch) the
+ * call restores the iterate it started from, repeats its loop with two launches per iteration and returns what it would
+ * have returned -- the reference's loop cannot fail there either (admm_two_level.jl:34-63); the handle then stays on
+ * that loop.  count = how often that has happened on this handle (0 or 1). */
+int exaadmm_loop_downgrades(exaadmm_handle *h, int *count);
 
 /* ---- fused: control stays on the device side ---- */
 /* Inner while-loop of admm_two_level (admm_two_level.jl:34-63) for outer iteration `outer`:

@@ -108,3 +108,128 @@ def test_grids_with_more_wavefronts_than_simds_keep_the_two_launch_loop(pkg):
     mod = pkg.ModelAcopf(env)
     assert mod.loop_kind() in (0, 1)       # 1 379 + 163 + 1 wavefronts do not fit 1 024 SIMDs
     mod.close()
+
+
+class _env:
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        for k, v in self.kv.items():
+            os.environ[k] = v
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.skipif(SWITCHED_OFF, reason="a switch of this run turns the resident loop off")
+@pytest.mark.parametrize("fail_at", [1, 2])
+def test_a_failed_resident_batch_is_restored_and_repeated_with_the_two_launch_loop(pkg, fail_at):
+    """The resident loop's only failure mode -- a wavefront of the launch is not on the chip (shared GPU), a wait hits its cap --
+    must not surface: the call restores the iterate it started from, repeats its loop with two launches per iteration, returns
+    OK with exactly the two-launch loop's results, and the handle remembers the downgrade.  The failure is injected into the
+    fail_at-th resident launch of the handle (the first batch of a loop / a later batch of a convergence-tested loop)."""
+    syn = exaadmm_loader.load_submodule("synthetic")
+    g = syn.sized_like("case1354pegase", seed=0)
+    runs = []
+    for inject in (False, True):
+        with _env(**({"EXAADMM_RESIDENT_TEST_FAIL": str(fail_at)} if inject else {"EXAADMM_NO_RESIDENT": "1"})):
+            env = pkg.AdmmEnv("case1354pegase", 1e1, 1e3, verbose=0, grid=g)
+            mod = pkg.ModelAcopf(env)
+            assert mod.loop_kind() == (2 if inject else 1) and mod.loop_downgrades() == 0
+            out = []
+            inner, res = mod.run_inner(1, 150, 1e3)          # three resident batches of 64 / two-launch batches of 8
+            out.append(_state(mod) + [res.copy(), np.array([inner])])
+            norms, _, _ = mod.run_fixed(21, first_major_iter=inner + 1, beta=1e3)
+            out.append(_state(mod) + [norms.copy()])
+            if inject:
+                assert mod.loop_downgrades() == 1 and mod.loop_kind() == 1
+            runs.append(out)
+            mod.close()
+    for a, b in zip(runs[0], runs[1]):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+
+
+@pytest.mark.skipif(SWITCHED_OFF, reason="a switch of this run turns the resident loop off")
+def test_injected_failure_in_a_fixed_count_run_and_in_a_whole_solve(pkg):
+    syn = exaadmm_loader.load_submodule("synthetic")
+    g = syn.sized_like("case1354pegase", seed=1)
+    res = []
+    for inject in (False, True):
+        with _env(**({"EXAADMM_RESIDENT_TEST_FAIL": "1"} if inject else {"EXAADMM_NO_RESIDENT": "1"})):
+            env = pkg.AdmmEnv("case1354pegase", 1e1, 1e3, verbose=0, grid=g)
+            mod = pkg.ModelAcopf(env)
+            norms, _, _ = mod.run_fixed(37, first_major_iter=1, beta=1e3)
+            st = _state(mod) + [norms.copy()]
+            assert mod.loop_downgrades() == (1 if inject else 0)
+            mod.close()
+            env2, mod2 = pkg.solve_acopf("case1354pegase", grid=g, rho_pq=1e1, rho_va=1e3, outer_iterlim=3, inner_iterlim=200, verbose=0)
+            i = mod2.info
+            st += [np.array([i.outer, i.cumul]), np.array([i.objval, i.primres, i.mismatch]), mod2.solution.u_curr.copy(), mod2.solution.v_curr.copy()]
+            assert mod2.loop_downgrades() == (1 if inject else 0)
+            mod2.close()
+            res.append(st)
+    for x, y in zip(res[0], res[1]):
+        assert np.array_equal(x, y)
+
+
+_CONTENDER = r'''
+import hashlib, json, os, sys, time
+sys.path.insert(0, %(root)r)
+import numpy as np
+import exaadmm_loader
+pkg = exaadmm_loader.load_package(); pkg.library()
+syn = exaadmm_loader.load_submodule("synthetic")
+g = syn.sized_like("case13659pegase", seed=0)
+env = pkg.AdmmEnv("case13659pegase", 5e1, 5e3, verbose=0, grid=g)
+mod = pkg.ModelAcopf(env)
+kind0 = mod.loop_kind()
+open(%(flag)r + str(os.getpid()), "w").write("ready")
+while len([f for f in os.listdir(os.path.dirname(%(flag)r)) if f.startswith(os.path.basename(%(flag)r))]) < %(n)d:
+    time.sleep(0.01)                       # all contenders start their loops together
+t0 = time.time()
+h = hashlib.sha256()
+it = 1
+for K in (300, 300, 300):
+    norms, _, _ = mod.run_fixed(K, first_major_iter=it, beta=1e3)
+    it += K
+    for v in (mod.solution.u_curr, mod.solution.v_curr, mod.solution.z_curr, mod.solution.l_curr, norms):
+        h.update(np.ascontiguousarray(v).tobytes())
+print("RESULT " + json.dumps({"digest": h.hexdigest(), "kind_before": kind0, "kind_after": mod.loop_kind(),
+                              "downgrades": mod.loop_downgrades(), "seconds": time.time() - t0}))
+'''
+
+
+@pytest.mark.skipif(SWITCHED_OFF, reason="a switch of this run turns the resident loop off")
+def test_three_processes_share_the_gpu_and_all_finish_with_the_same_bits(tmp_path):
+    """Three processes run the 13 659-bus grid on ONE GPU at the same time: 3 x 385 wavefronts do not fit 1 024 SIMDs, so not
+    every resident launch can have all its wavefronts on the chip.  Whatever the hardware scheduler does -- it may serialise the
+    launches (everybody stays resident) or interleave them (waits hit their cap: downgrade) -- every process must finish, with
+    status OK and the bits of an undisturbed run."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    flag = str(tmp_path / "ready_")
+    code = _CONTENDER % {"root": ROOT, "flag": flag, "n": 3}
+    procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for _ in range(3)]
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=900)
+        assert p.returncode == 0, (o[-1500:], e[-3000:])
+        outs.append(json.loads([l for l in o.splitlines() if l.startswith("RESULT ")][-1][7:]))
+    alone = subprocess.run([sys.executable, "-c", _CONTENDER % {"root": ROOT, "flag": str(tmp_path / "alone_"), "n": 1}],
+                           capture_output=True, text=True, timeout=900)
+    assert alone.returncode == 0, alone.stderr[-3000:]
+    ref = json.loads([l for l in alone.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert ref["kind_before"] == 2 and ref["downgrades"] == 0
+    print("contended runs:", outs, "alone:", ref)
+    for o in outs:
+        assert o["digest"] == ref["digest"], (o, ref)
+        assert o["kind_before"] == 2 and o["kind_after"] == (1 if o["downgrades"] else 2)

@@ -154,7 +154,9 @@ def main():
     ap.add_argument("--repeats", type=int, default=0,
                     help="how many times the K-step timed region is repeated (the median is reported); 0 = as many as fill "
                          "--gpu-seconds of GPU time")
-    ap.add_argument("--gpu-seconds", type=float, default=1.0)
+    ap.add_argument("--gpu-seconds", type=float, default=6.0,
+                    help="GPU time to spend on the repeated timed region (all GPU legs run BEFORE the CPU legs, long enough for the "
+                         "driver's utilisation sampling to see them)")
     ap.add_argument("--periods", type=int, default=1,
                     help="T > 1: multi-period ACOPF (SURVEY.md §8 f4) over T load levels of the same grid, one time-expanded device model")
     args = ap.parse_args()
@@ -248,7 +250,7 @@ def main():
     regions = []
     dt, norms, ms_total = region(done + 1)
     regions.append(dt)
-    repeats = 1 if args.repeats == 1 else (args.repeats if args.repeats > 1 else max(1, min(4000, int(round(args.gpu_seconds / max(dt, 1e-6))))))
+    repeats = 1 if args.repeats == 1 else (args.repeats if args.repeats > 1 else max(1, min(20000, int(round(args.gpu_seconds / max(dt, 1e-6))))))
     for _ in range(repeats - 1):
         if not can_snapshot:
             done += args.steps
@@ -280,7 +282,9 @@ def main():
     # to arrive, residual sums and stop test inside; the figures below are per ITERATION of that launch), 1 = two launches per iteration
     resident = (T == 1 and hasattr(mod, "loop_kind") and mod.loop_kind() == 2)
     lib_version = pkg.library().exaadmm_version().decode()
-    pmc_file = os.path.join("profiles", "r03_pmc_summary.json")
+    pmc_file = os.path.join("profiles", "r04_pmc_summary.json")
+    if not os.path.exists(os.path.join(ROOT, pmc_file)):
+        pmc_file = os.path.join("profiles", "r03_pmc_summary.json")
     traffic_source = "none: %s has no entry for this workload" % pmc_file
     try:
         pmc = json.load(open(os.path.join(ROOT, pmc_file)))
@@ -293,6 +297,15 @@ def main():
     except Exception as e:
         traffic_source = "none: %s unreadable (%s)" % (pmc_file, e)
     occ = mod.branch_kernel_occupancy() if hasattr(mod, "branch_kernel_occupancy") else None
+    # registers / spills / LDS of the dominant kernel, from the remarks of the library's own compile (csrc/Makefile ->
+    # exaadmm.jl_amd/kernel_resources.json, which carries the digest of the sources it belongs to)
+    kernel_resources = None
+    try:
+        kr = json.load(open(os.path.join(ROOT, "exaadmm.jl_amd", "kernel_resources.json")))
+        if kr.get("source_digest") and ("src:" + kr["source_digest"]) in lib_version:
+            kernel_resources = kr["kernels"].get("k_resident" if resident else ("k_branch_t<true,false>" if T > 1 else "k_branch_t<false,true>"))
+    except Exception:
+        pass
     branch_bytes = BYTES_PER_BRANCH_SOLVE * L
     fused_zl = (T == 1 and not os.environ.get("EXAADMM_NO_SPEC") and os.environ.get("EXAADMM_BUS_KERNEL") != "lane")
     if fused_zl:
@@ -331,6 +344,7 @@ def main():
                      # HBM is the wrong roof at the named sizes (state is Infinity-Cache resident, the kernel is the FP64
                      # dependent-issue chain of its slowest lane): occupancy and VALU utilisation say how it is bound
                      "waves_per_simd": occ, "waves_launched_per_simd": ((L + 63) // 64) / 1024.0,
+                     "kernel_resources": kernel_resources,
                      "valu_busy": valu_busy, "traffic_source": traffic_source, "library_version": lib_version,
                      "note": "latency/FP64-issue bound: state is Infinity-Cache resident; traffic / valu_busy come from the "
                              "rocprofv3 --pmc passes of this command (traffic_source); see DESIGN.md"},

@@ -128,21 +128,35 @@ struct FlowTrig {
 // (the minimax coefficients of fdlibm's __kernel_sin / __kernel_cos, < 1 ulp on that interval) need no argument reduction:
 // ~20 multiply-adds instead of the library call (441 clocks for a lone wavefront, scripts/microbench/valu_latency.hip).
 // Larger angles take the library call.
+// the two kernel polynomials, valid for |t| <= pi/4 (host-callable: tests/test_device_code_on_host.py compares them with libm over
+// the whole interval -- <= 1 ulp, exact at 0 -- so that a wrong coefficient is a failed CPU test, not a few extra
+// iteration-count mismatches in the GPU statistics)
+EXA_HD void sincos_quarter_pi(double t, double& sn, double& cs)
+{
+#if defined(__clang__)
+#pragma clang fp contract(off)   // every instantiation of the kernels must round this the same way: the fusions are written out
+#endif
+    const double z = t * t;
+    const double rs = fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08), 2.75573137070700676789e-06),
+                                 -1.98412698298579493134e-04), 8.33333333332248946124e-03);
+    sn = fma(z * t, fma(z, rs, -1.66666666666666324348e-01), t);
+    const double rc = z * fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07),
+                                              2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+    const double hz = 0.5 * z;
+    const double w = 1.0 - hz;
+    cs = w + fma(z, rc, (1.0 - w) - hz);
+}
+
+// EXA_FAST_SINCOS: on in the default device build, off in the exact-arithmetic build and in host builds (which may switch it on)
+#if !defined(EXA_FAST_SINCOS) && defined(__HIP_DEVICE_COMPILE__) && !defined(EXA_EXACT_ORACLE_ARITH)
+#define EXA_FAST_SINCOS 1
+#endif
 EXA_HD void angle_sincos(const double (&x)[6], double& sn, double& cs)
 {
     const double t = x[2] - x[3];
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(EXA_EXACT_ORACLE_ARITH)
+#if defined(EXA_FAST_SINCOS) && EXA_FAST_SINCOS
     if (fabs(t) <= 0.78539816339744830962) {
-#pragma clang fp contract(off)   // every instantiation of the kernels must round this the same way: the fusions are written out
-        const double z = t * t;
-        const double rs = fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08), 2.75573137070700676789e-06),
-                                     -1.98412698298579493134e-04), 8.33333333332248946124e-03);
-        sn = fma(z * t, fma(z, rs, -1.66666666666666324348e-01), t);
-        const double rc = z * fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07),
-                                                  2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
-        const double hz = 0.5 * z;
-        const double w = 1.0 - hz;
-        cs = w + fma(z, rc, (1.0 - w) - hz);
+        sincos_quarter_pi(t, sn, cs);
         return;
     }
 #endif

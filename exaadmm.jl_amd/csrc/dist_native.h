@@ -36,6 +36,9 @@ struct RcclApi {
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    // optional (reporting only): how many ranks the communicator really has, which RCCL it is
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
 };
 
 struct exaadmm_dist {
@@ -49,6 +52,18 @@ struct exaadmm_dist {
     int n_cut = 0;
     double *send = nullptr, *recv = nullptr, *local = nullptr;
     int *d_pos = nullptr, *d_off = nullptr, *d_rcode = nullptr, *d_rpos = nullptr;
+    // the exchange of an iteration runs on its own stream, beside the interior branch solves of the next iteration
+    hipStream_t xstream = nullptr;
+    std::vector<hipEvent_t> ev;        // fork / join and per-iteration hand-over events (also inside a captured batch)
+    hipEvent_t xev[2] = {nullptr, nullptr};   // around one sampled exchange (group + unpack) per directly enqueued batch
+    bool xev_armed = false;
+    double exchange_us_sum = 0.0;
+    int64_t exchange_us_n = 0;
+    // a batch of iterations INCLUDING its exchanges as one hipGraph: offered when the bound RCCL captured, instantiated and
+    // replayed a sums exchange with every peer at connect time (dist_probe); otherwise every batch is enqueued directly
+    bool graph_ok = false;
+    int64_t graph_batches = 0, direct_batches = 0;
+    int probe_result = -1;   // -1 not run, 0 capture refused (direct enqueue), 1 captured exchange replayed correctly
 };
 
 static RcclApi g_rccl;   // process-wide function table
@@ -103,6 +118,8 @@ static int rccl_bind(RcclApi* out)
         EXA_SYM(Recv, "ncclRecv");
         EXA_SYM(GetErrorString, "ncclGetErrorString");
 #undef EXA_SYM
+        *(void**)(&b.CommCount) = dlsym(lib, "ncclCommCount");
+        *(void**)(&b.GetVersion) = dlsym(lib, "ncclGetVersion");
         if (missing) {   // a rejected library leaves nothing behind: no handle, no half-filled table, no path
             set_err("RCCL symbol %s missing in %s", missing, path.c_str());
             (void)dlclose(lib);
@@ -125,7 +142,39 @@ static int rccl_bind(RcclApi* out)
         }                                                                                                  \
     } while (0)
 
+static int dist_probe(exaadmm_handle* h);
 static bool dist_has_peers(const exaadmm_handle* h) { return h->dist != nullptr && h->dist->nranks > 1; }
+static bool dist_graph_allowed(const exaadmm_handle* h) { return h->dist != nullptr && h->dist->graph_ok; }
+static void dist_graph_refused(exaadmm_handle* h)
+{
+    if (h->dist) h->dist->graph_ok = false;
+}
+static thread_local int64_t g_exchanges = 0;
+static void dist_count_batch(exaadmm_handle* h, bool graph, int exchanges)
+{
+    if (!h->dist) return;
+    (graph ? h->dist->graph_batches : h->dist->direct_batches) += 1;
+    g_exchanges += exchanges;   // (a replayed batch enqueues its exchanges without passing through dist_exchange)
+}
+// arm = true: the next directly enqueued batch brackets ONE of its exchanges (group + unpack) with HIP events on the exchange
+// stream; arm = false (after the batch's synchronisation): read them
+static void dist_sample_exchange(exaadmm_handle* h, bool arm)
+{
+    exaadmm_dist* d = h->dist;
+    if (!d || !d->xev[0]) return;
+    if (arm) {
+        d->xev_armed = true;
+        return;
+    }
+    if (!d->xev_armed) return;
+    d->xev_armed = false;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, d->xev[0], d->xev[1]) == hipSuccess && ms > 0.f) {
+        d->exchange_us_sum += 1e3 * (double)ms;
+        d->exchange_us_n += 1;
+    } else
+        (void)hipGetLastError();
+}
 static int64_t nvar_for_tolerances(const exaadmm_handle* h) { return h->dist ? h->dist->nvar_global : h->nvar_ctrl; }
 
 extern "C" int exaadmm_dist_unique_id(void* out, int64_t nbytes)
@@ -147,7 +196,12 @@ extern "C" int exaadmm_dist_detach(exaadmm_handle* h)
     if (!d) return EXAADMM_OK;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
+    if (d->xstream) (void)hipStreamSynchronize(d->xstream);
     if (d->comm) (void)d->api.CommDestroy(d->comm);
+    for (hipEvent_t e : d->ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : d->xev)
+        if (e) (void)hipEventDestroy(e);
+    if (d->xstream) (void)hipStreamDestroy(d->xstream);
     void* bufs[] = {d->send, d->recv, d->local, d->d_pos, d->d_off, d->d_rcode, d->d_rpos};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -213,6 +267,8 @@ static int dist_prepare_impl(exaadmm_handle* h, int nranks, int rank, int64_t nv
         if (p != rank) offs[p] = offs[(size_t)nranks + p] = (int)(d->msg_off[p] + 4 * d->ncut[p]);
     }
     if ((rc = rccl_bind(&d->api))) return rc;
+    HIPCHK(hipStreamCreateWithFlags(&d->xstream, hipStreamNonBlocking));
+    for (auto& e : d->xev) HIPCHK(hipEventCreate(&e));
     const size_t nbuf = (size_t)std::max<int64_t>(off, 4);
     HIPCHK(hipMalloc((void**)&d->send, nbuf * sizeof(double)));
     HIPCHK(hipMalloc((void**)&d->recv, nbuf * sizeof(double)));
@@ -279,6 +335,33 @@ extern "C" int exaadmm_dist_connect(exaadmm_handle* h, const void* unique_id, in
         g_err = keep;
         return EXAADMM_ERR_HIP;
     }
+    rc = dist_probe(h);   // (collective as well: every rank that got its communicator runs it)
+    if (rc != EXAADMM_OK) {
+        const std::string keep = g_err;
+        (void)exaadmm_dist_detach(h);
+        g_err = keep;
+    }
+    return rc;
+}
+
+// what the distributed loop of this handle did so far (bench.py's N > 1 line): ranks of the RCCL communicator as RCCL counts
+// them (-1: the bound library does not say), RCCL version code (0: unknown), mean duration in microseconds of the sampled
+// exchanges (group + unpack kernel, HIP events on the exchange stream; 0 when nothing was sampled), batches replayed from a
+// hipGraph / enqueued directly, result of the capture probe (-1 not run, 0 refused, 1 ok)
+extern "C" int exaadmm_dist_stats(exaadmm_handle* h, int* comm_ranks, int* rccl_version, double* exchange_us, int64_t* graph_batches,
+                                  int64_t* direct_batches, int* probe)
+{
+    REQUIRE(h && h->dist, "not a partition");
+    exaadmm_dist* d = h->dist;
+    int n = -1, v = 0;
+    if (d->comm && d->api.CommCount && d->api.CommCount(d->comm, &n) != ncclSuccess) n = -1;
+    if (d->api.GetVersion && d->api.GetVersion(&v) != ncclSuccess) v = 0;
+    if (comm_ranks) *comm_ranks = d->comm ? n : (d->nranks == 1 ? 1 : -1);
+    if (rccl_version) *rccl_version = v;
+    if (exchange_us) *exchange_us = d->exchange_us_n > 0 ? d->exchange_us_sum / (double)d->exchange_us_n : 0.0;
+    if (graph_batches) *graph_batches = d->graph_batches;
+    if (direct_batches) *direct_batches = d->direct_batches;
+    if (probe) *probe = d->probe_result;
     return EXAADMM_OK;
 }
 
@@ -293,12 +376,12 @@ extern "C" int exaadmm_dist_attach(exaadmm_handle* h, int nranks, int rank, cons
 }
 
 // number of grouped exchanges this handle has enqueued since it was attached (tests: exactly one per inner iteration)
-static thread_local int64_t g_exchanges = 0;
 extern "C" int64_t exaadmm_dist_exchange_count(void) { return g_exchanges; }
 
 // The one exchange: per peer one send and one receive of (its cut branches' v entries +) the four sums, grouped; then
-// the unpack kernel.  with_v = false: the sums only (end of an inner loop, ||z|| of the outer loop).
-static int dist_exchange(exaadmm_handle* h, const Dev& dv, bool with_v, Ctrl* c, double* out, int need_pending)
+// the unpack kernel, both on `stream`.  with_v = false: the sums only (end of an inner loop, ||z|| of the outer loop).
+// sums_mode: k_halo_unpack (0 = the message carries sums, 1 = if ctrl->pending says so, 2 = it carries none).
+static int dist_exchange(exaadmm_handle* h, const Dev& dv, bool with_v, Ctrl* c, double* out, int sums_mode, hipStream_t stream)
 {
     exaadmm_dist* d = h->dist;
     REQUIRE(d->comm != nullptr, "partition has peers but no communicator (exaadmm_dist_connect)");
@@ -308,8 +391,8 @@ static int dist_exchange(exaadmm_handle* h, const Dev& dv, bool with_v, Ctrl* c,
         if (p == d->rank) continue;
         const size_t off = (size_t)(with_v ? d->msg_off[p] : d->msg_off[p] + 4 * d->ncut[p]);
         const size_t n = (size_t)(with_v ? 4 * d->ncut[p] + 4 : 4);
-        bad = d->api.Send(d->send + off, n, ncclDouble, p, d->comm, h->stream);
-        if (bad == ncclSuccess) bad = d->api.Recv(d->recv + off, n, ncclDouble, p, d->comm, h->stream);
+        bad = d->api.Send(d->send + off, n, ncclDouble, p, d->comm, stream);
+        if (bad == ncclSuccess) bad = d->api.Recv(d->recv + off, n, ncclDouble, p, d->comm, stream);
     }
     const ncclResult_t ge = d->api.GroupEnd();   // always closed, also after a failed call inside the group
     if (bad != ncclSuccess || ge != ncclSuccess) {
@@ -318,8 +401,159 @@ static int dist_exchange(exaadmm_handle* h, const Dev& dv, bool with_v, Ctrl* c,
     }
     g_exchanges++;
     const int nc = with_v ? d->n_cut : 0;
-    hipLaunchKernelGGL(k_halo_unpack, grid_for(std::max(nc, 1), 256), dim3(256), 0, h->stream, dv, d->d_rcode, d->d_rpos, nc, c, out, need_pending);
+    hipLaunchKernelGGL(k_halo_unpack, grid_for(std::max(nc, 1), 256), dim3(256), 0, stream, dv, d->d_rcode, d->d_rpos, nc, c, out, sums_mode);
     return 0;
+}
+
+// Iterations [j0, j0 + n) of the fused loop on a partition with peers (j = position relative to ctrl->base; launch j uses the
+// buffer set j mod 3).  What an iteration consists of is what it consists of on one GPU -- branch launch (z / l pass of the
+// previous iteration in its prologue), bus launch -- plus ONE exchange; what changes is WHEN things may start.  Only a cut
+// branch's next solve needs the halo (the bus update never does), so the branch launch is split (exaadmm_create stores the
+// cut branches last):
+//     stream M :  ... Bus_j | Int_{j+1} ....................................| Bus_{j+1} | Int_{j+2} ...
+//     stream X :            | exchange_j | unpack_j | Cut_{j+1} |                      | exchange_{j+1} ...
+// Int = the blocks in front of the first cut branch + the generator blocks, Cut = the rest.  The iteration costs
+// max(interior solves, exchange + unpack + cut solves) + bus launch instead of their sum.  The stop test rides in unpack_j (it
+// needs the peers' sums of the z / l pass that launch j made for iteration j - 1), so Int_{j+1} runs TWO launches ahead of the
+// decision about iteration j - 1: three buffer sets (spec_prepare) keep that iterate intact, and every kernel that starts after
+// the decision returns at once (ctrl->done).  The host enqueues in the order of a software pipeline (Int_{j+1} BEFORE
+// exchange_j), so that the overlap also exists under a host-blocking communication library (the tests' stand-in).
+static int enqueue_dist_iterations(exaadmm_handle* h, Ctrl* c, int j0, int n, bool first_of_loop, hipEvent_t* bev)
+{
+    exaadmm_dist* d = h->dist;
+    // EXAADMM_DIST_OVERLAP=0 (A/B switch): everything on ONE stream, in the same order -- same results, the exchange fully exposed
+    const char* sw = getenv("EXAADMM_DIST_OVERLAP");
+    const bool overlap = (sw == nullptr || atoi(sw) != 0);
+    hipStream_t M = h->stream, X = overlap ? d->xstream : h->stream;
+    const int nb = branch_blocks(h), ng = gen_blocks(h), nbi = interior_blocks(h), nbus = (int)grid_for(h->B, BUS_BLOCK / BUS_W).x;
+    while ((int)d->ev.size() < 2 * n + 2) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        d->ev.push_back(e);
+    }
+    auto launch_int = [&](int j) {
+        if (nbi + ng <= 0) return;
+        if (bev) (void)hipEventRecord(bev[2 * (j - j0)], M);
+        hipLaunchKernelGGL((k_branch_t<false, true>), dim3(nbi + ng), dim3(BR_BLOCK), 0, M, h->d_dspec[j % 3][1], h->bo, h->par.scale, 0, c, ng, j, h->baseMVA);
+        if (bev) (void)hipEventRecord(bev[2 * (j - j0) + 1], M);
+    };
+    auto launch_cut = [&](int j) {
+        if (nb - nbi <= 0) return;
+        hipLaunchKernelGGL((k_branch_t<false, true>), dim3(nb - nbi), dim3(BR_BLOCK), 0, X, h->d_dspec[j % 3][2], h->bo, h->par.scale, 0, c, 0, j, h->baseMVA);
+    };
+    // fork: X joins behind whatever M has been given so far (state uploads, the previous batch)
+    if (overlap) {
+        HIPCHK(hipEventRecord(d->ev[0], M));
+        HIPCHK(hipStreamWaitEvent(X, d->ev[0], 0));
+    }
+    launch_int(j0);
+    launch_cut(j0);
+    int rc = 0;
+    for (int j = j0; j < j0 + n; j++) {
+        const Dev& dv = h->dspec[j % 3][0];
+        const bool has_sums = !(first_of_loop && j == j0);   // (the first launch of a loop has no z / l pass in its prologue)
+        hipEvent_t e_cut = d->ev[2 + 2 * (j - j0)], e_bus = d->ev[3 + 2 * (j - j0)];
+        if (overlap) {
+            HIPCHK(hipEventRecord(e_cut, X));
+            HIPCHK(hipStreamWaitEvent(M, e_cut, 0));
+        }
+        Ctrl* red = has_sums ? c : nullptr;
+        if (dv.rec != nullptr)
+            hipLaunchKernelGGL((k_bus_group_t<true>), dim3(nbus + (red ? 1 : 0)), dim3(BUS_BLOCK), 0, M, (const Ctrl*)c, red, (const double*)dv.rec, dv.EndCount, dv.SlotCode, dv.busc, dv.B, dv, h->baseMVA);
+        else
+            hipLaunchKernelGGL((k_bus_group_t<false>), dim3(nbus + (red ? 1 : 0)), dim3(BUS_BLOCK), 0, M, (const Ctrl*)c, red, (const double*)dv.rec, dv.EndCount, dv.SlotCode, dv.busc, dv.B, dv, h->baseMVA);
+        if (overlap) HIPCHK(hipEventRecord(e_bus, M));
+        if (j + 1 < j0 + n) launch_int(j + 1);
+        if (overlap) HIPCHK(hipStreamWaitEvent(X, e_bus, 0));
+        const bool sample = d->xev_armed && j == j0 + std::min(1, n - 1);
+        if (sample) (void)hipEventRecord(d->xev[0], X);
+        if ((rc = dist_exchange(h, dv, true, c, nullptr, has_sums ? 0 : 2, X))) break;
+        if (sample) (void)hipEventRecord(d->xev[1], X);
+        if (j + 1 < j0 + n) launch_cut(j + 1);
+    }
+    // join (also after a failed exchange: a capture in progress must see X return to M)
+    if (overlap) {
+        (void)hipEventRecord(d->ev[1], X);
+        (void)hipStreamWaitEvent(M, d->ev[1], 0);
+    }
+    if (rc) return rc;
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// Can the bound RCCL be captured?  Collective over the ranks, at connect time: one sums exchange enqueued directly (it also
+// opens every peer connection before anything is captured), then the same exchange captured into a hipGraph, instantiated
+// and replayed twice.  A rank whose capture fails still takes part in the two exchanges (enqueued directly: the peers' sends
+// and receives match either way) and keeps enqueuing its batches directly from then on.  Every exchange is checked:
+// rank r contributes (1, 2, 3, 4) (r + 1).
+static int dist_probe(exaadmm_handle* h)
+{
+    exaadmm_dist* d = h->dist;
+    d->graph_ok = false;
+    d->probe_result = 0;
+    if (d->nranks <= 1 || d->comm == nullptr) return EXAADMM_OK;
+    hipStream_t X = d->xstream;
+    const double mine[4] = {1.0 * (d->rank + 1), 2.0 * (d->rank + 1), 3.0 * (d->rank + 1), 4.0 * (d->rank + 1)};
+    const double tri = 0.5 * d->nranks * (d->nranks + 1);
+    double *d_in = nullptr, *d_out = nullptr;
+    HIPCHK(hipMalloc((void**)&d_in, 4 * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&d_out, 4 * sizeof(double)));
+    struct Free {
+        double *a, *b;
+        ~Free() { (void)hipFree(a); (void)hipFree(b); }
+    } free_on_exit{d_in, d_out};
+    HIPCHK(hipMemcpy(d_in, mine, sizeof(mine), hipMemcpyHostToDevice));
+    auto one = [&]() -> int {
+        hipLaunchKernelGGL(k_halo_pack_sums, dim3(1), dim3(64), 0, X, h->d, d_in, (const Ctrl*)nullptr);
+        return dist_exchange(h, h->d, false, nullptr, d_out, 0, X);
+    };
+    auto verify = [&](const char* what) -> int {
+        double got[4] = {0, 0, 0, 0};
+        HIPCHK(hipMemcpyAsync(got, d_out, sizeof(got), hipMemcpyDeviceToHost, X));
+        HIPCHK(hipStreamSynchronize(X));
+        for (int j = 0; j < 4; j++)
+            if (got[j] != (j + 1) * tri) {
+                set_err("exchange probe (%s): sum %d is %g, expected %g", what, j, got[j], (j + 1) * tri);
+                return EXAADMM_ERR_HIP;
+            }
+        HIPCHK(hipMemsetAsync(d_out, 0, 4 * sizeof(double), X));
+        return 0;
+    };
+    int rc;
+    if ((rc = one())) return rc;
+    if ((rc = verify("direct"))) return rc;
+    hipGraphExec_t exec = nullptr;
+    const char* sw = getenv("EXAADMM_DIST_GRAPH");   // (=0: A/B switch, every batch enqueued directly)
+    const bool want = h->use_graph && (sw == nullptr || atoi(sw) != 0);
+    if (want && hipStreamBeginCapture(X, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        const int crc = one();
+        hipGraph_t g = nullptr;
+        const hipError_t e = hipStreamEndCapture(X, &g);
+        if (crc == 0 && e == hipSuccess && g != nullptr && hipGraphInstantiate(&exec, g, nullptr, nullptr, 0) != hipSuccess) exec = nullptr;
+        if (crc != 0 || e != hipSuccess) exec = nullptr;
+        if (g) (void)hipGraphDestroy(g);
+    }
+    (void)hipGetLastError();
+    for (int rep = 0; rep < 2; rep++) {
+        if (exec) {
+            if (hipGraphLaunch(exec, X) != hipSuccess) {
+                (void)hipGetLastError();
+                (void)hipGraphExecDestroy(exec);
+                exec = nullptr;
+                if ((rc = one())) return rc;
+            } else
+                g_exchanges++;
+        } else if ((rc = one()))
+            return rc;
+        if ((rc = verify(exec ? "captured" : "direct, capture refused"))) {
+            if (exec) (void)hipGraphExecDestroy(exec);
+            return rc;
+        }
+    }
+    d->graph_ok = (exec != nullptr);
+    d->probe_result = d->graph_ok ? 1 : 0;
+    if (exec) (void)hipGraphExecDestroy(exec);
+    return EXAADMM_OK;
 }
 
 // Exercises every RCCL entry point the loop uses, on the handle's stream, with whatever communicator is attached: the
@@ -346,7 +580,7 @@ extern "C" int exaadmm_dist_selftest(exaadmm_handle* h, int64_t n, double* max_e
         const double mine[4] = {1.0 * (d->rank + 1), 2.0 * (d->rank + 1), 3.0 * (d->rank + 1), 4.0 * (d->rank + 1)};
         HIPCHK(hipMemcpyAsync(h->d_sums, mine, sizeof(mine), hipMemcpyHostToDevice, h->stream));
         hipLaunchKernelGGL(k_halo_pack_sums, dim3(1), dim3(64), 0, h->stream, h->d, h->d_sums, (const Ctrl*)nullptr);
-        int rc = dist_exchange(h, h->d, false, nullptr, h->d_sums, 0);
+        int rc = dist_exchange(h, h->d, false, nullptr, h->d_sums, 0, h->stream);
         if (rc) return rc;
         double got[4];
         HIPCHK(hipMemcpyAsync(got, h->d_sums, sizeof(got), hipMemcpyDeviceToHost, h->stream));

@@ -113,10 +113,19 @@ struct exaadmm_handle {
     // the two Dev variants (odd / even iteration) on host and device, a pinned word for the batch base.
     // EXAADMM_NO_SPEC=1 (A/B switch) runs the plain four-launch loop instead.
     bool spec_on = false;
-    double *u_alt = nullptr, *ls1_alt = nullptr, *ls2_alt = nullptr, *mu_alt = nullptr;
-    int *st_alt[3] = {nullptr, nullptr, nullptr};   // per-branch counters of the alternate set (auglag, minor, ticks)
-    // (the z/l pass of an iteration rides in the NEXT branch launch's prologue: alternate v, per-block partial sums)
-    double *v_alt = nullptr, *partials_br = nullptr;
+    // the iterate rotates through `nsets` buffer sets (IterSet): launch i of a loop reads set (i - 1) mod nsets and writes set
+    // i mod nsets; sets[nsets - 1] is the PRIMARY set (h->d's own buffers: where every loop starts and where spec_finish brings
+    // the result back).  One GPU: 2 sets, z / l / z_prev updated in place.  A partition with peers: 3 sets, z and l rotate
+    // as well (kernels.h Dev::z_in), z_prev is materialised at the end of the loop.
+    struct IterSet {
+        double *u = nullptr, *v = nullptr, *ls1 = nullptr, *ls2 = nullptr, *mu = nullptr, *z = nullptr, *l = nullptr;
+        int* st[3] = {nullptr, nullptr, nullptr};
+    };
+    IterSet sets[3], alt[2];
+    int nsets = 0;
+    double *zp_scratch = nullptr, *partials_br = nullptr;
+    // branch blocks [0, nb_int) hold only branches whose two buses are local (exaadmm_create stores the cut branches last)
+    int n_interior = 0;
     // resident loop (kernels.h k_resident): the default loop of a single-period grid without peers whose wavefronts all fit
     // the chip at once (EXAADMM_NO_RESIDENT=1: A/B switch).  resident_cap = wavefronts of k_resident this device holds
     // at once (computed once per handle); resident_downgrades = batches that ran into a wait cap (the GPU was shared):
@@ -129,8 +138,11 @@ struct exaadmm_handle {
     std::vector<void*> guard;
     size_t nrec_slots = 0;
     ResidentSync rsync = {};
-    Dev dspec[2];
-    Dev* d_dspec[2] = {nullptr, nullptr};
+    // Dev variants of the fused loops, [i mod nsets][0 = whole launch, 1 = interior blocks + generators, 2 = cut blocks], on
+    // host and device; dfin[r]: what the pass that completes a loop's last iteration sees (spec_complete_last)
+    Dev dspec[3][3];
+    Dev* d_dspec[3][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    Dev dfin[3];
     int* h_base = nullptr;
     hipGraphExec_t spec_graph = nullptr;
     bool ctrl_mode = false;
@@ -388,14 +400,32 @@ extern "C" int exaadmm_create(const exaadmm_grid* g, const exaadmm_params* p, in
         exaadmm_default_params(&h->par);
     fill_branch_options(h);
     {
+        // storage order of the branches: own branches sorted by from-bus, a partition's replicas of a peer's cut branches (to-bus
+        // local) after them, sorted by to-bus -- and, among the own ones, those whose to-bus belongs to a peer LAST: every block
+        // in front of the first cut branch can start its next solve without waiting for the peers' halo (split launches)
         const int64_t la = g->nline_owned > 0 ? g->nline_owned : g->nline;
+        std::vector<char> in_fr(h->L, 0), in_to(h->L, 0);
+        // (the CSR arrays are validated further down, by build_csr: no more than nline entries are looked at here)
+        const int64_t nfr = std::min<int64_t>(std::max<int64_t>(g->FrStart[h->B] - g->index_base, 0), h->L);
+        const int64_t nto = std::min<int64_t>(std::max<int64_t>(g->ToStart[h->B] - g->index_base, 0), h->L);
+        for (int64_t k = 0; k < nfr; k++) {
+            const int64_t b = g->FrIdx[k] - g->index_base;
+            if (b >= 0 && b < h->L) in_fr[(size_t)b] = 1;
+        }
+        for (int64_t k = 0; k < nto; k++) {
+            const int64_t b = g->ToIdx[k] - g->index_base;
+            if (b >= 0 && b < h->L) in_to[(size_t)b] = 1;
+        }
         std::vector<int> order(h->L);
         for (int b = 0; b < h->L; b++) order[b] = b;
         std::vector<int64_t> key(h->L);
+        h->n_interior = 0;
         for (int b = 0; b < h->L; b++) {
             const bool own = b < la;
+            const bool cut = in_fr[b] != in_to[b];
             const int64_t bus = g->brBusIdx[2 * (size_t)b + (own ? 0 : 1)] - g->index_base;
-            key[b] = (own ? 0 : ((int64_t)1 << 40)) + bus;
+            key[b] = ((int64_t)(own ? (cut ? 1 : 0) : 2) << 40) + bus;
+            if (own && !cut) h->n_interior++;
         }
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key[a] < key[b]; });
         h->perm.assign(h->L, 0);
@@ -1139,7 +1169,11 @@ static int fetch_sums(exaadmm_handle* h, double out[4], bool take_sqrt)
 
 // a partition with peers (dist_native.h): one grouped send / receive per peer + the unpack kernel
 static bool dist_has_peers(const exaadmm_handle* h);
-static int dist_exchange(exaadmm_handle* h, const Dev& dv, bool with_v, Ctrl* c, double* out, int need_pending);
+static bool dist_graph_allowed(const exaadmm_handle* h);
+static void dist_graph_refused(exaadmm_handle* h);
+static void dist_count_batch(exaadmm_handle* h, bool graph, int exchanges);
+static void dist_sample_exchange(exaadmm_handle* h, bool arm);
+static int dist_exchange(exaadmm_handle* h, const Dev& dv, bool with_v, Ctrl* c, double* out, int sums_mode, hipStream_t stream);
 
 // ------------------------------------------------------------------ step-wise plugin surface
 extern "C" int exaadmm_inner_prestep(exaadmm_handle* h)
@@ -1271,7 +1305,7 @@ extern "C" int exaadmm_norm_z(exaadmm_handle* h, double* out)
     launch_final(h, nullptr);
     if (dist_has_peers(h)) {   // a partition: the owned elements' sum of squares, added over the ranks in rank order
         hipLaunchKernelGGL(k_halo_pack_sums, dim3(1), dim3(64), 0, h->stream, h->d, h->d_sums, (const Ctrl*)nullptr);
-        int rc = dist_exchange(h, h->d, false, nullptr, h->d_sums, 0);
+        int rc = dist_exchange(h, h->d, false, nullptr, h->d_sums, 0, h->stream);
         if (rc) return rc;
     }
     double s[4];
@@ -1488,7 +1522,7 @@ static int enqueue_resident(exaadmm_handle* h, int n)
     if (const char* e = getenv("EXAADMM_RESIDENT_TEST_FAIL"))   // tests: the n-th resident launch of a handle reports a failed wait
         if (atoi(e) == h->resident_launches) HIPCHK(hipMemsetAsync(h->rsync.fail, 0x01, 1, h->stream));
     if (h->resident_coop) {
-        const Dev *d0 = h->d_dspec[0], *d1 = h->d_dspec[1];
+        const Dev *d0 = h->d_dspec[0][0], *d1 = h->d_dspec[1][0];
         double scale = h->par.scale, base = h->baseMVA;
         void* args[] = {(void*)&d0, (void*)&d1, (void*)&h->bo, (void*)&scale, (void*)&h->d_ctrl, (void*)&ng, (void*)&base, (void*)&n, (void*)&h->rsync};
         const hipError_t e = hipLaunchCooperativeKernel((const void*)k_resident, dim3(nb + ng + 1), dim3(BR_BLOCK), args, 0, h->stream);
@@ -1497,7 +1531,7 @@ static int enqueue_resident(exaadmm_handle* h, int n)
         if (e != hipErrorCooperativeLaunchTooLarge) h->resident_coop = false;   // (not offered after all: plain launches from here on)
         else return 1;   // the runtime says the grid is not co-resident: the caller takes the two-launch loop
     }
-    hipLaunchKernelGGL(k_resident, dim3(nb + ng + 1), dim3(BR_BLOCK), 0, h->stream, h->d_dspec[0], h->d_dspec[1], h->bo, h->par.scale, h->d_ctrl, ng,
+    hipLaunchKernelGGL(k_resident, dim3(nb + ng + 1), dim3(BR_BLOCK), 0, h->stream, h->d_dspec[0][0], h->d_dspec[1][0], h->bo, h->par.scale, h->d_ctrl, ng,
                        h->baseMVA, n, h->rsync);
     HIPCHK(hipGetLastError());
     return 0;
@@ -1539,70 +1573,121 @@ static int resident_downgrade(exaadmm_handle* h)
     return sync_check(h, true);
 }
 
+static int interior_blocks(const exaadmm_handle* h) { return h->n_interior / BR_BLOCK; }   // whole blocks in front of the first cut branch
+
 static int spec_prepare(exaadmm_handle* h)
 {
-    if (!h->u_alt) {
-        int rc;
-        if ((rc = dev_alloc(h, &h->u_alt, (size_t)h->N))) return rc;
-        if ((rc = dev_alloc(h, &h->ls1_alt, (size_t)h->Lp))) return rc;
-        if ((rc = dev_alloc(h, &h->ls2_alt, (size_t)h->Lp))) return rc;
-        if ((rc = dev_alloc(h, &h->mu_alt, (size_t)h->Lp))) return rc;
-        for (auto& q : h->st_alt) {
-            if ((rc = dev_alloc(h, &q, (size_t)h->Lp))) return rc;
-            HIPCHK(hipMemsetAsync(q, 0, (size_t)h->Lp * sizeof(int), h->stream));
+    int rc;
+    const int want = dist_has_peers(h) ? 3 : 2;
+    // alternate buffer sets: one for the two-set loop, a second one (and alternates of z, l; a sink for the z_prev the kernels
+    // write) once the handle has peers
+    for (int q = 0; q < want - 1; q++) {
+        exaadmm_handle::IterSet& a = h->alt[q];
+        if (a.u) continue;
+        if ((rc = dev_alloc(h, &a.u, (size_t)h->N))) return rc;
+        if ((rc = dev_alloc(h, &a.v, (size_t)h->N))) return rc;
+        if ((rc = dev_alloc(h, &a.ls1, (size_t)h->Lp))) return rc;
+        if ((rc = dev_alloc(h, &a.ls2, (size_t)h->Lp))) return rc;
+        if ((rc = dev_alloc(h, &a.mu, (size_t)h->Lp))) return rc;
+        for (auto& c : a.st) {
+            if ((rc = dev_alloc(h, &c, (size_t)h->Lp))) return rc;
+            HIPCHK(hipMemsetAsync(c, 0, (size_t)h->Lp * sizeof(int), h->stream));
         }
-        if ((rc = dev_alloc(h, &h->v_alt, (size_t)h->N))) return rc;
+        // padding entries (never written by the branch kernel) must agree in all sets
+        HIPCHK(hipMemcpyAsync(a.u, h->d.u, (size_t)h->N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(a.v, h->d.v, (size_t)h->N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemsetAsync(a.ls1, 0, (size_t)h->Lp * sizeof(double), h->stream));
+        HIPCHK(hipMemsetAsync(a.ls2, 0, (size_t)h->Lp * sizeof(double), h->stream));
+        HIPCHK(hipMemsetAsync(a.mu, 0, (size_t)h->Lp * sizeof(double), h->stream));
+    }
+    if (want == 3 && !h->zp_scratch) {
+        for (int q = 0; q < 2; q++) {
+            if ((rc = dev_alloc(h, &h->alt[q].z, (size_t)h->N))) return rc;
+            if ((rc = dev_alloc(h, &h->alt[q].l, (size_t)h->N))) return rc;
+            HIPCHK(hipMemcpyAsync(h->alt[q].z, h->d.z, (size_t)h->N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(h->alt[q].l, h->d.l, (size_t)h->N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        }
+        if ((rc = dev_alloc(h, &h->zp_scratch, (size_t)h->N))) return rc;
+    }
+    if (!h->partials_br) {
         if ((rc = dev_alloc(h, &h->partials_br, (size_t)(branch_blocks(h) + gen_blocks(h)) * 4))) return rc;
-        HIPCHK(hipMemcpyAsync(h->v_alt, h->d.v, (size_t)h->N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-        if ((rc = dev_alloc(h, &h->d_dspec[0], 1))) return rc;
-        if ((rc = dev_alloc(h, &h->d_dspec[1], 1))) return rc;
+        for (auto& row : h->d_dspec)
+            for (auto& q : row)
+                if ((rc = dev_alloc(h, &q, 1))) return rc;
         if (hipHostMalloc((void**)&h->h_base, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess) {   // [0] batch base, [1] resident failure flag
             set_err("hipHostMalloc failed");
             return EXAADMM_ERR_HIP;
         }
-        // padding entries (never written by the branch kernel) must agree in both sets
-        HIPCHK(hipMemcpyAsync(h->u_alt, h->d.u, (size_t)h->N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-        HIPCHK(hipMemsetAsync(h->ls1_alt, 0, (size_t)h->Lp * sizeof(double), h->stream));
-        HIPCHK(hipMemsetAsync(h->ls2_alt, 0, (size_t)h->Lp * sizeof(double), h->stream));
-        HIPCHK(hipMemsetAsync(h->mu_alt, 0, (size_t)h->Lp * sizeof(double), h->stream));
     }
     flush_bus_const(h);
-    // odd iteration (j even): read the primary set, write the alternate one; even iteration: the reverse
-    Dev a = h->d, b = h->d;
-    a.u_in = h->d.u;      a.u = h->u_alt;
-    a.ls1_in = h->d.ls1;  a.ls1 = h->ls1_alt;
-    a.ls2_in = h->d.ls2;  a.ls2 = h->ls2_alt;
-    a.mu_in = h->d.mu;    a.mu = h->mu_alt;
-    // the per-branch counters follow the iterate: a launch that the stop test discards (it runs one iteration
-    // ahead) must not overwrite the counters of the last accepted x-update
-    a.st_auglag = h->st_alt[0];  a.st_minor = h->st_alt[1];  a.st_ticks = h->st_alt[2];
-    b.u_in = h->u_alt;    b.ls1_in = h->ls1_alt;  b.ls2_in = h->ls2_alt;  b.mu_in = h->mu_alt;
-    // v follows the same parity as u: the bus launch of an odd iteration writes the alternate v, which the next
-    // (even) iteration's branch launch reads
-    a.v_in = h->d.v;   a.v = h->v_alt;
-    b.v_in = h->v_alt; // b.v stays the primary buffer
-    a.partials_br = b.partials_br = h->partials_br;
-    a.npartials_br = b.npartials_br = branch_blocks(h) + gen_blocks(h);
-    if (memcmp(&a, &h->dspec[0], sizeof(Dev)) != 0 || memcmp(&b, &h->dspec[1], sizeof(Dev)) != 0) {
+    const int n = want;
+    exaadmm_handle::IterSet prim;
+    prim.u = h->d.u; prim.v = h->d.v; prim.ls1 = h->d.ls1; prim.ls2 = h->d.ls2; prim.mu = h->d.mu; prim.z = h->d.z; prim.l = h->d.l;
+    prim.st[0] = h->d.st_auglag; prim.st[1] = h->d.st_minor; prim.st[2] = h->d.st_ticks;
+    exaadmm_handle::IterSet sets[3];
+    for (int q = 0; q < n - 1; q++) sets[q] = h->alt[q];
+    sets[n - 1] = prim;
+    const int nb = branch_blocks(h), ng = gen_blocks(h), nbi = interior_blocks(h);
+    Dev var[3][3], fin[3];
+    for (int r = 0; r < n; r++) {
+        // launch i (i mod n = r) reads the iterate of launch i - 1 and writes its own set.  The per-branch counters follow the
+        // iterate: a launch that the stop test discards (it runs ahead) must not overwrite those of the last accepted x-update;
+        // v follows the same rotation: the bus launch of iteration i writes the v the next branch launch reads.
+        const exaadmm_handle::IterSet &w = sets[r], &rd = sets[(r + n - 1) % n];
+        Dev a = h->d;
+        a.u_in = rd.u;      a.u = w.u;
+        a.v_in = rd.v;      a.v = w.v;
+        a.ls1_in = rd.ls1;  a.ls1 = w.ls1;
+        a.ls2_in = rd.ls2;  a.ls2 = w.ls2;
+        a.mu_in = rd.mu;    a.mu = w.mu;
+        a.st_auglag = w.st[0];  a.st_minor = w.st[1];  a.st_ticks = w.st[2];
+        if (n == 3) {
+            // the z / l pass in launch i's prologue completes iteration i - 1: it reads z, l of iteration i - 2 and writes those of
+            // i - 1 into the set of iteration i - 1 (where the solve then finds them); the z_prev it writes is not kept
+            a.z = rd.z;  a.l = rd.l;
+            a.z_in = sets[(r + 1) % 3].z;  a.l_in = sets[(r + 1) % 3].l;
+            a.zp = h->zp_scratch;
+        }
+        a.partials_br = h->partials_br;
+        a.npartials_br = nb + ng;
+        a.blk0 = 0;
+        a.gen_part0 = nb;
+        var[r][0] = var[r][1] = var[r][2] = a;
+        var[r][2].blk0 = nbi;
+        // the pass that completes a loop's LAST launch (index i, r = (i + 1) mod n: what launch i + 1's prologue would have done):
+        // u, v of launch i are its inputs; in place on two sets
+        fin[r] = a;
+        fin[r].u = const_cast<double*>(a.u_in);
+        fin[r].v = const_cast<double*>(a.v_in);
+    }
+    bool changed = (h->nsets != n);
+    for (int r = 0; r < n && !changed; r++)
+        for (int q = 0; q < 3; q++) changed = changed || memcmp(&var[r][q], &h->dspec[r][q], sizeof(Dev)) != 0;
+    if (changed) {
         invalidate_graph(h);
-        h->dspec[0] = a;
-        h->dspec[1] = b;
-        HIPCHK(hipMemcpyAsync(h->d_dspec[0], &h->dspec[0], sizeof(Dev), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(h->d_dspec[1], &h->dspec[1], sizeof(Dev), hipMemcpyHostToDevice, h->stream));
+        h->nsets = n;
+        for (int r = 0; r < n; r++) {
+            h->sets[r] = sets[r];
+            h->dfin[r] = fin[r];
+            for (int q = 0; q < 3; q++) {
+                h->dspec[r][q] = var[r][q];
+                HIPCHK(hipMemcpyAsync(h->d_dspec[r][q], &h->dspec[r][q], sizeof(Dev), hipMemcpyHostToDevice, h->stream));
+            }
+        }
         HIPCHK(hipStreamSynchronize(h->stream));
     }
     return 0;
 }
 
-// iteration base + j + 1 of the loop (j = position inside the batch; base is even)
+// iteration base + j + 1 of the loop on ONE GPU (j = position inside the batch; base is a multiple of the number of sets)
 static int enqueue_iteration_spec(exaadmm_handle* h, Ctrl* c, int j, bool sample = false, hipEvent_t* bev = nullptr)
 {
-    const int par = j & 1;
-    const Dev& dv = h->dspec[par];
+    const int r = j % h->nsets;
+    const Dev& dv = h->dspec[r][0];
     const int nb = branch_blocks(h), ng = gen_blocks(h);
     if (sample) (void)hipEventRecord(h->tev[0], h->stream);
     if (bev) (void)hipEventRecord(bev[0], h->stream);
-    hipLaunchKernelGGL((k_branch_t<false, true>), dim3(nb + ng), dim3(BR_BLOCK), 0, h->stream, h->d_dspec[par], h->bo, h->par.scale, 0, c,
+    hipLaunchKernelGGL((k_branch_t<false, true>), dim3(nb + ng), dim3(BR_BLOCK), 0, h->stream, h->d_dspec[r][0], h->bo, h->par.scale, 0, c,
                        ng, j, h->baseMVA);
     if (bev) (void)hipEventRecord(bev[1], h->stream);
     if (sample) (void)hipEventRecord(h->tev[1], h->stream);
@@ -1612,10 +1697,6 @@ static int enqueue_iteration_spec(exaadmm_handle* h, Ctrl* c, int j, bool sample
     else
         hipLaunchKernelGGL((k_bus_group_t<false>), dim3(grid_for(h->B, BUS_BLOCK / BUS_W).x + 1), dim3(BUS_BLOCK), 0, h->stream, (const Ctrl*)c, c, (const double*)dv.rec, dv.EndCount, dv.SlotCode,
                            dv.busc, dv.B, dv, h->baseMVA);
-    if (dist_has_peers(h)) {
-        int rc = dist_exchange(h, dv, true, c, nullptr, 1);
-        if (rc) return rc;
-    }
     if (sample) {
         (void)hipEventRecord(h->tev[2], h->stream);
         (void)hipEventRecord(h->tev[3], h->stream);
@@ -1623,19 +1704,31 @@ static int enqueue_iteration_spec(exaadmm_handle* h, Ctrl* c, int j, bool sample
     return 0;
 }
 
-// after a loop of `iters` completed iterations the valid iterate sits in the alternate set when `iters` is odd:
-// bring it home so that every other entry point keeps using the primary buffers
+// iterations [j0, j0 + n) of a partition WITH PEERS (dist_native.h): the pipelined two-stream form of the same iteration
+static int enqueue_dist_iterations(exaadmm_handle* h, Ctrl* c, int j0, int n, bool first_of_loop, hipEvent_t* bev);
+
+// After a loop of `iters` completed iterations the valid iterate sits in set (iters - 1) mod nsets: bring it home so that
+// every other entry point keeps using the primary buffers.
 static int spec_finish(exaadmm_handle* h, int iters)
 {
-    if (iters & 1) {
-        HIPCHK(hipMemcpyAsync(h->d.u, h->u_alt, (size_t)h->N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(h->d.v, h->v_alt, (size_t)h->N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(h->d.ls1, h->ls1_alt, (size_t)h->Lp * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(h->d.ls2, h->ls2_alt, (size_t)h->Lp * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(h->d.mu, h->mu_alt, (size_t)h->Lp * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-        int* prim[3] = {h->d.st_auglag, h->d.st_minor, h->d.st_ticks};
+    if (iters <= 0) return 0;
+    const int n = h->nsets, f = (iters - 1) % n;
+    const size_t NB = (size_t)h->N * sizeof(double), LB = (size_t)h->Lp * sizeof(double);
+    const exaadmm_handle::IterSet &src = h->sets[f], &dst = h->sets[n - 1];
+    if (n == 3)   // z_prev of the final iterate = z of the iteration before it (before z itself is overwritten below)
+        HIPCHK(hipMemcpyAsync(h->d.zp, h->sets[(f + 2) % 3].z, NB, hipMemcpyDeviceToDevice, h->stream));
+    if (f != n - 1) {
+        HIPCHK(hipMemcpyAsync(dst.u, src.u, NB, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(dst.v, src.v, NB, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(dst.ls1, src.ls1, LB, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(dst.ls2, src.ls2, LB, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(dst.mu, src.mu, LB, hipMemcpyDeviceToDevice, h->stream));
         for (int q = 0; q < 3; q++)
-            HIPCHK(hipMemcpyAsync(prim[q], h->st_alt[q], (size_t)h->Lp * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(dst.st[q], src.st[q], (size_t)h->Lp * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+        if (n == 3) {
+            HIPCHK(hipMemcpyAsync(dst.z, src.z, NB, hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(dst.l, src.l, NB, hipMemcpyDeviceToDevice, h->stream));
+        }
     }
     return 0;
 }
@@ -1645,7 +1738,7 @@ static int spec_finish(exaadmm_handle* h, int iters)
 static int spec_complete_last(exaadmm_handle* h, int enqueued)
 {
     if (enqueued <= 0) return 0;
-    const Dev& dv = h->dspec[(enqueued - 1) & 1];   // the buffers the last enqueued iteration wrote
+    const Dev& dv = h->dfin[enqueued % h->nsets];   // u, v, (z, l) of the last enqueued iteration -> its z / l pass
     hipLaunchKernelGGL(k_fused_zl, dim3(h->ew_blocks), dim3(EW_BLOCK), 0, h->stream, dv, 0.0, h->d_ctrl, &h->d_ctrl->pending);
     if (!dist_has_peers(h)) {
         hipLaunchKernelGGL(k_final_reduce, dim3(1), dim3(EW_BLOCK), 0, h->stream, h->d.partials, h->ew_blocks, h->d_sums, h->d_ctrl, 1, 1);
@@ -1653,7 +1746,36 @@ static int spec_complete_last(exaadmm_handle* h, int enqueued)
     }
     hipLaunchKernelGGL(k_final_reduce, dim3(1), dim3(EW_BLOCK), 0, h->stream, h->d.partials, h->ew_blocks, h->d_sums, h->d_ctrl, 1, 0);
     hipLaunchKernelGGL(k_halo_pack_sums, dim3(1), dim3(64), 0, h->stream, h->d, h->d_sums, (const Ctrl*)h->d_ctrl);
-    return dist_exchange(h, h->d, false, h->d_ctrl, h->d_sums, 1);
+    return dist_exchange(h, h->d, false, h->d_ctrl, h->d_sums, 1, h->stream);
+}
+
+constexpr int DIST_BATCH = 12;   // iterations per host visit / per hipGraph of a partition with peers (a multiple of its three buffer sets)
+
+__global__ void k_ctrl_set_base(Ctrl* c, int base) { c->base = base; }
+
+// One full batch of a partition's loop (not the first of a loop: every launch has a z / l pass in front) as a hipGraph -- two
+// streams, interior / cut / bus launches, the exchanges, the unpack kernels.  Offered when the bound RCCL proved at connect
+// time that it can be captured (dist_probe); a capture that fails anyway leaves the handle on direct enqueue (nothing of it has run).
+static bool dist_batch_graph(exaadmm_handle* h)
+{
+    if (h->spec_graph) return true;
+    if (!(h->use_graph && h->stream == h->own_stream && dist_graph_allowed(h))) return false;
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal);
+    int crc = 0;
+    if (e == hipSuccess) {
+        crc = enqueue_dist_iterations(h, h->d_ctrl, 0, DIST_BATCH, false, nullptr);
+        e = hipStreamEndCapture(h->stream, &g);
+    }
+    if (e == hipSuccess && crc == 0) e = hipGraphInstantiate(&h->spec_graph, g, nullptr, nullptr, 0);
+    if (g) (void)hipGraphDestroy(g);
+    if (e != hipSuccess || crc != 0) {
+        (void)hipGetLastError();
+        h->spec_graph = nullptr;
+        dist_graph_refused(h);
+        return false;
+    }
+    return true;
 }
 
 static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
@@ -1661,9 +1783,10 @@ static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
     int rc = spec_prepare(h);
     if (rc) return rc;
     const Ctrl ctrl0 = *hc;   // what exaadmm_run_inner has just uploaded (a downgraded resident call starts over from it)
-    const int batch = 8;
-    // RCCL calls are not captured: a partition with peers enqueues every batch directly
-    const bool graph_ok = h->use_graph && h->stream == h->own_stream && !dist_has_peers(h);
+    const bool peers = dist_has_peers(h);
+    // iterations per host visit: 8 on one GPU, 12 on a partition with peers
+    const int batch = peers ? DIST_BATCH : 8;
+    const bool graph_ok = h->use_graph && h->stream == h->own_stream;
     float ms_sample[3] = {0.f, 0.f, 0.f};
     int enq = 0;
     bool first = true;
@@ -1690,7 +1813,10 @@ static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
                 (void)hipEventRecord(h->tev[3], h->stream);
             }
             if ((rc = resident_check_enqueue(h))) return rc;
-        } else if (!first && graph_ok && nb == batch) {
+        } else if (peers && !first && nb == batch && dist_batch_graph(h)) {
+            HIPCHK(hipGraphLaunch(h->spec_graph, h->stream));
+            dist_count_batch(h, true, batch);
+        } else if (!peers && !first && graph_ok && nb == batch) {
             if (!h->spec_graph) {
                 hipGraph_t g = nullptr;
                 HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
@@ -1704,6 +1830,10 @@ static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
                 }
             }
             HIPCHK(hipGraphLaunch(h->spec_graph, h->stream));
+        } else if (peers) {
+            dist_sample_exchange(h, true);
+            if ((rc = enqueue_dist_iterations(h, h->d_ctrl, 0, nb, first, nullptr))) return rc;
+            dist_count_batch(h, false, 0);
         } else {
             for (int j = 0; j < nb; j++)
                 if ((rc = enqueue_iteration_spec(h, h->d_ctrl, j, first && j == 0))) return rc;
@@ -1715,9 +1845,10 @@ static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
             downgrade = true;
             break;
         }
+        if (peers) dist_sample_exchange(h, false);
         if (first) {
-            for (int q = 0; q < 3; q++)
-                if (hipEventElapsedTime(&ms_sample[q], h->tev[q], h->tev[q + 1]) != hipSuccess) ms_sample[q] = 0.f;
+            for (int q = 0; q < 3; q++)   // (a partition with peers interleaves its steps on two streams: no per-step sample there)
+                if (peers || hipEventElapsedTime(&ms_sample[q], h->tev[q], h->tev[q + 1]) != hipSuccess) ms_sample[q] = 0.f;
             if (resident) ms_sample[0] /= (float)std::max(1, std::min(nb, std::max(1, hc->inner)));   // per iteration of the sampled batch
             first = false;
         }
@@ -1948,6 +2079,21 @@ extern "C" int exaadmm_run_fixed(exaadmm_handle* h, int iters, int first_major_i
                 if ((rc = enqueue_resident(h, iters)) < 0) return rc;
                 refused = rc > 0;
                 if (time_branch) HIPCHK(hipEventRecord(h->ev[3], h->stream));   // (one launch: its time / iters is reported)
+            } else if (dist_has_peers(h)) {
+                // batches of 12 like the convergence-tested loop: the first one enqueued directly (its first launch has no z / l
+                // pass), full batches after it replayed from the hipGraph when there is one, the rest directly
+                for (int i0 = 0; i0 < iters; i0 += DIST_BATCH) {
+                    const int n = std::min(DIST_BATCH, iters - i0);
+                    if (i0 > 0) hipLaunchKernelGGL(k_ctrl_set_base, dim3(1), dim3(1), 0, h->stream, h->d_ctrl, first_major_iter - 1 + i0);
+                    if (i0 > 0 && n == DIST_BATCH && !time_branch && dist_batch_graph(h)) {
+                        HIPCHK(hipGraphLaunch(h->spec_graph, h->stream));
+                        dist_count_batch(h, true, DIST_BATCH);
+                        continue;
+                    }
+                    dist_sample_exchange(h, i0 == 0);
+                    if ((rc = enqueue_dist_iterations(h, h->d_ctrl, 0, n, i0 == 0, time_branch ? &h->ev[2 + 2 * i0] : nullptr))) return rc;
+                    dist_count_batch(h, false, 0);
+                }
             } else
                 for (int i = 0; i < iters; i++)
                     if ((rc = enqueue_iteration_spec(h, h->d_ctrl, i, false, time_branch ? &h->ev[2 + 2 * i] : nullptr))) return rc;
@@ -1968,6 +2114,7 @@ extern "C" int exaadmm_run_fixed(exaadmm_handle* h, int iters, int first_major_i
             if ((rc = spec_finish(h, iters))) return rc;
             double s[4];
             if ((rc = fetch_sums(h, s, true))) return rc;
+            if (dist_has_peers(h)) dist_sample_exchange(h, false);
             if (out)
                 for (int j = 0; j < 4; j++) out[j] = s[j];
             float ms = 0.f;

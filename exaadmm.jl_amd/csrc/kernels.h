@@ -85,6 +85,16 @@ struct Dev {
     const double* v_in;
     double* partials_br;
     int npartials_br;
+    // A partition with peers splits the branch launch of an iteration in two (exaadmm_hip.hip enqueue_dist_iterations): the
+    // INTERIOR blocks (+ the generator blocks) start right after the bus launch, the blocks that hold cut branches wait for the
+    // peers' halo.  blk0 = first branch block this launch covers, gen_part0 = partial-sum slot of the first generator block
+    // (= number of branch blocks of the whole grid; a one-piece launch: blk0 = 0, gen_part0 = its own branch blocks).
+    int blk0, gen_part0;
+    // ... and runs TWO launches ahead of the stop test (the interior launch of iteration j+1 starts before the halo of iteration
+    // j -- which carries the residual sums that decide about iteration j-1 -- has arrived): the iterate rotates through three
+    // buffer sets, z and l included.  z_in / l_in = z, l of the iteration BEFORE the one whose z / l pass rides in this launch's
+    // prologue (the pass reads them and writes d.z / d.l, another set); nullptr = in place (one GPU: two sets, d.zp kept).
+    const double *z_in, *l_in;
     // multi-period model (ModelMpacopf): T periods stored period-major inside every
     // plane (generator t*g1+i, branch t*l1+j, bus t*b1+k); T = 1 for the single-period model.
     // Ramp block (SolutionRamping of period t >= 1) at [t*g1 + i]; block 0 is unused.
@@ -264,13 +274,23 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_branch_t(const Dev* __restrict_
         else if (ZL) {
             const double* const uin = d.u_in ? d.u_in : d.u;
             const double* const vin = d.v_in ? d.v_in : d.v;
+            const double* const zsrc = (do_zl && d.z_in) ? d.z_in : d.z;
+            const double* const lsrc = (do_zl && d.l_in) ? d.l_in : d.l;
             if (gi < d.G) {
                 const int pg = gi, qg = d.Gp + gi;
                 const double rho_p = d.rho[pg], rho_q = d.rho[qg];
-                double lp = d.l[pg], lq = d.l[qg], zp = d.z[pg], zq = d.z[qg];
+                double lp = lsrc[pg], lq = lsrc[qg], zp = zsrc[pg], zq = zsrc[qg];
                 if (do_zl) {
-                    zl_element(d, pg, uin[pg], vin[pg], rho_p, zl_beta, zs, lp, zp);
-                    zl_element(d, qg, uin[qg], vin[qg], rho_q, zl_beta, zs, lq, zq);
+                    const double lzp = d.lz[pg], lzq = d.lz[qg];
+                    const double zold_p = zp, zold_q = zq;
+                    zl_values(uin[pg], vin[pg], rho_p, zl_beta, lzp, zold_p, lp, zs, lp, zp);
+                    zl_values(uin[qg], vin[qg], rho_q, zl_beta, lzq, zold_q, lq, zs, lq, zq);
+                    d.zp[pg] = zold_p;
+                    d.z[pg] = zp;
+                    d.l[pg] = lp;
+                    d.zp[qg] = zold_q;
+                    d.z[qg] = zq;
+                    d.l[qg] = lq;
                 }
                 double up, uq;
                 generator_update(d, baseMVA, gi, vin, up, uq);
@@ -291,8 +311,9 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_branch_t(const Dev* __restrict_
                     for (int off = 32; off > 0; off >>= 1) zs[j] += __shfl_down(zs[j], off, 64);
                 }
                 if (threadIdx.x == 0) {
+                    const int part = d.gen_part0 + ((int)blockIdx.x - nbr_blocks);
 #pragma unroll
-                    for (int j = 0; j < 4; j++) d.partials_br[blockIdx.x * 4 + j] = zs[j];
+                    for (int j = 0; j < 4; j++) d.partials_br[part * 4 + j] = zs[j];
                 }
             }
         } else
@@ -303,7 +324,8 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_branch_t(const Dev* __restrict_
     // of the step-wise launch has fewer than 64 lanes).
     __shared__ MuPowTable pw_lds;
     if (threadIdx.x < 24) reinterpret_cast<double*>(&pw_lds)[threadIdx.x] = reinterpret_cast<const double*>(&c_mupow)[threadIdx.x];
-    const int slot = blockIdx.x * BR_BLOCK + threadIdx.x;
+    const int blk = (ZL ? d.blk0 : 0) + (int)blockIdx.x;   // (split launches of a partition start at block blk0)
+    const int slot = blk * BR_BLOCK + threadIdx.x;
     const bool lane_on = slot < d.L;
     if (!ZL && !lane_on) return;
 #if defined(EXA_PROFILE_PHASES)
@@ -328,14 +350,16 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_branch_t(const Dev* __restrict_
         // (load, compute, store, eight times, then the multipliers) a wave needed 10.6 k clocks from kernel entry to
         // "loads landed" against 4.0 k for the launch without the pass (profiles/r02_wave_timeline_*).
         double vv[8], zo[8], lo[8], lzv[8];
+        const double* const zsrc = (do_zl && d.z_in) ? d.z_in : d.z;   // (three-set rotation of a partition with peers: see Dev::z_in)
+        const double* const lsrc = (do_zl && d.l_in) ? d.l_in : d.l;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int e = base + k * Lp;
             ub[k] = uin[e];
             bd.rho_[k] = d.rho[e];
             vv[k] = vin[e];
-            zo[k] = d.z[e];
-            lo[k] = d.l[e];
+            zo[k] = zsrc[e];
+            lo[k] = lsrc[e];
             lzv[k] = do_zl ? d.lz[e] : 0.0;
             bd.Y_[k] = d.Y[b + k * Lp];
             bnd[k] = d.bnd[b + k * Lp];
@@ -375,7 +399,7 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_branch_t(const Dev* __restrict_
             }
             if (threadIdx.x == 0) {
 #pragma unroll
-                for (int j = 0; j < 4; j++) d.partials_br[blockIdx.x * 4 + j] = zs[j];
+                for (int j = 0; j < 4; j++) d.partials_br[blk * 4 + j] = zs[j];
             }
         }
         if (!lane_on) return;
@@ -762,7 +786,10 @@ __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group_t(const Ctrl* ctrl, Ctr
     __shared__ double res[BUS_BLOCK / BUS_W][4];
     // (the reduction block is block 0: dispatched first, it runs beside the bus blocks instead of behind the last of them)
     if (red != nullptr && blockIdx.x == 0) {   // the reduction block (whole block takes this path)
-        if (red->done || !red->pending) return;
+        // (one GPU: `pending` says whether the preceding branch launch made a z / l pass.  A partition with peers passes red =
+        //  nullptr instead when it did not: there the flag is rewritten by k_halo_unpack on another stream while the next
+        //  interior branch launch is already setting it again)
+        if (red->done || (d.nranks <= 1 && !red->pending)) return;
         double s4[4] = {0.0, 0.0, 0.0, 0.0};
         for (int bq = threadIdx.x; bq < d.npartials_br; bq += BUS_BLOCK) {
 #pragma unroll
@@ -1426,7 +1453,8 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident(const Dev* __restrict_
 //     decision, on every rank) and advances the loop control -- or, out != nullptr, just delivers the totals.
 // rcode[i] = (side << 28) | local branch, side END_FROM / END_TO = which half ARRIVES, rpos[i] = where in the receive
 // buffer (a peer's message is its cut branches' entries followed by its four sums); n_cut = 0: sums only.
-__global__ void k_halo_unpack(Dev d, const int* rcode, const int* rpos, int n_cut, Ctrl* ctrl, double* out, int need_pending)
+// sums_mode: 0 = the message carries sums: add them; 1 = only if ctrl->pending says so (serial callers); 2 = no sums in this message
+__global__ void k_halo_unpack(Dev d, const int* rcode, const int* rpos, int n_cut, Ctrl* ctrl, double* out, int sums_mode)
 {
     if (ctrl != nullptr && ctrl->done) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1441,7 +1469,7 @@ __global__ void k_halo_unpack(Dev d, const int* rcode, const int* rpos, int n_cu
         d.v[e + (from ? 6 : 7) * Lp] = q[3];
     }
     if (i != 0) return;
-    if (need_pending && !ctrl->pending) return;   // first iteration of a loop: no residual sums travel yet
+    if (sums_mode == 2 || (sums_mode == 1 && !ctrl->pending)) return;   // first iteration of a loop: no residual sums travel yet
     double s[4] = {0.0, 0.0, 0.0, 0.0};
     for (int p = 0; p < d.nranks; p++) {
         const double* q = (p == d.rank) ? d.halo_local : d.halo_recv + d.halo_off[d.nranks + p];
@@ -1580,8 +1608,8 @@ __global__ void __launch_bounds__(EW_BLOCK) k_fused_zl(Dev d, double beta_arg, c
     double s[4] = {0.0, 0.0, 0.0, 0.0};
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.N; i += gridDim.x * blockDim.x) {
         const double u = d.u[i], v = d.v[i], rho = d.rho[i], lz = d.lz[i];
-        const double zold = d.z[i];
-        const double z = (-(lz + d.l[i] + rho * (u - v))) / (beta + rho);
+        const double zold = (d.z_in ? d.z_in : d.z)[i];   // (three-set rotation of a partition with peers: Dev::z_in)
+        const double z = (-(lz + (d.l_in ? d.l_in : d.l)[i] + rho * (u - v))) / (beta + rho);
         const double rp = u - v + z;
         const double rd = z - zold;
         const double ax = rp - z;

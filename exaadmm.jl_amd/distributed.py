@@ -617,6 +617,56 @@ def bench_main(args, rank, world, local_rank):
         res = torch.sqrt(be.sums).cpu().numpy()
     cuts = torch.tensor([part.n_cut, part.n_native], dtype=torch.float64, device="cuda")
     dist.all_reduce(cuts)
+    # what the in-library loop did: ranks of the communicator as RCCL counts them, RCCL version, duration of the sampled exchanges
+    # (grouped send / receive + unpack kernel, HIP events on the exchange stream), batches replayed from a hipGraph / enqueued directly
+    rccl = None
+    exchange_us = None
+    if native:
+        n_, v_, gb_, db_, pr_ = C.c_int(), C.c_int(), C.c_int64(), C.c_int64(), C.c_int()
+        us_ = C.c_double()
+        pkg._check(be.lib.exaadmm_dist_stats(be.mod.handle, C.byref(n_), C.byref(v_), C.byref(us_), C.byref(gb_), C.byref(db_), C.byref(pr_)), "exaadmm_dist_stats")
+        xs = torch.tensor([us_.value], dtype=torch.float64, device="cuda")
+        dist.all_reduce(xs, op=dist.ReduceOp.MAX)
+        exchange_us = float(xs.cpu()[0]) or None
+        rccl = {"nranks": n_.value, "version": v_.value, "path": be.lib.exaadmm_dist_rccl_path().decode(),
+                "capture_probe": {1: "ok: batches of 12 iterations incl. their exchanges replayed from one hipGraph", 0: "refused: batches enqueued directly",
+                                  -1: "not run (one rank)"}.get(pr_.value),
+                "graph_batches_rank0": gb_.value, "direct_batches_rank0": db_.value}
+    # N > 1: what ONE GPU does on one area with the loop the partitions run (two launches per iteration; the single-GPU bench
+    # line uses the resident loop, one launch per batch): separates the cost of communication from the change of loop
+    n1_same_loop = None
+    cpu_base = None
+    if rank == 0 and (world > 1 or getattr(args, "force_dist", False)):
+        try:
+            old = os.environ.get("EXAADMM_NO_RESIDENT")
+            os.environ["EXAADMM_NO_RESIDENT"] = "1"
+            g1 = syn.sized_like(args.case, seed=0)
+            env1 = pkg.AdmmEnv(args.case, params["rho_pq"], params["rho_va"], gpu_no=local_rank, verbose=0, grid=g1)
+            m1 = pkg.ModelAcopf(env1)
+            env1.params.scale = params["scale"]
+            m1.sync_params()
+            m1.run_fixed(prep + args.warmup, first_major_iter=1, beta=beta)
+            m1.state_save()
+            ts = []
+            for _ in range(30):
+                m1.state_restore()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                m1.run_fixed(args.steps, first_major_iter=prep + args.warmup + 1, beta=beta)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            n1_same_loop = {"iterations_per_s": args.steps / sorted(ts)[len(ts) // 2], "loop_kind": m1.loop_kind(),
+                            "what": "one case-sized area on one GPU, two launches per iteration (EXAADMM_NO_RESIDENT=1), same state, median of 30 regions"}
+            m1.close()
+            if old is None:
+                os.environ.pop("EXAADMM_NO_RESIDENT", None)
+            else:
+                os.environ["EXAADMM_NO_RESIDENT"] = old
+            if not getattr(args, "no_cpu_baseline", False):
+                cpu_base = B.cpu_baseline(g1, params, budget_s=10.0, prep=min(prep, 100))
+                cpu_base["sample"] += " -- ONE case-sized area (what one GPU of the job iterates on)"
+        except Exception as e:   # never lose the line over the extras
+            sys.stderr.write("bench: extras failed: %r\n" % (e,))
     # every rank pushes out whatever the runtime libraries buffered on C stdio (RCCL version banner) BEFORE
     # rank 0 prints, so that the JSON line is the last line of the job's stdout
     try:
@@ -646,6 +696,8 @@ def bench_main(args, rank, world, local_rank):
                        "state": "ADMM state after %d untimed preparation iterations from init_solution!" % prep,
                        "loop": "inside the library, RCCL from C++ (dist_native.h)" if native else "step-wise twin: Python-driven steps + torch collectives",
                        "exchanges_per_iteration_rank0": (exch2 - exch1) / float(max(args.steps, 1)) if native else None,
+                       "overlap": "exchange + cut-branch solves on a second stream beside the interior branch solves of the next iteration"
+                                  if os.environ.get("EXAADMM_DIST_OVERLAP", "1") != "0" else "off (EXAADMM_DIST_OVERLAP=0): one stream",
                        "parallelism": "bus/branch partition x%d (breadth-first bus ranges); cut branches solved on both owners; per "
                                       "iteration ONE grouped ncclSend/ncclRecv per peer (4 v entries per cut branch + 4 residual sums), "
                                       "sums added in rank order, no all-reduce" % world},
@@ -653,7 +705,11 @@ def bench_main(args, rank, world, local_rank):
                          "unit": "GB/s", "frac": B.BYTES_PER_ITER(G, Ln, Bn) * its / 1e9 / (world * B.HBM_PEAK_GBS),
                          "traffic": None, "note": "whole-iteration algorithmic bytes of the grid / wall time"},
             "solver": {"primres": float(res[0])},
+            "rccl": rccl, "exchange_us": exchange_us, "n1_same_loop": n1_same_loop,
         }
+        if cpu_base is not None:
+            out["cpu_baseline"] = cpu_base
+            out["speedup_vs_cpu_baseline_per_area"] = its / cpu_base["value"]
         try:
             C.CDLL(None).fflush(None)
         except Exception:

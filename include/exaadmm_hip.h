@@ -195,6 +195,9 @@ int exaadmm_state_restore(exaadmm_handle *h);
  * ranks: per inner iteration ONE grouped ncclSend / ncclRecv per peer (the cut branches' new v entries + this
  * rank's four partial residual sums), the sums are added in rank order on every rank (identical decisions, no
  * all-reduce), tolerances use nvar_global.  exaadmm_objective / info.objval stay this partition's share.
+ * The exchange runs on a second stream BESIDE the next iteration's interior branch solves (only a cut branch's next solve
+ * needs the halo); a batch of iterations including its exchanges is replayed from one hipGraph when the bound RCCL can
+ * be captured (probed at connect time), enqueued directly otherwise.
  *   exaadmm_dist_unique_id  on ONE rank; the 128 bytes reach the others by the caller's means (torch.distributed, MPI)
  *   exaadmm_dist_prepare    local: binds RCCL, checks the cut lists, allocates the message buffers.  ncut_per_peer
  *                           [nranks]; cut_branch: for every peer in rank order the zero-based local ids of the
@@ -212,6 +215,13 @@ int exaadmm_dist_detach(exaadmm_handle *h);
 /* the sums exchange + a ring send / receive of n doubles on the handle's stream; max_err = deviation from the
  * expected values.  Checks that RCCL and the library share one HIP runtime. */
 int exaadmm_dist_selftest(exaadmm_handle *h, int64_t n, double *max_err);
+/* what the distributed loop of this handle did so far: ranks of the communicator as RCCL counts them (ncclCommCount; -1 if the
+ * bound library does not say), RCCL version code (ncclGetVersion; 0 unknown), mean duration in microseconds of the sampled
+ * exchanges (grouped send / receive + unpack kernel, HIP events on the exchange stream; 0: none sampled), batches of
+ * iterations replayed from a hipGraph / enqueued directly, and the result of the connect-time capture probe (1 = the bound
+ * RCCL captured, instantiated and replayed an exchange with every peer, 0 = it refused: batches are enqueued directly) */
+int exaadmm_dist_stats(exaadmm_handle *h, int *comm_ranks, int *rccl_version, double *exchange_us, int64_t *graph_batches,
+                       int64_t *direct_batches, int *probe);
 const char *exaadmm_dist_rccl_path(void); /* the RCCL the library bound (next to its own HIP runtime), "" before */
 int64_t exaadmm_dist_exchange_count(void); /* grouped exchanges enqueued by the calling thread so far (tests) */
 

@@ -47,6 +47,12 @@ extern "C" double hostcheck_fgh(const double* x_, const double* param, const dou
     return f;
 }
 
+// the device build's sin / cos of small angles (branch_solver.h sincos_quarter_pi), n values
+extern "C" void hostcheck_sincos_quarter_pi(const double* t, int n, double* sn, double* cs)
+{
+    for (int i = 0; i < n; i++) sincos_quarter_pi(t[i], sn[i], cs[i]);
+}
+
 extern "C" double hostcheck_f(const double* x_, const double* param, const double* Y, double scale)
 {
     BranchData d;

@@ -157,6 +157,31 @@ def test_lane_generator_ramp_solve_matches_oracle(hc, oracle):
     assert same >= 0.97 * ncase
 
 
+def test_small_angle_sincos_of_the_device_build_is_libm_to_one_ulp(hc):
+    """The default device build evaluates sin / cos of the angle difference with the two kernel polynomials for |t| <= pi/4
+    (branch_solver.h sincos_quarter_pi; library call beyond).  Against libm on 2 million points of [-pi/4, pi/4] incl. the end
+    points, tiny arguments and 0: at most one unit in the last place apart, exact at 0, sin odd and cos even to the bit."""
+    rng = np.random.default_rng(7)
+    q = np.pi / 4
+    t = np.concatenate([rng.uniform(-q, q, 2_000_000), np.linspace(-q, q, 100_001), 10.0 ** rng.uniform(-300, -1, 20_000) * rng.choice([-1.0, 1.0], 20_000),
+                        [0.0, -0.0, q, -q, np.nextafter(q, 0), 5e-324, 1e-160]])
+    t = np.ascontiguousarray(t[np.abs(t) <= 0.78539816339744830962])
+    sn, cs = np.empty_like(t), np.empty_like(t)
+    hc.hostcheck_sincos_quarter_pi.argtypes = [C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    hc.hostcheck_sincos_quarter_pi(_p(t), t.size, _p(sn), _p(cs))
+    rs, rc = np.sin(t), np.cos(t)
+    ulp_s = np.abs(sn - rs) / np.spacing(np.abs(rs) + 5e-324)
+    ulp_c = np.abs(cs - rc) / np.spacing(np.abs(rc))
+    assert ulp_s.max() <= 1.0 and ulp_c.max() <= 1.0, (ulp_s.max(), ulp_c.max())
+    assert (ulp_s > 0).mean() < 0.2 and (ulp_c > 0).mean() < 0.2      # and mostly identical
+    z = t == 0.0
+    assert np.all(sn[z] == 0.0) and np.all(cs[z] == 1.0)
+    sn2, cs2 = np.empty_like(t), np.empty_like(t)
+    tm = np.ascontiguousarray(-t)
+    hc.hostcheck_sincos_quarter_pi(_p(tm), t.size, _p(sn2), _p(cs2))
+    assert np.array_equal(sn2, -sn) and np.array_equal(cs2, cs)
+
+
 def test_lane_code_gives_up_quickly_on_non_finite_inputs(hc):
     """NaN in the consensus targets must not make a lane spin through its guarded loops
     (50 x 500 evaluations with 1000-trip line searches = seconds on a GPU): one tick, then out,

@@ -233,3 +233,49 @@ def test_three_processes_share_the_gpu_and_all_finish_with_the_same_bits(tmp_pat
     for o in outs:
         assert o["digest"] == ref["digest"], (o, ref)
         assert o["kind_before"] == 2 and o["kind_after"] == (1 if o["downgrades"] else 2)
+
+
+def _hog_binary():
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "tests", "tools", "gpu_hog")
+    src = exe + ".hip"
+    if not os.path.exists(exe) or os.path.getmtime(src) > os.path.getmtime(exe):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-o", exe, src])
+    return exe
+
+
+@pytest.mark.skipif(SWITCHED_OFF, reason="a switch of this run turns the resident loop off")
+def test_a_gpu_mostly_taken_by_another_process_downgrades_the_loop_not_the_call(tmp_path):
+    """A REAL failed wait: another process holds 200 of the 256 compute units (one block per CU with all of its LDS) for a few
+    seconds while the 13 659-bus grid (385 wavefronts) starts its resident loop: at most 4 x 56 wavefronts find a place, the
+    others never start, waits hit their cap.  The call must come back OK with the bits of an undisturbed run, having switched
+    the handle to the two-launch loop."""
+    import json
+    import subprocess
+    import sys
+    import time
+    from conftest import ROOT
+    alone = subprocess.run([sys.executable, "-c", _CONTENDER % {"root": ROOT, "flag": str(tmp_path / "alone_"), "n": 1}],
+                           capture_output=True, text=True, timeout=900)
+    assert alone.returncode == 0, alone.stderr[-3000:]
+    ref = json.loads([l for l in alone.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    # the contender waits (flag files) until the hog is running: the hog's flag is written here once it says so
+    flag = str(tmp_path / "go_")
+    cont = subprocess.Popen([sys.executable, "-c", _CONTENDER % {"root": ROOT, "flag": flag, "n": 2}], stdout=subprocess.PIPE,
+                            stderr=subprocess.PIPE, text=True)
+    while not [f for f in os.listdir(tmp_path) if f.startswith("go_")]:      # contender has built its model
+        assert cont.poll() is None, cont.communicate()
+        time.sleep(0.05)
+    hog = subprocess.Popen([_hog_binary(), "200", "4.0"], stdout=subprocess.PIPE, text=True)
+    assert "HOG RUNNING" in hog.stdout.readline()
+    time.sleep(0.3)
+    open(flag + "hog", "w").write("ready")
+    o, e = cont.communicate(timeout=900)
+    hog_out = hog.communicate(timeout=60)[0]
+    assert cont.returncode == 0, (o[-1500:], e[-3000:])
+    assert "HOG DONE" in hog_out and hog.returncode == 0, hog_out
+    got = json.loads([l for l in o.splitlines() if l.startswith("RESULT ")][-1][7:])
+    print("beside the hog:", got, "alone:", ref)
+    assert got["digest"] == ref["digest"]
+    assert got["downgrades"] == 1 and got["kind_after"] == 1, got

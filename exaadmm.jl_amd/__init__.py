@@ -196,6 +196,7 @@ def library():
     L.exaadmm_dist_exchange_count.restype = C.c_int64
     L.exaadmm_dist_detach.argtypes = [H]
     L.exaadmm_dist_selftest.argtypes = [H, C.c_int64, c_double_p]
+    L.exaadmm_dist_capture_selftest.argtypes = [H, C.c_int64, C.POINTER(C.c_int)]
     L.exaadmm_dist_stats.argtypes = [H, C.POINTER(C.c_int), C.POINTER(C.c_int), c_double_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                      C.POINTER(C.c_int)]
     L.exaadmm_mp_create.argtypes = [C.POINTER(Grid), C.POINTER(Parameters), C.c_int, c_double_p, c_double_p,

@@ -600,3 +600,72 @@ extern "C" int exaadmm_dist_selftest(exaadmm_handle* h, int64_t n, double* max_e
     *max_err = e;
     return EXAADMM_OK;
 }
+
+// The ring send / receive of the self test CAPTURED into a hipGraph and replayed twice on the exchange stream (one rank: to
+// itself): is the bound RCCL capturable at all in this runtime?  *captured = 1: captured, instantiated, replayed, data correct;
+// 0: the library refused (the loop then enqueues directly).  An error is returned only for wrong data.
+extern "C" int exaadmm_dist_capture_selftest(exaadmm_handle* h, int64_t n, int* captured)
+{
+    REQUIRE(h && h->dist && h->dist->comm && n >= 1 && captured, "needs an attached communicator");
+    exaadmm_dist* d = h->dist;
+    *captured = 0;
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t X = d->xstream;
+    if (!X) HIPCHK(hipStreamCreateWithFlags(&d->xstream, hipStreamNonBlocking));
+    X = d->xstream;
+    std::vector<double> a((size_t)n), b((size_t)n, -1.0);
+    double *da = nullptr, *db = nullptr;
+    struct Free {
+        double *&a, *&b;
+        ~Free() { if (a) (void)hipFree(a); if (b) (void)hipFree(b); }
+    } free_on_exit{da, db};
+    HIPCHK(hipMalloc((void**)&da, (size_t)n * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&db, (size_t)n * sizeof(double)));
+    const int next = (d->rank + 1) % d->nranks, prev = (d->rank + d->nranks - 1) % d->nranks;
+    auto ring = [&]() -> bool {
+        if (d->api.GroupStart() != ncclSuccess) return false;
+        const ncclResult_t r1 = d->api.Send(da, (size_t)n, ncclDouble, next, d->comm, X);
+        const ncclResult_t r2 = r1 == ncclSuccess ? d->api.Recv(db, (size_t)n, ncclDouble, prev, d->comm, X) : r1;
+        const ncclResult_t r3 = d->api.GroupEnd();
+        return r1 == ncclSuccess && r2 == ncclSuccess && r3 == ncclSuccess;
+    };
+    // (first use of the connection outside any capture)
+    for (int64_t i = 0; i < n; i++) a[(size_t)i] = 0.25 * (double)i + d->rank;
+    HIPCHK(hipMemcpy(da, a.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    REQUIRE(ring(), "ring send / receive failed");
+    HIPCHK(hipStreamSynchronize(X));
+    hipGraphExec_t exec = nullptr;
+    if (hipStreamBeginCapture(X, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        const bool ok = ring();
+        hipGraph_t g = nullptr;
+        const hipError_t e = hipStreamEndCapture(X, &g);
+        if (ok && e == hipSuccess && g != nullptr && hipGraphInstantiate(&exec, g, nullptr, nullptr, 0) != hipSuccess) exec = nullptr;
+        if (!ok || e != hipSuccess) exec = nullptr;
+        if (g) (void)hipGraphDestroy(g);
+    }
+    (void)hipGetLastError();
+    for (int rep = 1; rep <= 2; rep++) {
+        for (int64_t i = 0; i < n; i++) a[(size_t)i] = 0.25 * (double)i + d->rank + 100.0 * rep;
+        HIPCHK(hipMemcpyAsync(da, a.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, X));
+        HIPCHK(hipMemsetAsync(db, 0, (size_t)n * sizeof(double), X));
+        if (exec) {
+            if (hipGraphLaunch(exec, X) != hipSuccess) {
+                (void)hipGetLastError();
+                (void)hipGraphExecDestroy(exec);
+                exec = nullptr;
+            }
+        }
+        if (!exec) REQUIRE(ring(), "ring send / receive failed");
+        HIPCHK(hipMemcpyAsync(b.data(), db, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, X));
+        HIPCHK(hipStreamSynchronize(X));
+        for (int64_t i = 0; i < n; i++)
+            if (b[(size_t)i] != 0.25 * (double)i + prev + 100.0 * rep) {
+                if (exec) (void)hipGraphExecDestroy(exec);
+                set_err("captured ring send / receive delivered wrong data at %lld (replay %d)", (long long)i, rep);
+                return EXAADMM_ERR_HIP;
+            }
+    }
+    *captured = exec ? 1 : 0;
+    if (exec) (void)hipGraphExecDestroy(exec);
+    return EXAADMM_OK;
+}

@@ -215,6 +215,9 @@ int exaadmm_dist_detach(exaadmm_handle *h);
 /* the sums exchange + a ring send / receive of n doubles on the handle's stream; max_err = deviation from the
  * expected values.  Checks that RCCL and the library share one HIP runtime. */
 int exaadmm_dist_selftest(exaadmm_handle *h, int64_t n, double *max_err);
+/* the same ring send / receive captured into a hipGraph and replayed twice on the exchange stream: *captured = 1 when the bound
+ * RCCL could be captured and delivered the right data from the replays, 0 when it refused capture (data then moved directly) */
+int exaadmm_dist_capture_selftest(exaadmm_handle *h, int64_t n, int *captured);
 /* what the distributed loop of this handle did so far: ranks of the communicator as RCCL counts them (ncclCommCount; -1 if the
  * bound library does not say), RCCL version code (ncclGetVersion; 0 unknown), mean duration in microseconds of the sampled
  * exchanges (grouped send / receive + unpack kernel, HIP events on the exchange stream; 0: none sampled), batches of

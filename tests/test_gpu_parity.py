@@ -665,6 +665,12 @@ def test_native_distributed_loop_at_one_rank_matches_fused_solve(pkg, syn):
     err = C.c_double(1.0)
     pkg._check(pkg.library().exaadmm_dist_selftest(be1.mod.handle, 4096, C.byref(err)), "exaadmm_dist_selftest")
     assert err.value == 0.0
+    # ... and the same ring captured into a hipGraph and replayed (what a partition's batches do with their exchanges): real RCCL
+    # must be capturable in this runtime
+    cap = C.c_int(-1)
+    pkg._check(pkg.library().exaadmm_dist_capture_selftest(be1.mod.handle, 4096, C.byref(cap)), "exaadmm_dist_capture_selftest")
+    print("real RCCL (one rank) captured into a hipGraph and replayed:", cap.value)
+    assert cap.value == 1
     info1 = m1.solve()
     assert (info1["outer"], info1["cumul"]) == (info["outer"], info["cumul"]) and info1["mismatch"] == info["mismatch"]
     # fixed-count mode (benchmark path) advances the same trajectory as the single-GPU fixed-count loop

@@ -135,6 +135,8 @@ struct exaadmm_handle {
     int resident_downgrades = 0;
     int resident_launches = 0;
     bool resident_coop = false;
+    int resident_cap2 = -1;      // the same for k_resident_t<2> (two tiles of 64 branches per wavefront)
+    ResidentTiles rtiles = {nullptr, 0, 0, 0, 0};
     std::vector<void*> guard;
     size_t nrec_slots = 0;
     ResidentSync rsync = {};
@@ -1422,9 +1424,13 @@ static int resident_capacity(exaadmm_handle* h)
         hipDeviceProp_t prop;
         int blocks = 0;
         const bool masked = getenv("HSA_CU_MASK") != nullptr || getenv("ROC_GLOBAL_CU_MASK") != nullptr;
-        if (!masked && hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0 &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_resident, BR_BLOCK, 0) == hipSuccess)
-            h->resident_cap = std::max(0, std::min(blocks, 4) * prop.multiProcessorCount - 8);
+        h->resident_cap2 = 0;
+        if (!masked && hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) {
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_resident_t<1>, BR_BLOCK, 0) == hipSuccess)
+                h->resident_cap = std::max(0, std::min(blocks, 4) * prop.multiProcessorCount - 8);
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_resident_t<2>, BR_BLOCK, 0) == hipSuccess)
+                h->resident_cap2 = std::max(0, std::min(blocks, 4) * prop.multiProcessorCount - 8);
+        }
         (void)hipGetLastError();
         // a cooperative launch makes the runtime check co-residency against its own occupancy figure and refuse what does
         // not fit (A/B switch EXAADMM_RESIDENT_COOP=0: plain launch; measured in profiles/r04_resident_hardening.txt)
@@ -1436,6 +1442,8 @@ static int resident_capacity(exaadmm_handle* h)
     }
     return h->resident_cap;
 }
+
+static int resident_mode(exaadmm_handle* h);
 
 // 8-byte-word copies of several buffers in one launch (the resident loop's guard snapshot: one kernel, no host loop of memcpys)
 struct CopyList {
@@ -1508,6 +1516,16 @@ static int resident_prepare(exaadmm_handle* h)
             HIPCHK(hipMemsetAsync(r.terms[q], 0, 4 * h->nrec_slots * sizeof(double), h->stream));
         }
     }
+    if (resident_mode(h) == 2 && !h->rtiles.tiles) {
+        const int nb = branch_blocks(h), ng = gen_blocks(h);
+        int* t = nullptr;
+        h->rtiles.nb = nb;
+        h->rtiles.ng = ng;
+        h->rtiles.wg = (ng + 1) / 2;
+        h->rtiles.wb = h->resident_cap2 - h->rtiles.wg - 1;
+        if ((rc = dev_alloc(h, &t, 2 * (size_t)h->rtiles.wb))) return rc;
+        h->rtiles.tiles = t;
+    }
     HIPCHK(hipMemsetAsync(r.fail, 0, sizeof(int), h->stream));
     h->h_base[1] = 0;
     return resident_guard(h, false);   // the iterate the call starts from: what a failed batch falls back to
@@ -1521,34 +1539,53 @@ static int enqueue_resident(exaadmm_handle* h, int n)
     h->resident_launches += 1;
     if (const char* e = getenv("EXAADMM_RESIDENT_TEST_FAIL"))   // tests: the n-th resident launch of a handle reports a failed wait
         if (atoi(e) == h->resident_launches) HIPCHK(hipMemsetAsync(h->rsync.fail, 0x01, 1, h->stream));
+    const int mode = resident_mode(h);
+    int grid = nb + ng + 1;
+    if (mode == 2) {
+        // which tiles share a wavefront in this launch: from the solver-trip counters of the last x-updates (both buffer sets)
+        const ResidentTiles& t = h->rtiles;
+        hipLaunchKernelGGL(k_resident_assign, dim3(1), dim3(1024), 2 * (size_t)t.nb * sizeof(int), h->stream, (const int*)h->sets[0].st[2], (const int*)h->sets[1].st[2],
+                           h->L, t.nb, t.wb, const_cast<int*>(t.tiles));
+        grid = t.wb + t.wg + 1;
+    }
     if (h->resident_coop) {
         const Dev *d0 = h->d_dspec[0][0], *d1 = h->d_dspec[1][0];
         double scale = h->par.scale, base = h->baseMVA;
-        void* args[] = {(void*)&d0, (void*)&d1, (void*)&h->bo, (void*)&scale, (void*)&h->d_ctrl, (void*)&ng, (void*)&base, (void*)&n, (void*)&h->rsync};
-        const hipError_t e = hipLaunchCooperativeKernel((const void*)k_resident, dim3(nb + ng + 1), dim3(BR_BLOCK), args, 0, h->stream);
+        void* args[] = {(void*)&d0, (void*)&d1, (void*)&h->bo, (void*)&scale, (void*)&h->d_ctrl, (void*)&ng, (void*)&base, (void*)&n, (void*)&h->rsync, (void*)&h->rtiles};
+        const hipError_t e = hipLaunchCooperativeKernel(mode == 2 ? (const void*)k_resident_t<2> : (const void*)k_resident_t<1>, dim3(grid), dim3(BR_BLOCK), args, 0, h->stream);
         if (e == hipSuccess) return 0;
         (void)hipGetLastError();
         if (e != hipErrorCooperativeLaunchTooLarge) h->resident_coop = false;   // (not offered after all: plain launches from here on)
         else return 1;   // the runtime says the grid is not co-resident: the caller takes the two-launch loop
     }
-    hipLaunchKernelGGL(k_resident, dim3(nb + ng + 1), dim3(BR_BLOCK), 0, h->stream, h->d_dspec[0][0], h->d_dspec[1][0], h->bo, h->par.scale, h->d_ctrl, ng,
-                       h->baseMVA, n, h->rsync);
+    if (mode == 2)
+        hipLaunchKernelGGL(k_resident_t<2>, dim3(grid), dim3(BR_BLOCK), 0, h->stream, h->d_dspec[0][0], h->d_dspec[1][0], h->bo, h->par.scale, h->d_ctrl, ng,
+                           h->baseMVA, n, h->rsync, h->rtiles);
+    else
+        hipLaunchKernelGGL(k_resident_t<1>, dim3(grid), dim3(BR_BLOCK), 0, h->stream, h->d_dspec[0][0], h->d_dspec[1][0], h->bo, h->par.scale, h->d_ctrl, ng,
+                           h->baseMVA, n, h->rsync, h->rtiles);
     HIPCHK(hipGetLastError());
     return 0;
 }
 
-static bool resident_eligible(exaadmm_handle* h)
+static int resident_mode(exaadmm_handle* h)
 {
-    // default: on whenever every wavefront of the launch can be resident (EXAADMM_NO_RESIDENT=1 / EXAADMM_RESIDENT=0: the two-launch loop, A/B)
 #if defined(EXA_PROFILE_PHASES)
-    return false;   // (the diagnostic build's per-wavefront timelines and phase counters belong to k_branch_t)
+    // (the diagnostic build's per-wavefront timelines belong to k_branch_t; EXAADMM_PROF_RESIDENT=1: phase clocks of the resident loop's lanes)
+    if (getenv("EXAADMM_PROF_RESIDENT") == nullptr) return 0;
 #endif
-    if (getenv("EXAADMM_NO_RESIDENT") != nullptr) return false;
+    if (getenv("EXAADMM_NO_RESIDENT") != nullptr) return 0;
     if (const char* e = getenv("EXAADMM_RESIDENT"))
-        if (atoi(e) == 0) return false;
-    return h->resident_ok && h->resident_downgrades == 0 && spec_eligible(h) && !dist_has_peers(h) && h->stream == h->own_stream &&
-           branch_blocks(h) + gen_blocks(h) + 1 <= resident_capacity(h);
+        if (atoi(e) == 0) return 0;
+    if (!(h->resident_ok && h->resident_downgrades == 0 && spec_eligible(h) && !dist_has_peers(h) && h->stream == h->own_stream)) return 0;
+    const int nb = branch_blocks(h), ng = gen_blocks(h);
+    if (nb + ng + 1 <= resident_capacity(h)) return 1;
+    if (const char* e = getenv("EXAADMM_RESIDENT_TILES"))
+        if (atoi(e) == 0) return 0;
+    const int wg = (ng + 1) / 2, wb = h->resident_cap2 - wg - 1;
+    return (wb > 0 && nb > wb && nb <= 2 * wb) ? 2 : 0;
 }
+static bool resident_eligible(exaadmm_handle* h) { return resident_mode(h) != 0; }
 
 // The failure flag of the resident launches travels with the download that ends a batch (no round trip of its own):
 // resident_check_enqueue before that download's synchronisation, resident_failed after it.

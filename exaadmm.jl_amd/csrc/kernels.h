@@ -1161,10 +1161,11 @@ __device__ __forceinline__ void resident_arrive(const Dev& d, const ResidentSync
 //  plain stores while the launch runs)
 __device__ __forceinline__ int resident_passes(bool first_has_zl, int i) { return (i + 1) - (first_has_zl ? 0 : 1); }
 
-__device__ __forceinline__ void resident_contribute(const Dev& d, const ResidentSync& rs, int parity, const double (&zs)[4])
+__device__ __forceinline__ void resident_contribute(const ResidentSync& rs, int parity, int part, const double (&zs)[4])
 {
-    // (lane 0 of a wavefront, after the wave reduction of its terms)
-    double* q = rs.partials[parity] + 4 * (size_t)blockIdx.x;
+    // (lane 0 of a wavefront, after the wave reduction of its terms; part = the tile's slot in the reduction order: its block
+    //  index in the two-launch loop)
+    double* q = rs.partials[parity] + 4 * (size_t)part;
 #pragma unroll
     for (int j = 0; j < 4; j++) st_agent(q + j, zs[j]);
     resident_order_stores();
@@ -1179,17 +1180,35 @@ __device__ __forceinline__ bool resident_go_on(const ResidentSync& rs, int passe
     return __hip_atomic_load(rs.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
 }
 
-__global__ void __launch_bounds__(BR_BLOCK, 1) k_resident(const Dev* __restrict__ dp0, const Dev* __restrict__ dp1, BranchOptions o, double scale,
-                                                           Ctrl* ctrl, int gen_blocks, double baseMVA, int iters, ResidentSync rs)
+// TILES = 2: grids with more tiles of 64 branches than the chip has SIMDs (up to twice as many: ~120 000 branches).  A resident
+// wavefront then owns up to two tiles and runs, per iteration, the body once per tile (the per-lane state lives in memory between
+// iterations anyway).  Which tiles share a wavefront is decided per launch by k_resident_assign from the solver-trip counters
+// of the last iterations: the heaviest tiles -- the launch's slowest branch sets the pace of every iteration, and the set of
+// heavy branches is persistent -- get a wavefront of their own, the others are paired heavy with light, heavier first.
+// tiles[2 w], tiles[2 w + 1] = the tiles of branch wavefront w (-1: none); generator wavefront v handles generator tiles v and
+// v + wg.  Waits only ever refer to earlier (iteration, position) pairs, so the order inside a wavefront cannot deadlock.
+// Partial residual sums are indexed by TILE (the block index of the two-launch loop): the control wavefront adds them in the
+// same order as before -- same bits.
+struct ResidentTiles {
+    const int* tiles;
+    int nb, ng, wb, wg;   // branch tiles, generator tiles, branch wavefronts, generator wavefronts
+};
+
+template <int TILES>
+__global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restrict__ dp0, const Dev* __restrict__ dp1, BranchOptions o, double scale,
+                                                             Ctrl* ctrl, int gen_blocks, double baseMVA, int iters, ResidentSync rs, ResidentTiles rt)
 {
     if (ctrl->done) return;
     const int base_iter = ctrl->base;
     const double zl_beta = ctrl->beta;
     const bool first_has_zl = (base_iter + 1 != ctrl->first_iter);
-    const int nwork = gridDim.x - 1;             // the last block is the control wavefront
-    const int nbr_blocks = nwork - gen_blocks;
+    const int nwaves = gridDim.x - 1;             // the last block is the control wavefront
+    // contributions the control wavefront expects per z / l pass = tiles of the grid; wavefronts [0, nbr_waves) hold branches
+    const int nwork = (TILES == 1) ? nwaves : rt.nb + rt.ng;
+    const int nbr_waves = (TILES == 1) ? nwaves - gen_blocks : rt.wb;
+    const int nbr_tiles = (TILES == 1) ? nbr_waves : rt.nb;
     const int lane = threadIdx.x;
-    if ((int)blockIdx.x == nwork) {
+    if ((int)blockIdx.x == nwaves) {
         // ---------------- control wavefront: one decision per z / l pass
         const int npass = resident_passes(first_has_zl, iters - 1);
         for (int p = 1; p <= npass; p++) {
@@ -1223,65 +1242,76 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident(const Dev* __restrict_
         }
         return;
     }
-    if ((int)blockIdx.x >= nbr_blocks) {
+    if ((int)blockIdx.x >= nbr_waves) {
         // ---------------- generator lanes
-        const int gi = ((int)blockIdx.x - nbr_blocks) * BR_BLOCK + lane;
-        const bool on = gi < dp0->G;
-        const int g = on ? gi : 0;
-        const int I = dp0->gen_bus2[2 * g], cnt = dp0->gen_bus2[2 * g + 1];
+        const int gw = (int)blockIdx.x - nbr_waves;
         int i = 0;
         for (; i < iters; i++) {
             if (i > 0 && !resident_go_on(rs, resident_passes(first_has_zl, i - 1))) return;   // (wave-uniform)
             const Dev& d = (i & 1) ? *dp1 : *dp0;
             const bool do_zl = (i > 0) || first_has_zl;
-            double zs[4] = {0.0, 0.0, 0.0, 0.0};
-            if (on) {
-                const double* const uin = d.u_in ? d.u_in : d.u;
-                double* const vbuf = const_cast<double*>(d.v_in ? d.v_in : d.v);
-                const int pg = g, qg = d.Gp + g;
-                const double rho_p = d.rho[pg], rho_q = d.rho[qg];
-                double lp = d.l[pg], lq = d.l[qg], zp = d.z[pg], zq = d.z[qg];
-                if (do_zl) {
-                    const double up0 = uin[pg], uq0 = uin[qg];
-                    double vp, vq;
-                    if (i > 0) {
-                        if (!resident_wait(rs.ready + I, i, rs.fail)) return;
-                        const double* r = rs.busres[i & 1] + 4 * (size_t)I;
-                        vp = (up0 + zp) + (lp - ld_agent(r)) / rho_p;
-                        vq = (uq0 + zq) + (lq - ld_agent(r + 1)) / rho_q;
-                        vbuf[pg] = vp;
-                        vbuf[qg] = vq;
-                    } else {   // first index of a later batch: the previous launch left v in memory
-                        vp = vbuf[pg];
-                        vq = vbuf[qg];
+            for (int t = 0; t < TILES; t++) {
+                const int gt = gw + t * ((TILES == 1) ? 0 : rt.wg);
+                if (TILES > 1 && gt >= rt.ng) break;
+                const int gi = gt * BR_BLOCK + lane;
+                const bool on = gi < d.G;
+                const int g = on ? gi : 0;
+                const int I = d.gen_bus2[2 * g], cnt = d.gen_bus2[2 * g + 1];
+                double zs[4] = {0.0, 0.0, 0.0, 0.0};
+                if (on) {
+                    const double* const uin = d.u_in ? d.u_in : d.u;
+                    double* const vbuf = const_cast<double*>(d.v_in ? d.v_in : d.v);
+                    const int pg = g, qg = d.Gp + g;
+                    const double rho_p = d.rho[pg], rho_q = d.rho[qg];
+                    double lp = d.l[pg], lq = d.l[qg], zp = d.z[pg], zq = d.z[qg];
+                    if (do_zl) {
+                        const double up0 = uin[pg], uq0 = uin[qg];
+                        double vp, vq;
+                        if (i > 0) {
+                            if (!resident_wait(rs.ready + I, i, rs.fail)) return;
+                            const double* r = rs.busres[i & 1] + 4 * (size_t)I;
+                            vp = (up0 + zp) + (lp - ld_agent(r)) / rho_p;
+                            vq = (uq0 + zq) + (lq - ld_agent(r + 1)) / rho_q;
+                            vbuf[pg] = vp;
+                            vbuf[qg] = vq;
+                        } else {   // first index of a later batch: the previous launch left v in memory
+                            vp = vbuf[pg];
+                            vq = vbuf[qg];
+                        }
+                        zl_element(d, pg, up0, vp, rho_p, zl_beta, zs, lp, zp);
+                        zl_element(d, qg, uq0, vq, rho_q, zl_beta, zs, lq, zq);
                     }
-                    zl_element(d, pg, up0, vp, rho_p, zl_beta, zs, lp, zp);
-                    zl_element(d, qg, uq0, vq, rho_q, zl_beta, zs, lq, zq);
+                    double up, uq;
+                    generator_update(d, baseMVA, g, vbuf, up, uq);
+                    double* q = rs.terms[(i + 1) & 1] + 4 * (size_t)d.rec_gen[g];
+                    st_agent(q, (up + zp) + (lp / rho_p));
+                    st_agent(q + 1, (uq + zq) + (lq / rho_q));
                 }
-                double up, uq;
-                generator_update(d, baseMVA, g, vbuf, up, uq);
-                double* q = rs.terms[(i + 1) & 1] + 4 * (size_t)d.rec_gen[g];
-                st_agent(q, (up + zp) + (lp / rho_p));
-                st_agent(q + 1, (uq + zq) + (lq / rho_q));
-            }
-            if (do_zl) {
+                if (do_zl) {
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
+                    for (int j = 0; j < 4; j++) {
 #pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) zs[j] += __shfl_down(zs[j], off, 64);
+                        for (int off = 32; off > 0; off >>= 1) zs[j] += __shfl_down(zs[j], off, 64);
+                    }
+                    if (lane == 0) resident_contribute(rs, i & 1, nbr_tiles + gt, zs);
                 }
-                if (lane == 0) resident_contribute(d, rs, i & 1, zs);
+                resident_order_stores();
+                if (on) resident_arrive(d, rs, I, cnt, i + 1);
             }
-            resident_order_stores();
-            if (on) resident_arrive(d, rs, I, cnt, i + 1);
         }
-        if (on) {   // v of the last index (what its bus launch would have written)
+        for (int t = 0; t < TILES; t++) {   // v of the last index (what its bus launch would have written)
             const Dev& d = ((iters - 1) & 1) ? *dp1 : *dp0;
-            if (!resident_wait(rs.ready + I, iters, rs.fail)) return;
-            const double* r = rs.busres[iters & 1] + 4 * (size_t)I;
-            const int pg = g, qg = d.Gp + g;
-            d.v[pg] = (d.u[pg] + d.z[pg]) + (d.l[pg] - ld_agent(r)) / d.rho[pg];
-            d.v[qg] = (d.u[qg] + d.z[qg]) + (d.l[qg] - ld_agent(r + 1)) / d.rho[qg];
+            const int gt = gw + t * ((TILES == 1) ? 0 : rt.wg);
+            if (TILES > 1 && gt >= rt.ng) break;
+            const int gi = gt * BR_BLOCK + lane;
+            if (gi < d.G) {
+                const int I = d.gen_bus2[2 * gi];
+                if (!resident_wait(rs.ready + I, iters, rs.fail)) return;
+                const double* r = rs.busres[iters & 1] + 4 * (size_t)I;
+                const int pg = gi, qg = d.Gp + gi;
+                d.v[pg] = (d.u[pg] + d.z[pg]) + (d.l[pg] - ld_agent(r)) / d.rho[pg];
+                d.v[qg] = (d.u[qg] + d.z[qg]) + (d.l[qg] - ld_agent(r + 1)) / d.rho[qg];
+            }
         }
         return;
     }
@@ -1289,143 +1319,157 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident(const Dev* __restrict_
     __shared__ MuPowTable pw_lds;
     if (lane < 24) reinterpret_cast<double*>(&pw_lds)[lane] = reinterpret_cast<const double*>(&c_mupow)[lane];
     __shared__ double park_lds[40 * BR_BLOCK];
-    const int slot = blockIdx.x * BR_BLOCK + lane;
-    const bool lane_on = slot < dp0->L;
-    const int b = lane_on ? slot : 0;
     const int Lp = dp0->Lp;
-    const int base = 2 * dp0->Gp + b;
+    const int my_tile0 = (TILES == 1) ? (int)blockIdx.x : rt.tiles[2 * blockIdx.x];
+    const int my_tile1 = (TILES == 1) ? -1 : rt.tiles[2 * blockIdx.x + 1];
     for (int i = 0; i < iters; i++) {
         if (i > 0 && !resident_go_on(rs, resident_passes(first_has_zl, i - 1))) return;   // (wave-uniform: the loop has stopped)
         const Dev& d = (i & 1) ? *dp1 : *dp0;
-        const int4 bus4 = reinterpret_cast<const int4*>(d.br_bus4)[b];
-        const int rec_from = d.rec_br[2 * b], rec_to = d.rec_br[2 * b + 1];
-        const int major_iter = base_iter + i + 1;
-        const bool do_zl = (i > 0) || first_has_zl;
-        const bool v_from_bus = (i > 0);
-        const double* const uin = d.u_in ? d.u_in : d.u;
-        double* const vbuf = const_cast<double*>(d.v_in ? d.v_in : d.v);
-        double zs[4] = {0.0, 0.0, 0.0, 0.0};
-        double ub[8], bnd[8], vv[8], zo[8], lo[8], lzv[8];
-        BranchData bd;
+        for (int t = 0; t < TILES; t++) {
+            const int tile = (t == 0) ? my_tile0 : my_tile1;
+            if (TILES > 1 && tile < 0) break;
+            const int slot = tile * BR_BLOCK + lane;
+            const bool lane_on = slot < d.L;
+            const int b = lane_on ? slot : 0;
+            const int base = 2 * d.Gp + b;
+            const int4 bus4 = reinterpret_cast<const int4*>(d.br_bus4)[b];
+            const int rec_from = d.rec_br[2 * b], rec_to = d.rec_br[2 * b + 1];
+            const int major_iter = base_iter + i + 1;
+            const bool do_zl = (i > 0) || first_has_zl;
+            const bool v_from_bus = (i > 0);
+            const double* const uin = d.u_in ? d.u_in : d.u;
+            double* const vbuf = const_cast<double*>(d.v_in ? d.v_in : d.v);
+            double zs[4] = {0.0, 0.0, 0.0, 0.0};
+            double ub[8], bnd[8], vv[8], zo[8], lo[8], lzv[8];
+            BranchData bd;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int e = base + k * Lp;
-            ub[k] = uin[e];
-            bd.rho_[k] = d.rho[e];
-            zo[k] = d.z[e];
-            lo[k] = d.l[e];
-            lzv[k] = do_zl ? d.lz[e] : 0.0;
-            vv[k] = v_from_bus ? 0.0 : vbuf[e];
-            bd.Y_[k] = d.Y[b + k * Lp];
-            bnd[k] = d.bnd[b + k * Lp];
-        }
-        bd.ls1 = (d.ls1_in ? d.ls1_in : d.ls1)[b];
-        bd.ls2 = (d.ls2_in ? d.ls2_in : d.ls2)[b];
-        const double mu_0 = (d.mu_in ? d.mu_in : d.mu)[b];
-        const double rate_0 = d.rateA[b];
-        if (v_from_bus && lane_on) {
-            if (!resident_wait(rs.ready + bus4.x, i, rs.fail)) return;
-            if (!resident_wait(rs.ready + bus4.z, i, rs.fail)) return;
-            const double* pf = rs.busres[i & 1] + 4 * (size_t)bus4.x;
-            const double* pt = rs.busres[i & 1] + 4 * (size_t)bus4.z;
-            const double rf[4] = {ld_agent(pf), ld_agent(pf + 1), ld_agent(pf + 2), ld_agent(pf + 3)};
-            const double rt[4] = {ld_agent(pt), ld_agent(pt + 1), ld_agent(pt + 2), ld_agent(pt + 3)};
-            vv[0] = (ub[0] + zo[0]) + (lo[0] + rf[0]) / bd.rho_[0];
-            vv[1] = (ub[1] + zo[1]) + (lo[1] + rf[1]) / bd.rho_[1];
-            vv[4] = rf[2];
-            vv[6] = rf[3];
-            vv[2] = (ub[2] + zo[2]) + (lo[2] + rt[0]) / bd.rho_[2];
-            vv[3] = (ub[3] + zo[3]) + (lo[3] + rt[1]) / bd.rho_[3];
-            vv[5] = rt[2];
-            vv[7] = rt[3];
-#pragma unroll
-            for (int k = 0; k < 8; k++) vbuf[base + k * Lp] = vv[k];   // (what the bus launch of the previous index would have written)
-        }
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            if (do_zl && lane_on) {
+            for (int k = 0; k < 8; k++) {
                 const int e = base + k * Lp;
-                double zn;
-                zl_values(ub[k], vv[k], bd.rho_[k], zl_beta, lzv[k], zo[k], lo[k], zs, bd.lam_[k], zn);
-                d.zp[e] = zo[k];
-                d.z[e] = zn;
-                d.l[e] = bd.lam_[k];
-                bd.xt_[k] = vv[k] - zn;
-                zo[k] = zn;
-            } else {
-                bd.lam_[k] = lo[k];
-                bd.xt_[k] = vv[k] - zo[k];
+                ub[k] = uin[e];
+                bd.rho_[k] = d.rho[e];
+                zo[k] = d.z[e];
+                lo[k] = d.l[e];
+                lzv[k] = do_zl ? d.lz[e] : 0.0;
+                vv[k] = v_from_bus ? 0.0 : vbuf[e];
+                bd.Y_[k] = d.Y[b + k * Lp];
+                bnd[k] = d.bnd[b + k * Lp];
             }
-            park_lds[(32 + k) * BR_BLOCK + lane] = zo[k];
-        }
-        if (do_zl) {
-            const bool counts = lane_on && (b < d.Lown);
+            bd.ls1 = (d.ls1_in ? d.ls1_in : d.ls1)[b];
+            bd.ls2 = (d.ls2_in ? d.ls2_in : d.ls2)[b];
+            const double mu_0 = (d.mu_in ? d.mu_in : d.mu)[b];
+            const double rate_0 = d.rateA[b];
+            if (v_from_bus && lane_on) {
+                if (!resident_wait(rs.ready + bus4.x, i, rs.fail)) return;
+                if (!resident_wait(rs.ready + bus4.z, i, rs.fail)) return;
+                const double* pf = rs.busres[i & 1] + 4 * (size_t)bus4.x;
+                const double* pt = rs.busres[i & 1] + 4 * (size_t)bus4.z;
+                const double rf[4] = {ld_agent(pf), ld_agent(pf + 1), ld_agent(pf + 2), ld_agent(pf + 3)};
+                const double rt4[4] = {ld_agent(pt), ld_agent(pt + 1), ld_agent(pt + 2), ld_agent(pt + 3)};
+                vv[0] = (ub[0] + zo[0]) + (lo[0] + rf[0]) / bd.rho_[0];
+                vv[1] = (ub[1] + zo[1]) + (lo[1] + rf[1]) / bd.rho_[1];
+                vv[4] = rf[2];
+                vv[6] = rf[3];
+                vv[2] = (ub[2] + zo[2]) + (lo[2] + rt4[0]) / bd.rho_[2];
+                vv[3] = (ub[3] + zo[3]) + (lo[3] + rt4[1]) / bd.rho_[3];
+                vv[5] = rt4[2];
+                vv[7] = rt4[3];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                if (!counts) zs[j] = 0.0;
+                for (int k = 0; k < 8; k++) vbuf[base + k * Lp] = vv[k];   // (what the bus launch of the previous index would have written)
+            }
 #pragma unroll
-                for (int off = 32; off > 0; off >>= 1) zs[j] += __shfl_down(zs[j], off, 64);
+            for (int k = 0; k < 8; k++) {
+                if (do_zl && lane_on) {
+                    const int e = base + k * Lp;
+                    double zn;
+                    zl_values(ub[k], vv[k], bd.rho_[k], zl_beta, lzv[k], zo[k], lo[k], zs, bd.lam_[k], zn);
+                    d.zp[e] = zo[k];
+                    d.z[e] = zn;
+                    d.l[e] = bd.lam_[k];
+                    bd.xt_[k] = vv[k] - zn;
+                    zo[k] = zn;
+                } else {
+                    bd.lam_[k] = lo[k];
+                    bd.xt_[k] = vv[k] - zo[k];
+                }
+                park_lds[(32 + k) * BR_BLOCK + lane] = zo[k];
             }
-            if (lane == 0) resident_contribute(d, rs, i & 1, zs);
-        }
-        if (lane_on) {
-            bd.mu = (major_iter == 1) ? 10.0 : mu_0;
-            bd.scale = scale;
-            SymMat<6> A, L;
-            double x[6], xl[6], xu[6], phi[4];
-            branch_start(ub, bnd, rate_0, x, xl, xu);
-            BranchStats st;
-            st.tl = nullptr;
-            branch_solve(bd, o, pw_lds, x, xl, xu, A, L, phi, st, park_lds + lane);
-            d.u[base] = phi[0];
-            d.u[base + Lp] = phi[1];
-            d.u[base + 2 * Lp] = phi[2];
-            d.u[base + 3 * Lp] = phi[3];
-            d.u[base + 4 * Lp] = x[0] * x[0];
-            d.u[base + 5 * Lp] = x[1] * x[1];
-            d.u[base + 6 * Lp] = x[2];
-            d.u[base + 7 * Lp] = x[3];
-            double zz[8];
+            if (do_zl) {
+                const bool counts = lane_on && (b < d.Lown);
 #pragma unroll
-            for (int k = 0; k < 8; k++) zz[k] = park_lds[(32 + k) * BR_BLOCK + lane];
-            const double un[8] = {phi[0], phi[1], phi[2], phi[3], x[0] * x[0], x[1] * x[1], x[2], x[3]};
-            double* const tm = rs.terms[(i + 1) & 1];
-            {
-                double* q = tm + 4 * (size_t)rec_from;
-                st_agent(q, (un[0] + zz[0]) + (bd.lam_[0] / bd.rho_[0]));
-                st_agent(q + 1, (un[1] + zz[1]) + (bd.lam_[1] / bd.rho_[1]));
-                st_agent(q + 2, bd.lam_[4] + bd.rho_[4] * (un[4] + zz[4]));
-                st_agent(q + 3, bd.lam_[6] + bd.rho_[6] * (un[6] + zz[6]));
+                for (int j = 0; j < 4; j++) {
+                    if (!counts) zs[j] = 0.0;
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) zs[j] += __shfl_down(zs[j], off, 64);
+                }
+                if (lane == 0) resident_contribute(rs, i & 1, tile, zs);
             }
-            {
-                double* q = tm + 4 * (size_t)rec_to;
-                st_agent(q, (un[2] + zz[2]) + (bd.lam_[2] / bd.rho_[2]));
-                st_agent(q + 1, (un[3] + zz[3]) + (bd.lam_[3] / bd.rho_[3]));
-                st_agent(q + 2, bd.lam_[5] + bd.rho_[5] * (un[5] + zz[5]));
-                st_agent(q + 3, bd.lam_[7] + bd.rho_[7] * (un[7] + zz[7]));
+            if (lane_on) {
+                bd.mu = (major_iter == 1) ? 10.0 : mu_0;
+                bd.scale = scale;
+                SymMat<6> A, L;
+                double x[6], xl[6], xu[6], phi[4];
+                branch_start(ub, bnd, rate_0, x, xl, xu);
+                BranchStats st;
+                st.tl = nullptr;
+                branch_solve(bd, o, pw_lds, x, xl, xu, A, L, phi, st, park_lds + lane);
+                d.u[base] = phi[0];
+                d.u[base + Lp] = phi[1];
+                d.u[base + 2 * Lp] = phi[2];
+                d.u[base + 3 * Lp] = phi[3];
+                d.u[base + 4 * Lp] = x[0] * x[0];
+                d.u[base + 5 * Lp] = x[1] * x[1];
+                d.u[base + 6 * Lp] = x[2];
+                d.u[base + 7 * Lp] = x[3];
+                double zz[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) zz[k] = park_lds[(32 + k) * BR_BLOCK + lane];
+                const double un[8] = {phi[0], phi[1], phi[2], phi[3], x[0] * x[0], x[1] * x[1], x[2], x[3]};
+                double* const tm = rs.terms[(i + 1) & 1];
+                {
+                    double* q = tm + 4 * (size_t)rec_from;
+                    st_agent(q, (un[0] + zz[0]) + (bd.lam_[0] / bd.rho_[0]));
+                    st_agent(q + 1, (un[1] + zz[1]) + (bd.lam_[1] / bd.rho_[1]));
+                    st_agent(q + 2, bd.lam_[4] + bd.rho_[4] * (un[4] + zz[4]));
+                    st_agent(q + 3, bd.lam_[6] + bd.rho_[6] * (un[6] + zz[6]));
+                }
+                {
+                    double* q = tm + 4 * (size_t)rec_to;
+                    st_agent(q, (un[2] + zz[2]) + (bd.lam_[2] / bd.rho_[2]));
+                    st_agent(q + 1, (un[3] + zz[3]) + (bd.lam_[3] / bd.rho_[3]));
+                    st_agent(q + 2, bd.lam_[5] + bd.rho_[5] * (un[5] + zz[5]));
+                    st_agent(q + 3, bd.lam_[7] + bd.rho_[7] * (un[7] + zz[7]));
+                }
+                d.ls1[b] = bd.ls1;
+                d.ls2[b] = bd.ls2;
+                d.mu[b] = bd.mu;
+                d.st_auglag[b] = st.auglag_it;
+                d.st_minor[b] = st.minor_it;
+                d.st_ticks[b] = st.ticks;
+#if defined(EXA_PROFILE_PHASES)
+                for (int q = 0; q < 13; q++) d.st_cyc[q * d.Lp + b] = st.cyc[q];   // (phase clocks of the lane's last solve)
+#endif
             }
-            d.ls1[b] = bd.ls1;
-            d.ls2[b] = bd.ls2;
-            d.mu[b] = bd.mu;
-            d.st_auglag[b] = st.auglag_it;
-            d.st_minor[b] = st.minor_it;
-            d.st_ticks[b] = st.ticks;
-        }
-        resident_order_stores();
-        if (lane_on) {
-            resident_arrive(d, rs, bus4.x, bus4.y, i + 1);
-            resident_arrive(d, rs, bus4.z, bus4.w, i + 1);
+            resident_order_stores();
+            if (lane_on) {
+                resident_arrive(d, rs, bus4.x, bus4.y, i + 1);
+                resident_arrive(d, rs, bus4.z, bus4.w, i + 1);
+            }
         }
     }
-    if (lane_on) {   // v of the last index (what its bus launch would have written)
+    for (int t = 0; t < TILES; t++) {   // v of the last index (what its bus launch would have written)
         const Dev& d = ((iters - 1) & 1) ? *dp1 : *dp0;
+        const int tile = (t == 0) ? my_tile0 : my_tile1;
+        if (TILES > 1 && tile < 0) break;
+        const int slot = tile * BR_BLOCK + lane;
+        if (slot >= d.L) continue;
+        const int b = slot, base = 2 * d.Gp + b;
         const int4 bus4 = reinterpret_cast<const int4*>(d.br_bus4)[b];
         if (!resident_wait(rs.ready + bus4.x, iters, rs.fail)) return;
         if (!resident_wait(rs.ready + bus4.z, iters, rs.fail)) return;
         const double* pf = rs.busres[iters & 1] + 4 * (size_t)bus4.x;
         const double* pt = rs.busres[iters & 1] + 4 * (size_t)bus4.z;
         const double rf[4] = {ld_agent(pf), ld_agent(pf + 1), ld_agent(pf + 2), ld_agent(pf + 3)};
-        const double rt[4] = {ld_agent(pt), ld_agent(pt + 1), ld_agent(pt + 2), ld_agent(pt + 3)};
+        const double rt4[4] = {ld_agent(pt), ld_agent(pt + 1), ld_agent(pt + 2), ld_agent(pt + 3)};
         double uu[8], zz[8], ll[8], rr[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
@@ -1437,12 +1481,49 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident(const Dev* __restrict_
         }
         d.v[base] = (uu[0] + zz[0]) + (ll[0] + rf[0]) / rr[0];
         d.v[base + Lp] = (uu[1] + zz[1]) + (ll[1] + rf[1]) / rr[1];
-        d.v[base + 2 * Lp] = (uu[2] + zz[2]) + (ll[2] + rt[0]) / rr[2];
-        d.v[base + 3 * Lp] = (uu[3] + zz[3]) + (ll[3] + rt[1]) / rr[3];
+        d.v[base + 2 * Lp] = (uu[2] + zz[2]) + (ll[2] + rt4[0]) / rr[2];
+        d.v[base + 3 * Lp] = (uu[3] + zz[3]) + (ll[3] + rt4[1]) / rr[3];
         d.v[base + 4 * Lp] = rf[2];
-        d.v[base + 5 * Lp] = rt[2];
+        d.v[base + 5 * Lp] = rt4[2];
         d.v[base + 6 * Lp] = rf[3];
-        d.v[base + 7 * Lp] = rt[3];
+        d.v[base + 7 * Lp] = rt4[3];
+    }
+}
+
+// Which tiles share a resident wavefront (k_resident_t<2>): one block.  key[tile] = largest solver-trip count of the tile's
+// lanes in the last accepted x-updates (both buffer sets), tiles ranked by key (ties by index), the S = 2 wb - nb heaviest
+// get a wavefront each, the other 2 (nb - wb) are paired heaviest with lightest, the heavier of a pair first.
+__global__ void __launch_bounds__(1024) k_resident_assign(const int* __restrict__ ticks0, const int* __restrict__ ticks1, int L, int nb, int wb, int* __restrict__ tiles)
+{
+    extern __shared__ int sh[];   // key[nb], order[nb]
+    int* key = sh;
+    int* order = sh + nb;
+    for (int t = threadIdx.x; t < nb; t += blockDim.x) {
+        int k = 0;
+        for (int j = 0; j < BR_BLOCK; j++) {
+            const int b = t * BR_BLOCK + j;
+            if (b < L) k = max(k, max(ticks0[b], ticks1[b]));
+        }
+        key[t] = k;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < nb; t += blockDim.x) {
+        const int k = key[t];
+        int rank = 0;
+        for (int s = 0; s < nb; s++) rank += (key[s] > k || (key[s] == k && s < t)) ? 1 : 0;
+        order[rank] = t;
+    }
+    __syncthreads();
+    const int singles = 2 * wb - nb, pairs = nb - wb;
+    for (int w = threadIdx.x; w < wb; w += blockDim.x) {
+        if (w < singles) {
+            tiles[2 * w] = order[w];
+            tiles[2 * w + 1] = -1;
+        } else {
+            const int k = w - singles;
+            tiles[2 * w] = order[singles + k];
+            tiles[2 * w + 1] = (k < pairs) ? order[nb - 1 - k] : -1;
+        }
     }
 }
 

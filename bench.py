@@ -303,11 +303,11 @@ def main():
     try:
         kr = json.load(open(os.path.join(ROOT, "exaadmm.jl_amd", "kernel_resources.json")))
         if kr.get("source_digest") and ("src:" + kr["source_digest"]) in lib_version:
-            kernel_resources = kr["kernels"].get("k_resident" if resident else ("k_branch_t<true,false>" if T > 1 else "k_branch_t<false,true>"))
+            kernel_resources = kr["kernels"].get("k_resident" if resident else (("k_branch_t<true,true>" if mod.loop_kind() == 1 else "k_branch_t<true,false>") if T > 1 else "k_branch_t<false,true>"))
     except Exception:
         pass
     branch_bytes = BYTES_PER_BRANCH_SOLVE * L
-    fused_zl = (T == 1 and not os.environ.get("EXAADMM_NO_SPEC") and os.environ.get("EXAADMM_BUS_KERNEL") != "lane")
+    fused_zl = (not os.environ.get("EXAADMM_NO_SPEC") and os.environ.get("EXAADMM_BUS_KERNEL") != "lane" and (T == 1 or not os.environ.get("EXAADMM_MP_NO_SPEC")))
     if fused_zl:
         # the launch also carries the generator update (128 B per generator) and the z / l / residual pass of the previous
         # iteration; of the latter only what the branch loads do not already bring counts: lz read + z, z_prev, l writes

@@ -783,6 +783,12 @@ class ModelMpacopf:
         a = np.ascontiguousarray(np.asarray(value, dtype=np.float64).T)
         _check(library().exaadmm_upload_membuf(self._h, _dp(a), 31, n), "upload membuf")
 
+    def loop_kind(self):
+        """0 = four launches per iteration, 1 = two (the z / l pass of an iteration rides in the next branch launch)"""
+        k = C.c_int()
+        _check(library().exaadmm_loop_kind(self._h, C.byref(k)), "exaadmm_loop_kind")
+        return k.value
+
     def run_inner(self, outer, max_inner, beta):
         self.sync_params()
         done = C.c_int()

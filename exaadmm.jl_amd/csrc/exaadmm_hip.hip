@@ -120,6 +120,7 @@ struct exaadmm_handle {
     struct IterSet {
         double *u = nullptr, *v = nullptr, *ls1 = nullptr, *ls2 = nullptr, *mu = nullptr, *z = nullptr, *l = nullptr;
         int* st[3] = {nullptr, nullptr, nullptr};
+        double *r_u = nullptr, *r_s = nullptr, *r_mu = nullptr, *r_xi = nullptr;   // multi-period model: what the ramp subproblems write
     };
     IterSet sets[3], alt[2];
     int nsets = 0;
@@ -1411,7 +1412,8 @@ extern "C" int exaadmm_debug_wave_timeline(exaadmm_handle* h, unsigned long long
 // every cut branch + this rank's four residual sums -> grouped ncclSend / ncclRecv -> k_halo_unpack (scatter, add the
 // sums in rank order, advance the loop control).  The loop test of iteration k is known one launch late; the iterate is
 // double-buffered by iteration parity so that the stopping iteration's state survives its speculative successor.
-static bool spec_eligible(const exaadmm_handle* h) { return h->spec_on && h->T == 1 && !h->ctrl_mode; }
+// (EXAADMM_MP_NO_SPEC=1: A/B switch, the multi-period model keeps the four-launch loop)
+static bool spec_eligible(const exaadmm_handle* h) { return h->spec_on && !h->ctrl_mode && (h->T == 1 || getenv("EXAADMM_MP_NO_SPEC") == nullptr); }
 
 // resident loop: every wavefront of the launch must hold a SIMD for the whole launch (one wavefront per SIMD)
 static int resident_capacity(exaadmm_handle* h)
@@ -1577,7 +1579,7 @@ static int resident_mode(exaadmm_handle* h)
     if (getenv("EXAADMM_NO_RESIDENT") != nullptr) return 0;
     if (const char* e = getenv("EXAADMM_RESIDENT"))
         if (atoi(e) == 0) return 0;
-    if (!(h->resident_ok && h->resident_downgrades == 0 && spec_eligible(h) && !dist_has_peers(h) && h->stream == h->own_stream)) return 0;
+    if (!(h->resident_ok && h->T == 1 && h->resident_downgrades == 0 && spec_eligible(h) && !dist_has_peers(h) && h->stream == h->own_stream)) return 0;
     const int nb = branch_blocks(h), ng = gen_blocks(h);
     if (nb + ng + 1 <= resident_capacity(h)) return 1;
     if (const char* e = getenv("EXAADMM_RESIDENT_TILES"))
@@ -1637,6 +1639,16 @@ static int spec_prepare(exaadmm_handle* h)
         HIPCHK(hipMemsetAsync(a.ls2, 0, (size_t)h->Lp * sizeof(double), h->stream));
         HIPCHK(hipMemsetAsync(a.mu, 0, (size_t)h->Lp * sizeof(double), h->stream));
     }
+    const size_t nramp = (size_t)std::max(h->T * h->g1, 1);
+    if (h->T > 1 && !h->alt[0].r_u) {
+        exaadmm_handle::IterSet& a = h->alt[0];
+        double** rv[4] = {&a.r_u, &a.r_s, &a.r_mu, &a.r_xi};
+        const double* src[4] = {h->d.r_u, h->d.r_s, h->d.r_mu, h->d.r_xi};
+        for (int q = 0; q < 4; q++) {
+            if ((rc = dev_alloc(h, rv[q], nramp))) return rc;
+            HIPCHK(hipMemcpyAsync(*rv[q], src[q], nramp * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        }
+    }
     if (want == 3 && !h->zp_scratch) {
         for (int q = 0; q < 2; q++) {
             if ((rc = dev_alloc(h, &h->alt[q].z, (size_t)h->N))) return rc;
@@ -1646,8 +1658,11 @@ static int spec_prepare(exaadmm_handle* h)
         }
         if ((rc = dev_alloc(h, &h->zp_scratch, (size_t)h->N))) return rc;
     }
+    // multi-period model: a block's partial sums have one slot per period its 64 lanes can belong to
+    const int part_k = (h->T > 1) ? std::min(h->T, (BR_BLOCK - 1) / std::max(1, std::min(h->l1, std::max(h->g1, 1))) + 2) : 1;
     if (!h->partials_br) {
-        if ((rc = dev_alloc(h, &h->partials_br, (size_t)(branch_blocks(h) + gen_blocks(h)) * 4))) return rc;
+        if ((rc = dev_alloc(h, &h->partials_br, (size_t)(branch_blocks(h) + gen_blocks(h)) * 4 * part_k))) return rc;
+        HIPCHK(hipMemsetAsync(h->partials_br, 0, (size_t)(branch_blocks(h) + gen_blocks(h)) * 4 * part_k * sizeof(double), h->stream));
         for (auto& row : h->d_dspec)
             for (auto& q : row)
                 if ((rc = dev_alloc(h, &q, 1))) return rc;
@@ -1661,6 +1676,7 @@ static int spec_prepare(exaadmm_handle* h)
     exaadmm_handle::IterSet prim;
     prim.u = h->d.u; prim.v = h->d.v; prim.ls1 = h->d.ls1; prim.ls2 = h->d.ls2; prim.mu = h->d.mu; prim.z = h->d.z; prim.l = h->d.l;
     prim.st[0] = h->d.st_auglag; prim.st[1] = h->d.st_minor; prim.st[2] = h->d.st_ticks;
+    prim.r_u = h->d.r_u; prim.r_s = h->d.r_s; prim.r_mu = h->d.r_mu; prim.r_xi = h->d.r_xi;
     exaadmm_handle::IterSet sets[3];
     for (int q = 0; q < n - 1; q++) sets[q] = h->alt[q];
     sets[n - 1] = prim;
@@ -1685,6 +1701,13 @@ static int spec_prepare(exaadmm_handle* h)
             a.z_in = sets[(r + 1) % 3].z;  a.l_in = sets[(r + 1) % 3].l;
             a.zp = h->zp_scratch;
         }
+        if (h->T > 1) {   // multi-period model: the ramp subproblems' outputs rotate with the iterate (the bus launch gathers the generators)
+            a.r_u_in = rd.r_u;    a.r_u = w.r_u;
+            a.r_s_in = rd.r_s;    a.r_s = w.r_s;
+            a.r_mu_in = rd.r_mu;  a.r_mu = w.r_mu;
+            a.r_xi_in = rd.r_xi;  a.r_xi = w.r_xi;
+        }
+        a.part_k = part_k;
         a.partials_br = h->partials_br;
         a.npartials_br = nb + ng;
         a.blk0 = 0;
@@ -1696,6 +1719,7 @@ static int spec_prepare(exaadmm_handle* h)
         fin[r] = a;
         fin[r].u = const_cast<double*>(a.u_in);
         fin[r].v = const_cast<double*>(a.v_in);
+        if (h->T > 1) fin[r].r_u = const_cast<double*>(a.r_u_in);
     }
     bool changed = (h->nsets != n);
     for (int r = 0; r < n && !changed; r++)
@@ -1724,11 +1748,18 @@ static int enqueue_iteration_spec(exaadmm_handle* h, Ctrl* c, int j, bool sample
     const int nb = branch_blocks(h), ng = gen_blocks(h);
     if (sample) (void)hipEventRecord(h->tev[0], h->stream);
     if (bev) (void)hipEventRecord(bev[0], h->stream);
-    hipLaunchKernelGGL((k_branch_t<false, true>), dim3(nb + ng), dim3(BR_BLOCK), 0, h->stream, h->d_dspec[r][0], h->bo, h->par.scale, 0, c,
-                       ng, j, h->baseMVA);
+    if (h->T > 1)
+        hipLaunchKernelGGL((k_branch_t<true, true>), dim3(nb + ng), dim3(BR_BLOCK), 0, h->stream, h->d_dspec[r][0], h->bo, h->par.scale, 0, c,
+                           ng, j, h->baseMVA);
+    else
+        hipLaunchKernelGGL((k_branch_t<false, true>), dim3(nb + ng), dim3(BR_BLOCK), 0, h->stream, h->d_dspec[r][0], h->bo, h->par.scale, 0, c,
+                           ng, j, h->baseMVA);
     if (bev) (void)hipEventRecord(bev[1], h->stream);
     if (sample) (void)hipEventRecord(h->tev[1], h->stream);
-    if (dv.rec != nullptr)   // the branch launch has pushed the bus records
+    if (dv.rec != nullptr && h->T > 1)   // multi-period model: records for the branch ends, gathers for the generators (ramp partners)
+        hipLaunchKernelGGL((k_bus_group_t<true, true>), dim3(grid_for(h->B, BUS_BLOCK / BUS_W).x + 1), dim3(BUS_BLOCK), 0, h->stream, (const Ctrl*)c, c, (const double*)dv.rec, dv.EndCount, dv.SlotCode,
+                           dv.busc, dv.B, dv, h->baseMVA);
+    else if (dv.rec != nullptr)   // the branch launch has pushed the bus records
         hipLaunchKernelGGL((k_bus_group_t<true>), dim3(grid_for(h->B, BUS_BLOCK / BUS_W).x + 1), dim3(BUS_BLOCK), 0, h->stream, (const Ctrl*)c, c, (const double*)dv.rec, dv.EndCount, dv.SlotCode,
                            dv.busc, dv.B, dv, h->baseMVA);
     else
@@ -1762,6 +1793,13 @@ static int spec_finish(exaadmm_handle* h, int iters)
         HIPCHK(hipMemcpyAsync(dst.mu, src.mu, LB, hipMemcpyDeviceToDevice, h->stream));
         for (int q = 0; q < 3; q++)
             HIPCHK(hipMemcpyAsync(dst.st[q], src.st[q], (size_t)h->Lp * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+        if (h->T > 1) {
+            const size_t RB = (size_t)h->T * h->g1 * sizeof(double);
+            HIPCHK(hipMemcpyAsync(dst.r_u, src.r_u, RB, hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(dst.r_s, src.r_s, RB, hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(dst.r_mu, src.r_mu, RB, hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(dst.r_xi, src.r_xi, RB, hipMemcpyDeviceToDevice, h->stream));
+        }
         if (n == 3) {
             HIPCHK(hipMemcpyAsync(dst.z, src.z, NB, hipMemcpyDeviceToDevice, h->stream));
             HIPCHK(hipMemcpyAsync(dst.l, src.l, NB, hipMemcpyDeviceToDevice, h->stream));
@@ -1776,6 +1814,11 @@ static int spec_complete_last(exaadmm_handle* h, int enqueued)
 {
     if (enqueued <= 0) return 0;
     const Dev& dv = h->dfin[enqueued % h->nsets];   // u, v, (z, l) of the last enqueued iteration -> its z / l pass
+    if (h->T > 1) {   // multi-period model: the per-period pass and reduction of the four-launch loop (both return at once after a stop)
+        hipLaunchKernelGGL((k_mp_elem<MP_FUSED_ZL>), dim3(h->mp_nbx, h->T, MP_PLANES), dim3(EW_BLOCK), 0, h->stream, dv, 0.0, h->par.MAX_MULTIPLIER, (const Ctrl*)h->d_ctrl);
+        hipLaunchKernelGGL(k_final_reduce_mp, dim3(1), dim3(EW_BLOCK), 0, h->stream, h->d.partials, MP_PLANES * h->mp_nbx, h->T, h->d_sums, h->d_ctrl);
+        return 0;
+    }
     hipLaunchKernelGGL(k_fused_zl, dim3(h->ew_blocks), dim3(EW_BLOCK), 0, h->stream, dv, 0.0, h->d_ctrl, &h->d_ctrl->pending);
     if (!dist_has_peers(h)) {
         hipLaunchKernelGGL(k_final_reduce, dim3(1), dim3(EW_BLOCK), 0, h->stream, h->d.partials, h->ew_blocks, h->d_sums, h->d_ctrl, 1, 1);

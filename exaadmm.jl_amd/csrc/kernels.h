@@ -95,6 +95,11 @@ struct Dev {
     // buffer sets, z and l included.  z_in / l_in = z, l of the iteration BEFORE the one whose z / l pass rides in this launch's
     // prologue (the pass reads them and writes d.z / d.l, another set); nullptr = in place (one GPU: two sets, d.zp kept).
     const double *z_in, *l_in;
+    // multi-period model on the fused loop: what the ramp subproblem of a generator READS of the previous iterate (phat, s,
+    // multiplier, penalty; nullptr = the buffers it writes), and how many per-period slots a block's partial residual sums
+    // have (a block of 64 lanes may hold lanes of several periods: the norms are per period, max over periods)
+    const double *r_u_in, *r_s_in, *r_mu_in, *r_xi_in;
+    int part_k;
     // multi-period model (ModelMpacopf): T periods stored period-major inside every
     // plane (generator t*g1+i, branch t*l1+j, bus t*b1+k); T = 1 for the single-period model.
     // Ramp block (SolutionRamping of period t >= 1) at [t*g1 + i]; block 0 is unused.
@@ -160,6 +165,28 @@ __device__ __forceinline__ void zl_element(const Dev& d, int e, double u, double
     d.l[e] = l_new;
 }
 
+// per-period partial sums of a wavefront whose lanes [first, first + 64) of a period-major index range (n per period) may belong to
+// several periods: slot k of the block = period t_first + k.  t_lane < 0: the lane contributes nothing.
+__device__ __forceinline__ void mp_block_partials(const Dev& d, int part, int first, int n, int total, int t_lane, const double (&zs)[4])
+{
+    const int t0 = first / n;
+    const int last = min(total, first + BR_BLOCK) - 1;
+    const int t1 = last >= first ? last / n : t0 - 1;
+    for (int t = t0; t <= t1; t++) {
+        double s[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            s[j] = (t_lane == t) ? zs[j] : 0.0;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) s[j] += __shfl_down(s[j], off, 64);
+        }
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) d.partials_br[((size_t)part * d.part_k + (t - t0)) * 4 + j] = s[j];
+        }
+    }
+}
+
 __global__ void k_generator(Dev d, double baseMVA, const Ctrl* ctrl)
 {
     if (loop_done(ctrl)) return;
@@ -196,6 +223,66 @@ __device__ __forceinline__ void gen_ramp_lane(const Dev& d, const BranchOptions&
     gd.xt_h = d.v[pg - d.g1] - d.r_z[i];   // pbar of the previous period (mpacopf_admm_update_x_cpu.jl:19)
     gd.mu = d.r_mu[i];
     gd.xi = (major_iter <= 1) ? 10.0 : d.r_xi[i];
+    gd.c2 = d.c2[i];
+    gd.c1 = d.c1[i];
+    gd.c0 = d.c0[i];
+    gd.M = baseMVA;
+    int it, minor;
+    genramp_solve(gd, o, c_mupow, x, xl, xu, it, minor);
+    d.u[pg] = x[0];
+    d.r_u[i] = x[1];
+    d.r_s[i] = x[2];
+    d.r_mu[i] = gd.mu;
+    d.r_xi[i] = gd.xi;
+}
+
+// The same lane in the fused loop (k_branch_t<true, true>): the z / l / residual pass of the PREVIOUS iteration for the lane's own
+// elements -- pg, qg and, for a generator of period t >= 1, its ramp element (consensus partner: pbar of the previous period,
+// mpacopf_admm_update_z_cpu.jl:10-14) -- then the update, reading the previous iterate (u_in, v_in, r_*_in) and writing the
+// other buffer set.  zs receives the lane's residual terms (they count in the lane's period).
+__device__ __forceinline__ void gen_ramp_lane_zl(const Dev& d, const BranchOptions& o, double baseMVA, int major_iter, int i, bool do_zl,
+                                                 double zl_beta, double (&zs)[4])
+{
+    if (i >= d.G) return;
+    const double* const uin = d.u_in ? d.u_in : d.u;
+    const double* const vin = d.v_in ? d.v_in : d.v;
+    const int pg = i, qg = d.Gp + i;
+    const bool ramp = (i >= d.g1);
+    if (do_zl) {
+        double ln, zn;
+        zl_element(d, pg, uin[pg], vin[pg], d.rho[pg], zl_beta, zs, ln, zn);
+        zl_element(d, qg, uin[qg], vin[qg], d.rho[qg], zl_beta, zs, ln, zn);
+        if (ramp) {
+            const double lz = d.r_lz[i], zold = d.r_z[i];
+            zl_values((d.r_u_in ? d.r_u_in : d.r_u)[i], vin[pg - d.g1], d.r_rho[i], zl_beta, lz, zold, d.r_l[i], zs, ln, zn);
+            d.r_zp[i] = zold;
+            d.r_z[i] = zn;
+            d.r_l[i] = ln;
+        }
+    }
+    if (!ramp) {
+        double up, uq;
+        generator_update(d, baseMVA, i, vin, up, uq);
+        return;
+    }
+    d.u[qg] = fmax(d.qgmin[i], fmin(d.qgmax[i], (-(d.l[qg] + d.rho[qg] * (-vin[qg] + d.z[qg]))) / d.rho[qg]));
+    double x[3], xl[3], xu[3];
+    xl[0] = xl[1] = d.pgmin[i];
+    xu[0] = xu[1] = d.pgmax[i];
+    xl[2] = -d.ramp_rate[i];
+    xu[2] = d.ramp_rate[i];
+    x[0] = fmin(xu[0], fmax(xl[0], uin[pg]));
+    x[1] = fmin(xu[1], fmax(xl[1], (d.r_u_in ? d.r_u_in : d.r_u)[i]));
+    x[2] = fmin(xu[2], fmax(xl[2], (d.r_s_in ? d.r_s_in : d.r_s)[i]));
+    GenRampData gd;
+    gd.lam_p = d.l[pg];
+    gd.lam_h = d.r_l[i];
+    gd.rho_p = d.rho[pg];
+    gd.rho_h = d.r_rho[i];
+    gd.xt_p = vin[pg] - d.z[pg];
+    gd.xt_h = vin[pg - d.g1] - d.r_z[i];   // pbar of the previous period (mpacopf_admm_update_x_cpu.jl:19)
+    gd.mu = (d.r_mu_in ? d.r_mu_in : d.r_mu)[i];
+    gd.xi = (major_iter <= 1) ? 10.0 : (d.r_xi_in ? d.r_xi_in : d.r_xi)[i];
     gd.c2 = d.c2[i];
     gd.c1 = d.c1[i];
     gd.c0 = d.c0[i];
@@ -269,7 +356,10 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_branch_t(const Dev* __restrict_
     double zs[4] = {0.0, 0.0, 0.0, 0.0};   // ZL: this lane's residual terms
     if ((int)blockIdx.x >= nbr_blocks) {
         const int gi = ((int)blockIdx.x - nbr_blocks) * BR_BLOCK + threadIdx.x;
-        if (MP)   // multi-period model: ramp subproblems run beside the branch solves, same launch
+        if (MP && ZL) {   // multi-period model on the fused loop: z / l pass (incl. the ramp element) + ramp subproblem, per-period partial sums
+            gen_ramp_lane_zl(d, o, baseMVA, major_iter, gi, do_zl, zl_beta, zs);
+            if (do_zl) mp_block_partials(d, d.gen_part0 + ((int)blockIdx.x - nbr_blocks), ((int)blockIdx.x - nbr_blocks) * BR_BLOCK, d.g1, d.G, gi < d.G ? gi / d.g1 : -1, zs);
+        } else if (MP)   // multi-period model: ramp subproblems run beside the branch solves, same launch
             gen_ramp_lane(d, o, baseMVA, major_iter, gi);
         else if (ZL) {
             const double* const uin = d.u_in ? d.u_in : d.u;
@@ -389,7 +479,9 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_branch_t(const Dev* __restrict_
             }
             park_lds[(32 + k) * BR_BLOCK + threadIdx.x] = zo[k];   // z of the iterate: the epilogue's bus records need it again
         }
-        if (do_zl) {   // per-block partial sums of the four residual norms (fixed topology: wave shuffle, one wave per block)
+        if (MP && do_zl) {   // multi-period model: per-period partial sums (a block may hold lanes of several periods)
+            mp_block_partials(d, blk, blk * BR_BLOCK, d.l1, d.L, lane_on ? b / d.l1 : -1, zs);
+        } else if (do_zl) {   // per-block partial sums of the four residual norms (fixed topology: wave shuffle, one wave per block)
             const bool counts = (b < d.Lown);   // a peer's branch replicated here: its terms are summed by its owner
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -740,6 +832,21 @@ __device__ __forceinline__ void ctrl_advance(Ctrl* c, const double (&s)[4])
     if ((test && c->res[0] <= c->eps_pri) || inner >= c->max_inner) c->done = 1;
 }
 
+// the same from the four NORMS (multi-period model: per-period norms, maximum over the periods -- mpacopf_admm_update_residual_cpu.jl:1-55)
+__device__ __forceinline__ void ctrl_advance_norms(Ctrl* c, const double (&best)[4])
+{
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        c->sums[j] = best[j] * best[j];
+        c->res[j] = best[j];
+    }
+    const int inner = c->inner + 1;
+    c->inner = inner;
+    c->pending = 0;
+    const bool test = (c->check_every <= 1) || (inner % c->check_every == 0);
+    if ((test && c->res[0] <= c->eps_pri) || inner >= c->max_inner) c->done = 1;
+}
+
 // index of the v entries a component of a bus receives (generator: pg, qg; branch end: p, q, w, theta of that end)
 __device__ __forceinline__ void bus_end_index(const Dev& d, int code, int (&idx)[4])
 {
@@ -770,7 +877,9 @@ __device__ __forceinline__ void bus_end_index(const Dev& d, int code, int (&idx)
 // Parameter order: what a wavefront needs for its FIRST loads -- loop control, record / slot tables, the bus constants --
 // leads, inside the 16 SGPRs the firmware preloads at wavefront launch (Makefile KERNARG_PRELOAD); the Dev block by value
 // follows and is read from the kernarg segment while those loads are in flight.  hot_* repeat d.rec, d.EndCount, d.SlotCode, d.busc.
-template <bool REC>
+// MPG = true (multi-period model on the fused loop, with REC): branch ends come from the pushed records, GENERATORS gather -- the
+// real power of a generator is also tied to the ramp element of the next period, which another lane owns (bus_gen_has_ramp).
+template <bool REC, bool MPG = false>
 __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group_t(const Ctrl* ctrl, Ctrl* red, const double* __restrict__ hot_rec,
                                                             const int* __restrict__ hot_count, const int* __restrict__ hot_slot,
                                                             const double* __restrict__ hot_busc, int hot_B, Dev d, double baseMVA)
@@ -790,6 +899,34 @@ __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group_t(const Ctrl* ctrl, Ctr
         //  nullptr instead when it did not: there the flag is rewritten by k_halo_unpack on another stream while the next
         //  interior branch launch is already setting it again)
         if (red->done || (d.nranks <= 1 && !red->pending)) return;
+        if (d.T > 1) {
+            // multi-period model: per period the sums of the blocks that hold its lanes (branch blocks, then generator blocks, whose
+            // terms include the ramp elements), norm = sqrt, model norm = max over the periods (k_final_reduce_mp's definition)
+            double best[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int t = 0; t < d.T; t++) {
+                double s4[4] = {0.0, 0.0, 0.0, 0.0};
+                const int b0 = (t * d.l1) / BR_BLOCK, b1 = ((t + 1) * d.l1 - 1) / BR_BLOCK;
+                for (int bq = b0 + (int)threadIdx.x; bq <= b1; bq += BUS_BLOCK) {
+                    const int k = t - (bq * BR_BLOCK) / d.l1;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) s4[j] += d.partials_br[((size_t)bq * d.part_k + k) * 4 + j];
+                }
+                const int g0 = (t * d.g1) / BR_BLOCK, g1 = ((t + 1) * d.g1 - 1) / BR_BLOCK;
+                for (int gq = g0 + (int)threadIdx.x; gq <= g1; gq += BUS_BLOCK) {
+                    const int k = t - (gq * BR_BLOCK) / d.g1;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) s4[j] += d.partials_br[((size_t)(d.gen_part0 + gq) * d.part_k + k) * 4 + j];
+                }
+                block_reduce4(s4);
+                if (threadIdx.x == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) best[j] = fmax(best[j], sqrt(s4[j]));
+                }
+                __syncthreads();   // block_reduce4's scratch is reused by the next period
+            }
+            if (threadIdx.x == 0) ctrl_advance_norms(red, best);
+            return;
+        }
         double s4[4] = {0.0, 0.0, 0.0, 0.0};
         for (int bq = threadIdx.x; bq < d.npartials_br; bq += BUS_BLOCK) {
 #pragma unroll
@@ -848,7 +985,8 @@ __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group_t(const Ctrl* ctrl, Ctr
         if (lane < m) {
             code = (c0 == 0) ? code0 : d.EndCode[e0 + c0 + lane];
             kind = (code >> 28) & 3;
-            if (REC) {
+            const bool rec_lane = REC && !(MPG && kind == END_GEN);   // (compile-time REC unless MPG)
+            if (rec_lane) {
                 if (c0 > 0) {
                     const double* q = d.rec + 8 * (size_t)(BUS_W * d.B + e0 + c0 + lane);
 #pragma unroll
@@ -861,7 +999,7 @@ __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group_t(const Ctrl* ctrl, Ctr
             asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb2) : "v"(r[0]) : "memory");
 #endif
             double tp, tq, tw = -0.0, tt = -0.0;
-            if (REC) {   // record: (u+z, l, rho) of p / pg, the same of q / qg, the w term, the theta term
+            if (rec_lane) {   // record: (u+z, l, rho) of p / pg, the same of q / qg, the w term, the theta term
                 tp = r[0] + (r[1] / r[2]);
                 tq = r[3] + (r[4] / r[5]);
                 if (kind != END_GEN) {
@@ -951,7 +1089,7 @@ __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group_t(const Ctrl* ctrl, Ctr
             if (n > BUS_W) {  // registers only hold the last chunk: fetch this one again
                 code = (c0 == 0) ? code0 : d.EndCode[e0 + c0 + lane];
                 kind = (code >> 28) & 3;
-                if (REC) {
+                if (REC && !(MPG && kind == END_GEN)) {
                     const double* q = d.rec + 8 * (size_t)((c0 == 0) ? (I * BUS_W + lane) : (BUS_W * d.B + e0 + c0 + lane));
 #pragma unroll
                     for (int k = 0; k < 8; k++) r[k] = q[k];
@@ -959,11 +1097,12 @@ __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group_t(const Ctrl* ctrl, Ctr
                 } else
                     bus_load_end(d, code, r, idx);
             }
+            const bool rec_lane = REC && !(MPG && kind == END_GEN);
             // (u+z), l, rho of the component's p (pg) and q (qg) entries
-            const double uzp = REC ? r[0] : (r[0] + r[1]), lp = REC ? r[1] : r[2], rhop = REC ? r[2] : r[3];
-            const double uzq = REC ? r[3] : (r[4] + r[5]), lq = REC ? r[4] : r[6], rhoq = REC ? r[5] : r[7];
+            const double uzp = rec_lane ? r[0] : (r[0] + r[1]), lp = rec_lane ? r[1] : r[2], rhop = rec_lane ? r[2] : r[3];
+            const double uzq = rec_lane ? r[3] : (r[4] + r[5]), lq = rec_lane ? r[4] : r[6], rhoq = rec_lane ? r[5] : r[7];
             if (kind == END_GEN) {
-                if (!REC && idx[2] <= -2)
+                if (!rec_lane && idx[2] <= -2)
                     d.v[idx[0]] = ((r[2] + r[3] * (r[0] + r[1])) + (r[10] + r[11] * (r[8] + r[9])) - mu1) / (r[3] + r[11]);
                 else
                     d.v[idx[0]] = uzp + (lp - mu1) / rhop;

@@ -328,3 +328,49 @@ def test_lane_per_bus_kernel_carries_the_ramp_terms_too(pkg, syn):
     for name in ("u_curr", "v_curr", "z_curr"):
         assert np.array_equal(a.download(name), b.download(name)), name
     assert np.array_equal(a.download_ramp("u_curr"), b.download_ramp("u_curr"))
+
+
+@pytest.mark.parametrize("size,T", [("case118", 3), ("case1354pegase", 4)])
+def test_fused_two_launch_loop_of_the_multi_period_model_equals_the_four_launch_loop(pkg, syn, size, T):
+    """Round 4: the multi-period model runs the speculative two-launch loop (the z / l pass incl. the ramp block rides in the next
+    branch launch's prologue, k_branch_t<true, true>; per-period residual sums reduced by the bus launch's extra block; the ramp
+    subproblems' outputs rotate with the iterate) instead of four launches per iteration (EXAADMM_MP_NO_SPEC=1, A/B).  Every
+    lane does the same arithmetic on the same inputs in both loops: u, v, z, l, lz of all periods and every ramp vector BITWISE
+    equal after fixed-count runs of odd and even length and after convergence-tested loops; the norms (summed in a different
+    order) to 1e-12; blocks that hold lanes of several periods are covered by the small case."""
+    grid = syn.sized_like(size, seed=4)
+    rng = np.random.default_rng(11)
+    al = 1.0 + 0.02 * rng.standard_normal(T)
+    load = (np.stack([grid["Pd"] * a for a in al], 1), np.stack([grid["Qd"] * a for a in al], 1))
+    runs = []
+    for four in (True, False):
+        old = os.environ.get("EXAADMM_MP_NO_SPEC")
+        if four:
+            os.environ["EXAADMM_MP_NO_SPEC"] = "1"
+        try:
+            env = pkg.AdmmEnv("mp", 1e1, 1e3, verbose=0, grid=grid)
+            mod = pkg.ModelMpacopf(env, load, end_period=T, ramp_ratio=0.02)
+            assert mod.loop_kind() == (0 if four else 1)
+            out, it = [], 1
+            for K in (1, 2, 7, 24):
+                norms, _, _ = mod.run_fixed(K, first_major_iter=it, beta=1e3)
+                it += K
+                out.append([mod.download(n) for n in ("u_curr", "v_curr", "z_curr", "z_prev", "l_curr")] +
+                           [mod.download_ramp(n) for n in ("u_curr", "s_curr", "z_curr", "z_prev", "l_curr", "mu", "xi")] + [mod.membuf.copy(), norms.copy()])
+            for outer, limit in ((1, 21), (2, 150)):
+                inner, res = mod.run_inner(outer, limit, 1e3)
+                out.append([mod.download(n) for n in ("u_curr", "v_curr", "z_curr", "z_prev", "l_curr")] +
+                           [mod.download_ramp(n) for n in ("u_curr", "s_curr", "z_curr", "z_prev", "l_curr", "mu", "xi")] + [mod.membuf.copy(), np.array([float(inner)]), res.copy()])
+            runs.append(out)
+            mod.close()
+        finally:
+            if old is None:
+                os.environ.pop("EXAADMM_MP_NO_SPEC", None)
+            else:
+                os.environ["EXAADMM_MP_NO_SPEC"] = old
+    for a, b in zip(runs[0], runs[1]):
+        for k, (x, y) in enumerate(zip(a, b)):
+            if k < 13 or (x.size == 1):
+                assert np.array_equal(x, y), k
+            else:     # the four norms: per-period sums added in another order
+                assert np.allclose(x, y, rtol=1e-12, atol=0), (k, x, y)

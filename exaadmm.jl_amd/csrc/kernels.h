@@ -1462,6 +1462,10 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
     const int my_tile0 = (TILES == 1) ? (int)blockIdx.x : rt.tiles[2 * blockIdx.x];
     const int my_tile1 = (TILES == 1) ? -1 : rt.tiles[2 * blockIdx.x + 1];
     for (int i = 0; i < iters; i++) {
+#if defined(EXA_PROFILE_PHASES)
+        unsigned long long ts[8];   // diagnostic build: stamps of this iteration (scripts/resident_timeline.py)
+        ts[0] = __builtin_amdgcn_s_memtime();
+#endif
         if (i > 0 && !resident_go_on(rs, resident_passes(first_has_zl, i - 1))) return;   // (wave-uniform: the loop has stopped)
         const Dev& d = (i & 1) ? *dp1 : *dp0;
         for (int t = 0; t < TILES; t++) {
@@ -1497,9 +1501,15 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
             bd.ls2 = (d.ls2_in ? d.ls2_in : d.ls2)[b];
             const double mu_0 = (d.mu_in ? d.mu_in : d.mu)[b];
             const double rate_0 = d.rateA[b];
+#if defined(EXA_PROFILE_PHASES)
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts[1]) : "v"(rate_0) : "memory");   // loads landed
+#endif
             if (v_from_bus && lane_on) {
                 if (!resident_wait(rs.ready + bus4.x, i, rs.fail)) return;
                 if (!resident_wait(rs.ready + bus4.z, i, rs.fail)) return;
+#if defined(EXA_PROFILE_PHASES)
+                ts[2] = __builtin_amdgcn_s_memtime();   // both buses ready
+#endif
                 const double* pf = rs.busres[i & 1] + 4 * (size_t)bus4.x;
                 const double* pt = rs.busres[i & 1] + 4 * (size_t)bus4.z;
                 const double rf[4] = {ld_agent(pf), ld_agent(pf + 1), ld_agent(pf + 2), ld_agent(pf + 3)};
@@ -1542,6 +1552,9 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
                 }
                 if (lane == 0) resident_contribute(rs, i & 1, tile, zs);
             }
+#if defined(EXA_PROFILE_PHASES)
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts[3]) : : "memory");   // v, z / l pass, contribution done
+#endif
             if (lane_on) {
                 bd.mu = (major_iter == 1) ? 10.0 : mu_0;
                 bd.scale = scale;
@@ -1551,6 +1564,9 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
                 BranchStats st;
                 st.tl = nullptr;
                 branch_solve(bd, o, pw_lds, x, xl, xu, A, L, phi, st, park_lds + lane);
+#if defined(EXA_PROFILE_PHASES)
+                ts[4] = __builtin_amdgcn_s_memtime();   // (of the lanes that reach this point last: the wavefront's solve is over)
+#endif
                 d.u[base] = phi[0];
                 d.u[base + Lp] = phi[1];
                 d.u[base + 2 * Lp] = phi[2];
@@ -1589,10 +1605,21 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
 #endif
             }
             resident_order_stores();
+#if defined(EXA_PROFILE_PHASES)
+            ts[5] = __builtin_amdgcn_s_memtime();   // results and terms stored
+#endif
             if (lane_on) {
                 resident_arrive(d, rs, bus4.x, bus4.y, i + 1);
                 resident_arrive(d, rs, bus4.z, bus4.w, i + 1);
             }
+#if defined(EXA_PROFILE_PHASES)
+            ts[6] = __builtin_amdgcn_s_memtime();   // arrivals (and the bus updates this wavefront's lanes completed) done
+            if (TILES == 1 && d.st_tl && lane == 0) {   // the last two iterations of the launch survive
+                unsigned long long* q = d.st_tl + (size_t)blockIdx.x * 128 + 8 * (i & 1);
+                for (int k = 0; k < 7; k++) q[k] = ts[k];
+                q[7] = (unsigned long long)i;
+            }
+#endif
         }
     }
     for (int t = 0; t < TILES; t++) {   // v of the last index (what its bus launch would have written)

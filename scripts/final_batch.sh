@@ -1,8 +1,9 @@
 #!/bin/bash
 # GPU box: the measurements profiles/ is refreshed from.  Order matters: kernel traces and PMC passes first, then
-# scripts/refresh_profiles.py writes profiles/r03_pmc_summary.json (with the version string of THIS build), then the bench lines --
-# which read `traffic` / `valu_busy` from that summary and refuse it for any other build.  usage: bash scripts/final_batch.sh OUTDIR
+# scripts/refresh_profiles.py writes profiles/<round>_pmc_summary.json (with the version string of THIS build), then the bench lines --
+# which read `traffic` / `valu_busy` from that summary and refuse it for any other build.  usage: bash scripts/final_batch.sh OUTDIR [ROUND]
 O=${1:-gpurun_out/final}; mkdir -p $O
+RND=${2:-r04}
 T="timeout 500"
 R=$PWD; cd /tmp; export TMPDIR=/tmp
 for c in "" case1354pegase case_ACTIVSg70k synthetic1M; do
@@ -17,8 +18,8 @@ bash scripts/collect_pmc.sh case1354pegase $O/pmc_case1354pegase 200 > $O/pmc2.l
 bash scripts/collect_pmc.sh case_ACTIVSg70k $O/pmc_case_ACTIVSg70k 100 > $O/pmc3.log 2>&1
 bash scripts/collect_pmc.sh synthetic1M $O/pmc_synthetic1M 50 > $O/pmc4.log 2>&1
 find $O -name "*kernel_trace.csv" -delete
-python scripts/refresh_profiles.py $O r03 "${BUILD_NOTE:-round 3 final build}" > $O/refresh1.log 2>&1
-cp profiles/r03_pmc_summary.json $O/r03_pmc_summary.json
+python scripts/refresh_profiles.py $O $RND "${BUILD_NOTE:-round 4 final build}" > $O/refresh1.log 2>&1
+cp profiles/${RND}_pmc_summary.json $O/${RND}_pmc_summary.json
 $T python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.log 2>&1
 $T python bench.py > $O/bench_default.log 2>&1
 $T python bench.py --case case118 > $O/bench_case118.log 2>&1
@@ -29,6 +30,8 @@ $T python bench.py --case synthetic1M --steps 100 --warmup 20 --no-cpu-baseline 
 $T python bench.py --force-dist --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_dist1.log 2>&1
 $T python bench.py --force-dist --case case_ACTIVSg70k --steps 100 --warmup 20 --no-cpu-baseline > $O/bench_dist1_70k.log 2>&1
 $T python bench.py --periods 4 --steps 100 --warmup 20 > $O/bench_mp4.log 2>&1
+EXAADMM_RESIDENT_TILES=0 $T python bench.py --case case_ACTIVSg70k --steps 100 --warmup 20 --no-cpu-baseline > $O/bench_case_ACTIVSg70k_two_launch.log 2>&1
+EXAADMM_MP_NO_SPEC=1 $T python bench.py --periods 4 --steps 100 --warmup 20 --no-cpu-baseline > $O/bench_mp4_four_launch.log 2>&1
 EXAADMM_NO_RESIDENT=1 $T python bench.py --no-cpu-baseline > $O/bench_two_launch_loop.log 2>&1
 for f in $O/bench_*.log; do echo "$f: $(python -c "
 import json

@@ -1525,7 +1525,7 @@ static int resident_prepare(exaadmm_handle* h)
         h->rtiles.ng = ng;
         h->rtiles.wg = (ng + 1) / 2;
         h->rtiles.wb = h->resident_cap2 - h->rtiles.wg - 1;
-        if ((rc = dev_alloc(h, &t, 2 * (size_t)h->rtiles.wb))) return rc;
+        if ((rc = dev_alloc(h, &t, 2 * (size_t)h->rtiles.wb + (size_t)nb))) return rc;   // the table, then the tiles' keys
         h->rtiles.tiles = t;
     }
     HIPCHK(hipMemsetAsync(r.fail, 0, sizeof(int), h->stream));
@@ -1546,8 +1546,9 @@ static int enqueue_resident(exaadmm_handle* h, int n)
     if (mode == 2) {
         // which tiles share a wavefront in this launch: from the solver-trip counters of the last x-updates (both buffer sets)
         const ResidentTiles& t = h->rtiles;
-        hipLaunchKernelGGL(k_resident_assign, dim3(1), dim3(1024), 2 * (size_t)t.nb * sizeof(int), h->stream, (const int*)h->sets[0].st[2], (const int*)h->sets[1].st[2],
-                           h->L, t.nb, t.wb, const_cast<int*>(t.tiles));
+        int* const keys = const_cast<int*>(t.tiles) + 2 * (size_t)t.wb;   // (behind the table)
+        hipLaunchKernelGGL(k_tile_keys, dim3((t.nb + 3) / 4), dim3(256), 0, h->stream, (const int*)h->sets[0].st[2], (const int*)h->sets[1].st[2], h->L, t.nb, keys);
+        hipLaunchKernelGGL(k_tile_assign, dim3(1), dim3(1024), 2 * (size_t)t.nb * sizeof(int), h->stream, (const int*)keys, t.nb, t.wb, const_cast<int*>(t.tiles));
         grid = t.wb + t.wg + 1;
     }
     if (h->resident_coop) {
@@ -1874,7 +1875,10 @@ static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
     if (resident && (rc = resident_prepare(h))) return rc;
     bool downgrade = false;
     while (enq < max_inner) {
-        const int nb = std::min(resident ? 8 * batch : batch, max_inner - enq);   // (resident: one launch and one host round trip per 64 iterations)
+        // resident: ONE launch (and one host visit) per 1 024 iterations -- normally the whole inner loop; the launch ends inside the
+        // kernel at the iteration the stop test names, so its length only bounds the host visits (a launch has a fixed cost of
+        // 0.1 ms at 13 659 buses and 0.7 ms at 88 207 branches: profiles/r04_resident_launch_fixed_cost.txt)
+        const int nb = std::min(resident ? 1024 : batch, max_inner - enq);
         *h->h_base = enq;   // the stream is idle here (synchronised at the end of every batch)
         HIPCHK(hipMemcpyAsync(&h->d_ctrl->base, h->h_base, sizeof(int), hipMemcpyHostToDevice, h->stream));
         if (resident) {

@@ -1321,7 +1321,7 @@ __device__ __forceinline__ bool resident_go_on(const ResidentSync& rs, int passe
 
 // TILES = 2: grids with more tiles of 64 branches than the chip has SIMDs (up to twice as many: ~120 000 branches).  A resident
 // wavefront then owns up to two tiles and runs, per iteration, the body once per tile (the per-lane state lives in memory between
-// iterations anyway).  Which tiles share a wavefront is decided per launch by k_resident_assign from the solver-trip counters
+// iterations anyway).  Which tiles share a wavefront is decided per launch by k_tile_keys / k_tile_assign from the solver-trip counters
 // of the last iterations: the heaviest tiles -- the launch's slowest branch sets the pace of every iteration, and the set of
 // heavy branches is persistent -- get a wavefront of their own, the others are paired heavy with light, heavier first.
 // tiles[2 w], tiles[2 w + 1] = the tiles of branch wavefront w (-1: none); generator wavefront v handles generator tiles v and
@@ -1656,22 +1656,27 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
     }
 }
 
-// Which tiles share a resident wavefront (k_resident_t<2>): one block.  key[tile] = largest solver-trip count of the tile's
-// lanes in the last accepted x-updates (both buffer sets), tiles ranked by key (ties by index), the S = 2 wb - nb heaviest
-// get a wavefront each, the other 2 (nb - wb) are paired heaviest with lightest, the heavier of a pair first.
-__global__ void __launch_bounds__(1024) k_resident_assign(const int* __restrict__ ticks0, const int* __restrict__ ticks1, int L, int nb, int wb, int* __restrict__ tiles)
+// Which tiles share a resident wavefront (k_resident_t<2>), in two small launches in front of every resident launch:
+// k_tile_keys -- one wavefront per tile: key[tile] = largest solver-trip count of the tile's lanes in the last accepted x-updates
+// (both buffer sets; coalesced reads, wave maximum); k_tile_assign -- one block: tiles ranked by key (ties by index), the
+// S = 2 wb - nb heaviest get a wavefront each, the other 2 (nb - wb) are paired heaviest with lightest, the heavier of a pair first.
+__global__ void __launch_bounds__(256) k_tile_keys(const int* __restrict__ ticks0, const int* __restrict__ ticks1, int L, int nb, int* __restrict__ key)
+{
+    const int t = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (t >= nb) return;
+    const int b = t * BR_BLOCK + lane;
+    int k = (b < L) ? max(ticks0[b], ticks1[b]) : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) k = max(k, __shfl_down(k, off, 64));
+    if (lane == 0) key[t] = k;
+}
+
+__global__ void __launch_bounds__(1024) k_tile_assign(const int* __restrict__ key_g, int nb, int wb, int* __restrict__ tiles)
 {
     extern __shared__ int sh[];   // key[nb], order[nb]
     int* key = sh;
     int* order = sh + nb;
-    for (int t = threadIdx.x; t < nb; t += blockDim.x) {
-        int k = 0;
-        for (int j = 0; j < BR_BLOCK; j++) {
-            const int b = t * BR_BLOCK + j;
-            if (b < L) k = max(k, max(ticks0[b], ticks1[b]));
-        }
-        key[t] = k;
-    }
+    for (int t = threadIdx.x; t < nb; t += blockDim.x) key[t] = key_g[t];
     __syncthreads();
     for (int t = threadIdx.x; t < nb; t += blockDim.x) {
         const int k = key[t];

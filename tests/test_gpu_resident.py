@@ -153,7 +153,10 @@ def test_a_failed_resident_batch_is_restored_and_repeated_with_the_two_launch_lo
             mod = pkg.ModelAcopf(env)
             assert mod.loop_kind() == (2 if inject else 1) and mod.loop_downgrades() == 0
             out = []
-            inner, res = mod.run_inner(1, 150, 1e3)          # three resident batches of 64 / two-launch batches of 8
+            # (a resident launch covers up to 1 024 iterations: the tolerance of a (hypothetical) millionth outer iteration keeps the loop going into a
+            #  second launch, which is where fail_at = 2 strikes)
+            inner, res = mod.run_inner(1000000 if fail_at == 2 else 1, 1100 if fail_at == 2 else 150, 1e3)
+            assert fail_at == 1 or inner > 1024
             out.append(_state(mod) + [res.copy(), np.array([inner])])
             norms, _, _ = mod.run_fixed(21, first_major_iter=inner + 1, beta=1e3)
             out.append(_state(mod) + [norms.copy()])

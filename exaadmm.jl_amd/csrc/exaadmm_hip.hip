@@ -1877,7 +1877,7 @@ static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
     while (enq < max_inner) {
         // resident: ONE launch (and one host visit) per 1 024 iterations -- normally the whole inner loop; the launch ends inside the
         // kernel at the iteration the stop test names, so its length only bounds the host visits (a launch has a fixed cost of
-        // 0.1 ms at 13 659 buses and 0.7 ms at 88 207 branches: profiles/r04_resident_launch_fixed_cost.txt)
+        // 0.15 ms at 13 659 buses, 0.23 ms at 88 207 branches: profiles/r04_resident_launch_fixed_cost.txt)
         const int nb = std::min(resident ? 1024 : batch, max_inner - enq);
         *h->h_base = enq;   // the stream is idle here (synchronised at the end of every batch)
         HIPCHK(hipMemcpyAsync(&h->d_ctrl->base, h->h_base, sizeof(int), hipMemcpyHostToDevice, h->stream));

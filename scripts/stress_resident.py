@@ -40,7 +40,9 @@ def run(g, rho, two_launch, plan):
 t0 = time.time()
 bad = 0
 cases = [(2, 64, 40, 0, "pegase"), (6, 200, 120, 1, "pegase"), (40, 700, 400, 2, "market"), (260, 1991, 1354, 3, "pegase"), (500, 5000, 3000, 4, "pegase"),
-         (1500, 12000, 8000, 5, "market"), (4092, 20467, 13659, 6, "pegase"), (6000, 40000, 26000, 7, "pegase"), (7000, 50000, 33000, 8, "market")]
+         (1500, 12000, 8000, 5, "market"), (4092, 20467, 13659, 6, "pegase"), (6000, 40000, 26000, 7, "pegase"), (7000, 50000, 33000, 8, "market"),
+         # round 4: more tiles of 64 branches than SIMDs -- up to two tiles per resident wavefront (k_resident_t<2>)
+         (8000, 70000, 52000, 9, "pegase"), (10390, 88207, 70000, 10, "market"), (12000, 110000, 80000, 11, "pegase")]
 for ngen, nline, nbus, seed, cost in cases:
     g = syn.synthetic_grid(ngen, nline, nbus, seed=seed, cost=cost)
     rho = (5e1, 5e3) if cost == "pegase" else (3e2, 3e3)
@@ -64,5 +66,13 @@ for r in range(reps):
     _, sig = run(g, (1e1, 1e3), False, (1, 2, 7, 30))
     nbad2 += (sig != ref)
 print("1 354 buses: %d repetitions of the resident run, %d differ from the two-launch result" % (reps, nbad2), flush=True)
-print("TOTAL mismatches: %d (%.0f s)" % (bad + nbad + nbad2, time.time() - t0))
-sys.exit(1 if (bad + nbad + nbad2) else 0)
+g = syn.sized_like("case_ACTIVSg70k", seed=0)
+k0, ref = run(g, (3e4, 3e5), True, (1, 2, 7, 30))
+nbad3 = 0
+reps3 = max(1, reps // 5)
+for r in range(reps3):
+    _, sig = run(g, (3e4, 3e5), False, (1, 2, 7, 30))
+    nbad3 += (sig != ref)
+print("88 207 branches (two tiles per wavefront): %d repetitions of the resident run, %d differ from the two-launch result" % (reps3, nbad3), flush=True)
+print("TOTAL mismatches: %d (%.0f s)" % (bad + nbad + nbad2 + nbad3, time.time() - t0))
+sys.exit(1 if (bad + nbad + nbad2 + nbad3) else 0)

@@ -330,6 +330,8 @@ def test_lane_per_bus_kernel_carries_the_ramp_terms_too(pkg, syn):
     assert np.array_equal(a.download_ramp("u_curr"), b.download_ramp("u_curr"))
 
 
+@pytest.mark.skipif(bool(os.environ.get("EXAADMM_MP_NO_SPEC") or os.environ.get("EXAADMM_NO_SPEC") or os.environ.get("EXAADMM_BUS_KERNEL") == "lane"),
+                    reason="a switch of this run keeps the multi-period model on the four-launch loop")
 @pytest.mark.parametrize("size,T", [("case118", 3), ("case1354pegase", 4)])
 def test_fused_two_launch_loop_of_the_multi_period_model_equals_the_four_launch_loop(pkg, syn, size, T):
     """Round 4: the multi-period model runs the speculative two-launch loop (the z / l pass incl. the ramp block rides in the next

@@ -17,9 +17,12 @@
 //   1  control: the same WITHOUT the s_waitcnt between data and flag               (flag may overtake the data)
 //   2  control: PLAIN data stores / loads + workgroup-scope fence (compiles to nothing on gfx950) (stale per-XCD L2 lines)
 //   3  reference: plain data, agent-scope release fence / acquire fence              (the language memory model's way; correct, slow)
+//   5  candidate: data in UNCACHED device memory (hipExtMallocWithFlags(hipDeviceMallocUncached): MTYPE UC, no per-XCD L2 line to
+//      go stale), PLAIN 16-byte stores / loads (global_store / load_dwordx4 -- an agent-scope atomic cannot be wider than 8 bytes),
+//      s_waitcnt vmcnt(0), relaxed agent-scope flag
 //   4  SHIPPED, arrive mode
 // Every wait is capped (no hang on a protocol error).  Output: hand-overs, mismatching words, capped waits, ns per hand-over.
-//   hipcc --offload-arch=gfx950 -O2 -o mp_litmus mp_litmus.hip && for v in 0 4 1 2 3; do timeout 600 ./mp_litmus $v; done
+//   hipcc --offload-arch=gfx950 -O2 -o mp_litmus mp_litmus.hip && for v in 0 4 1 2 3 5; do timeout 600 ./mp_litmus $v; done
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -45,6 +48,8 @@ __device__ __forceinline__ bool wait_ge(const int* flag, int want, unsigned long
     return true;
 }
 
+typedef double double2v __attribute__((ext_vector_type(2)));
+
 template <int V>
 __global__ void __launch_bounds__(64) k_pairs(int* flags, double* data, int iters, unsigned long long* bad, unsigned long long* capped,
                                               unsigned* xcc_of_block)
@@ -62,6 +67,12 @@ __global__ void __launch_bounds__(64) k_pairs(int* flags, double* data, int iter
     unsigned long long nbad = 0;
     for (int it = 1; it <= iters; ++it) {
         if (writer) {
+            if (V == 5) {
+                double2v* p = reinterpret_cast<double2v*>(d + 4 * lane);
+                double2v a = {f(it, lane, 0), f(it, lane, 1)}, b = {f(it, lane, 2), f(it, lane, 3)};
+                __builtin_nontemporal_store(a, p);          // (plain 16-byte stores; the memory itself is uncached)
+                __builtin_nontemporal_store(b, p + 1);
+            } else {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 if (V == 2 || V == 3)
@@ -69,7 +80,8 @@ __global__ void __launch_bounds__(64) k_pairs(int* flags, double* data, int iter
                 else
                     st_agent(d + 4 * lane + q, f(it, lane, q));
             }
-            if (V == 0) order_stores();
+            }
+            if (V == 0 || V == 5) order_stores();
             if (V == 2) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (V == 3) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             // ONE lane announces the wavefront's stores (like lane 0 of resident_contribute); all 64 lanes' stores are covered by the
@@ -80,10 +92,16 @@ __global__ void __launch_bounds__(64) k_pairs(int* flags, double* data, int iter
             if (!wait_ge(flag, it, capped)) return;
             if (V == 3) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             if (V == 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (V == 5) {
+                const double2v* p = reinterpret_cast<const double2v*>(d + 4 * lane);
+                const double2v a = __builtin_nontemporal_load(p), b = __builtin_nontemporal_load(p + 1);
+                nbad += (a.x != f(it, lane, 0)) + (a.y != f(it, lane, 1)) + (b.x != f(it, lane, 2)) + (b.y != f(it, lane, 3));
+            } else {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const double v = (V == 2 || V == 3) ? ((volatile double*)d)[4 * lane + q] : ld_agent(d + 4 * lane + q);
                 nbad += (v != f(it, lane, q));
+            }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the reads are done before the writer may overwrite the words
             if (lane == 0) __hip_atomic_store(ack, it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -142,7 +160,10 @@ int main(int argc, char** argv)
     unsigned long long *bad, *capped;
     unsigned* xcc;
     CHECK(hipMalloc(&flags, sizeof(int) * 32 * 2 * (size_t)pairs));
-    CHECK(hipMalloc(&data, sizeof(double) * 256 * (size_t)pairs));
+    if (variant == 5)
+        CHECK(hipExtMallocWithFlags((void**)&data, sizeof(double) * 256 * (size_t)pairs, hipDeviceMallocUncached));
+    else
+        CHECK(hipMalloc(&data, sizeof(double) * 256 * (size_t)pairs));
     CHECK(hipMalloc(&result, sizeof(double) * 4 * (size_t)pairs));
     CHECK(hipMalloc(&bad, 8));
     CHECK(hipMalloc(&capped, 8));
@@ -162,6 +183,7 @@ int main(int argc, char** argv)
         case 0: name = "SHIPPED (sc1 data, s_waitcnt vmcnt(0), relaxed flag / relaxed poll, sc1 loads)"; hipLaunchKernelGGL(k_pairs<0>, dim3(2 * pairs), dim3(64), 0, 0, flags, data, iters, bad, capped, xcc); break;
         case 1: name = "control: sc1 data, NO s_waitcnt between data and flag"; hipLaunchKernelGGL(k_pairs<1>, dim3(2 * pairs), dim3(64), 0, 0, flags, data, iters, bad, capped, xcc); break;
         case 2: name = "control: plain data + workgroup-scope fence"; hipLaunchKernelGGL(k_pairs<2>, dim3(2 * pairs), dim3(64), 0, 0, flags, data, iters, bad, capped, xcc); break;
+        case 5: name = "candidate: UNCACHED memory (hipDeviceMallocUncached), plain 16-byte stores / loads, s_waitcnt, relaxed flag"; hipLaunchKernelGGL(k_pairs<5>, dim3(2 * pairs), dim3(64), 0, 0, flags, data, iters, bad, capped, xcc); break;
         case 3: name = "reference: plain data + agent-scope release / acquire fences"; hipLaunchKernelGGL(k_pairs<3>, dim3(2 * pairs), dim3(64), 0, 0, flags, data, iters, bad, capped, xcc); break;
         default: name = "SHIPPED, arrive mode (4 arrivals per round, the last one reads all terms: resident_arrive)"; hipLaunchKernelGGL(k_arrive, dim3(4 * (pairs / 2)), dim3(64), 0, 0, flags, data, result, iters, bad, capped); break;
     }
@@ -174,12 +196,12 @@ int main(int argc, char** argv)
     CHECK(hipMemcpy(&hb, bad, 8, hipMemcpyDeviceToHost));
     CHECK(hipMemcpy(&hc, capped, 8, hipMemcpyDeviceToHost));
     unsigned hx[8] = {0};
-    if (variant < 4) CHECK(hipMemcpy(hx, xcc, sizeof(hx), hipMemcpyDeviceToHost));
-    const double n = (variant < 4) ? (double)pairs * iters : (double)(pairs / 2) * iters;
+    if (variant != 4) CHECK(hipMemcpy(hx, xcc, sizeof(hx), hipMemcpyDeviceToHost));
+    const double n = (variant != 4) ? (double)pairs * iters : (double)(pairs / 2) * iters;
     printf("variant %d: %s\n", variant, name);
-    printf("  %s x %d rounds = %.3g hand-overs, %.1f ms, %.0f ns per round of one %s\n", variant < 4 ? "pairs" : "groups", iters, n, ms,
-           1e6 * ms / iters, variant < 4 ? "pair (there and back)" : "group");
-    if (variant < 4) printf("  XCC of blocks 0..7: %u %u %u %u %u %u %u %u (writer / reader of a pair sit on different XCDs)\n", hx[0], hx[1], hx[2], hx[3], hx[4], hx[5], hx[6], hx[7]);
+    printf("  %s x %d rounds = %.3g hand-overs, %.1f ms, %.0f ns per round of one %s\n", variant != 4 ? "pairs" : "groups", iters, n, ms,
+           1e6 * ms / iters, variant != 4 ? "pair (there and back)" : "group");
+    if (variant != 4) printf("  XCC of blocks 0..7: %u %u %u %u %u %u %u %u (writer / reader of a pair sit on different XCDs)\n", hx[0], hx[1], hx[2], hx[3], hx[4], hx[5], hx[6], hx[7]);
     printf("  mismatching words: %llu    capped waits: %llu\n", hb, hc);
     return 0;
 }

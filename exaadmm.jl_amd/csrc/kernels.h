@@ -263,6 +263,15 @@ __device__ __forceinline__ void gen_ramp_lane_zl(const Dev& d, const BranchOptio
     if (!ramp) {
         double up, uq;
         generator_update(d, baseMVA, i, vin, up, uq);
+        if (d.rec != nullptr) {   // what the bus update needs from this generator (the fields of k_branch_t's single-period generator lanes)
+            double* q = d.rec + 8 * (size_t)d.rec_gen[i];
+            q[0] = up + d.z[pg];
+            q[1] = d.l[pg];
+            q[2] = d.rho[pg];
+            q[3] = uq + d.z[qg];
+            q[4] = d.l[qg];
+            q[5] = d.rho[qg];
+        }
         return;
     }
     d.u[qg] = fmax(d.qgmin[i], fmin(d.qgmax[i], (-(d.l[qg] + d.rho[qg] * (-vin[qg] + d.z[qg]))) / d.rho[qg]));
@@ -294,6 +303,20 @@ __device__ __forceinline__ void gen_ramp_lane_zl(const Dev& d, const BranchOptio
     d.r_s[i] = x[2];
     d.r_mu[i] = gd.mu;
     d.r_xi[i] = gd.xi;
+    if (d.rec != nullptr) {
+        double* q = d.rec + 8 * (size_t)d.rec_gen[i];
+        q[0] = x[0] + d.z[pg];
+        q[1] = d.l[pg];
+        q[2] = d.rho[pg];
+        q[3] = d.u[qg] + d.z[qg];
+        q[4] = d.l[qg];
+        q[5] = d.rho[qg];
+        // ... and what the bus of the SAME generator one period earlier needs from this lane's ramp element (its real power is tied
+        // to it, bus_kernel_ramp, mpacopf_bus_kernel_cpu.jl:53-62): into the two free fields of that generator's record
+        double* qp = d.rec + 8 * (size_t)d.rec_gen[i - d.g1];
+        qp[6] = d.r_l[i] + d.r_rho[i] * (x[1] + d.r_z[i]);
+        qp[7] = d.r_rho[i];
+    }
 }
 
 __global__ void __launch_bounds__(64) k_gen_ramp(Dev d, BranchOptions o, double baseMVA, int major_iter, const Ctrl* ctrl)
@@ -877,8 +900,9 @@ __device__ __forceinline__ void bus_end_index(const Dev& d, int code, int (&idx)
 // Parameter order: what a wavefront needs for its FIRST loads -- loop control, record / slot tables, the bus constants --
 // leads, inside the 16 SGPRs the firmware preloads at wavefront launch (Makefile KERNARG_PRELOAD); the Dev block by value
 // follows and is read from the kernarg segment while those loads are in flight.  hot_* repeat d.rec, d.EndCount, d.SlotCode, d.busc.
-// MPG = true (multi-period model on the fused loop, with REC): branch ends come from the pushed records, GENERATORS gather -- the
-// real power of a generator is also tied to the ramp element of the next period, which another lane owns (bus_gen_has_ramp).
+// MPG = true (multi-period model on the fused loop, with REC): the real power of a generator of period t < T - 1 is also tied to the
+// ramp element of the next period (bus_gen_has_ramp); that element's lane has put its consensus term and its rho into fields 6
+// and 7 of the generator's record (gen_ramp_lane_zl).
 template <bool REC, bool MPG = false>
 __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group_t(const Ctrl* ctrl, Ctrl* red, const double* __restrict__ hot_rec,
                                                             const int* __restrict__ hot_count, const int* __restrict__ hot_slot,
@@ -985,7 +1009,8 @@ __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group_t(const Ctrl* ctrl, Ctr
         if (lane < m) {
             code = (c0 == 0) ? code0 : d.EndCode[e0 + c0 + lane];
             kind = (code >> 28) & 3;
-            const bool rec_lane = REC && !(MPG && kind == END_GEN);   // (compile-time REC unless MPG)
+            const bool rec_lane = REC;
+            const bool ramp_gen = MPG && kind == END_GEN && bus_gen_has_ramp(d, code & END_INDEX);
             if (rec_lane) {
                 if (c0 > 0) {
                     const double* q = d.rec + 8 * (size_t)(BUS_W * d.B + e0 + c0 + lane);
@@ -1000,7 +1025,7 @@ __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group_t(const Ctrl* ctrl, Ctr
 #endif
             double tp, tq, tw = -0.0, tt = -0.0;
             if (rec_lane) {   // record: (u+z, l, rho) of p / pg, the same of q / qg, the w term, the theta term
-                tp = r[0] + (r[1] / r[2]);
+                tp = ramp_gen ? ((r[1] + r[2] * r[0]) + r[6]) / (r[2] + r[7]) : r[0] + (r[1] / r[2]);
                 tq = r[3] + (r[4] / r[5]);
                 if (kind != END_GEN) {
                     tw = r[6];
@@ -1089,7 +1114,7 @@ __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group_t(const Ctrl* ctrl, Ctr
             if (n > BUS_W) {  // registers only hold the last chunk: fetch this one again
                 code = (c0 == 0) ? code0 : d.EndCode[e0 + c0 + lane];
                 kind = (code >> 28) & 3;
-                if (REC && !(MPG && kind == END_GEN)) {
+                if (REC) {
                     const double* q = d.rec + 8 * (size_t)((c0 == 0) ? (I * BUS_W + lane) : (BUS_W * d.B + e0 + c0 + lane));
 #pragma unroll
                     for (int k = 0; k < 8; k++) r[k] = q[k];
@@ -1097,13 +1122,15 @@ __global__ void __launch_bounds__(BUS_BLOCK) k_bus_group_t(const Ctrl* ctrl, Ctr
                 } else
                     bus_load_end(d, code, r, idx);
             }
-            const bool rec_lane = REC && !(MPG && kind == END_GEN);
+            const bool rec_lane = REC;
             // (u+z), l, rho of the component's p (pg) and q (qg) entries
             const double uzp = rec_lane ? r[0] : (r[0] + r[1]), lp = rec_lane ? r[1] : r[2], rhop = rec_lane ? r[2] : r[3];
             const double uzq = rec_lane ? r[3] : (r[4] + r[5]), lq = rec_lane ? r[4] : r[6], rhoq = rec_lane ? r[5] : r[7];
             if (kind == END_GEN) {
                 if (!rec_lane && idx[2] <= -2)
                     d.v[idx[0]] = ((r[2] + r[3] * (r[0] + r[1])) + (r[10] + r[11] * (r[8] + r[9])) - mu1) / (r[3] + r[11]);
+                else if (MPG && bus_gen_has_ramp(d, code & END_INDEX))
+                    d.v[idx[0]] = ((r[1] + r[2] * r[0]) + r[6] - mu1) / (r[2] + r[7]);
                 else
                     d.v[idx[0]] = uzp + (lp - mu1) / rhop;
                 d.v[idx[1]] = uzq + (lq - mu2) / rhoq;

@@ -234,7 +234,7 @@ def main():
     # converges, 13.1 k it/s at iteration 320 and 16.3 k at 13 000, so consecutive stretches would not measure one thing)
     # -- until the GPU has been busy for about a second, and the MEDIAN region is reported: K = 20 steps last 1.6 ms, too
     # short for the driver's smi sampling to see and at the mercy of one scheduling hiccup.
-    can_snapshot = (T == 1)
+    can_snapshot = True   # (multi-period handles snapshot their ramp blocks as well)
     if can_snapshot:
         mod.state_save()
 

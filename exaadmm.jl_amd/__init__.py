@@ -783,6 +783,12 @@ class ModelMpacopf:
         a = np.ascontiguousarray(np.asarray(value, dtype=np.float64).T)
         _check(library().exaadmm_upload_membuf(self._h, _dp(a), 31, n), "upload membuf")
 
+    def state_save(self):
+        _check(library().exaadmm_state_save(self._h), "exaadmm_state_save")
+
+    def state_restore(self):
+        _check(library().exaadmm_state_restore(self._h), "exaadmm_state_restore")
+
     def loop_kind(self):
         """0 = four launches per iteration, 1 = two (the z / l pass of an iteration rides in the next branch launch)"""
         k = C.c_int()

@@ -2256,9 +2256,9 @@ extern "C" int exaadmm_run_fixed(exaadmm_handle* h, int iters, int first_major_i
 extern "C" int exaadmm_state_save(exaadmm_handle* h)
 {
     REQUIRE(h, "null handle");
-    REQUIRE(h->T == 1, "not available on a multi-period handle");
     HIPCHK(hipSetDevice(h->device));
     int rc;
+    const size_t nramp = (h->T > 1) ? (size_t)h->T * h->g1 : 0;
     if (h->snap.empty()) {
         for (int q = 0; q < 6; q++) {
             double* p = nullptr;
@@ -2270,10 +2270,16 @@ extern "C" int exaadmm_state_save(exaadmm_handle* h)
             if ((rc = dev_alloc(h, &p, (size_t)h->Lp))) return rc;
             h->snap.push_back(p);
         }
+        for (int q = 0; q < 8 && nramp > 0; q++) {   // multi-period model: the ramp blocks (phat, s, z, z_prev, l, lz, multiplier, penalty)
+            double* p = nullptr;
+            if ((rc = dev_alloc(h, &p, nramp))) return rc;
+            h->snap.push_back(p);
+        }
     }
-    double* src[9] = {h->d.u, h->d.v, h->d.z, h->d.zp, h->d.l, h->d.lz, h->d.ls1, h->d.ls2, h->d.mu};
-    for (int q = 0; q < 9; q++)
-        HIPCHK(hipMemcpyAsync(h->snap[q], src[q], (size_t)(q < 6 ? h->N : h->Lp) * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    double* src[17] = {h->d.u, h->d.v, h->d.z, h->d.zp, h->d.l, h->d.lz, h->d.ls1, h->d.ls2, h->d.mu,
+                       h->d.r_u, h->d.r_s, h->d.r_z, h->d.r_zp, h->d.r_l, h->d.r_lz, h->d.r_mu, h->d.r_xi};
+    for (size_t q = 0; q < h->snap.size(); q++)
+        HIPCHK(hipMemcpyAsync(h->snap[q], src[q], (q < 6 ? (size_t)h->N : (q < 9 ? (size_t)h->Lp : nramp)) * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     return sync_check(h, true);
 }
 
@@ -2281,9 +2287,11 @@ extern "C" int exaadmm_state_restore(exaadmm_handle* h)
 {
     REQUIRE(h && !h->snap.empty(), "exaadmm_state_save first");
     HIPCHK(hipSetDevice(h->device));
-    double* dst[9] = {h->d.u, h->d.v, h->d.z, h->d.zp, h->d.l, h->d.lz, h->d.ls1, h->d.ls2, h->d.mu};
-    for (int q = 0; q < 9; q++)
-        HIPCHK(hipMemcpyAsync(dst[q], h->snap[q], (size_t)(q < 6 ? h->N : h->Lp) * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    const size_t nramp = (h->T > 1) ? (size_t)h->T * h->g1 : 0;
+    double* dst[17] = {h->d.u, h->d.v, h->d.z, h->d.zp, h->d.l, h->d.lz, h->d.ls1, h->d.ls2, h->d.mu,
+                       h->d.r_u, h->d.r_s, h->d.r_z, h->d.r_zp, h->d.r_l, h->d.r_lz, h->d.r_mu, h->d.r_xi};
+    for (size_t q = 0; q < h->snap.size(); q++)
+        HIPCHK(hipMemcpyAsync(dst[q], h->snap[q], (q < 6 ? (size_t)h->N : (q < 9 ? (size_t)h->Lp : nramp)) * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     h->residual_vectors_valid = false;
     return sync_check(h, true);
 }

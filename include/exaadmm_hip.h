@@ -177,8 +177,8 @@ int exaadmm_solve_two_level(exaadmm_handle *h, exaadmm_info *out);
 int exaadmm_run_fixed(exaadmm_handle *h, int iters, int first_major_iter, double beta, double out[4],
                       double *ms_total, double *ms_branch);
 
-/* device-side snapshot / restore of the iterate (u, v, z, z_prev, l, lz, line-limit multipliers and penalty):
- * benchmark drivers time repeated stretches of iterations from one defined ADMM state */
+/* device-side snapshot / restore of the iterate (u, v, z, z_prev, l, lz, line-limit multipliers and penalty; on a multi-period
+ * handle the ramp blocks as well): benchmark drivers time repeated stretches of iterations from one defined ADMM state */
 int exaadmm_state_save(exaadmm_handle *h);
 int exaadmm_state_restore(exaadmm_handle *h);
 

@@ -376,3 +376,28 @@ def test_fused_two_launch_loop_of_the_multi_period_model_equals_the_four_launch_
                 assert np.array_equal(x, y), k
             else:     # the four norms: per-period sums added in another order
                 assert np.allclose(x, y, rtol=1e-12, atol=0), (k, x, y)
+
+
+def test_state_snapshot_of_a_multi_period_handle_restores_every_ramp_block(pkg, syn):
+    """exaadmm_state_save / _restore on a multi-period handle (bench.py times repeated regions from ONE state): after a restore the
+    same iterations give the same bits, period vectors and ramp blocks alike."""
+    grid = syn.sized_like("case118", seed=6)
+    T = 3
+    load = (np.stack([grid["Pd"] * a for a in (1.0, 1.01, 0.99)], 1), np.stack([grid["Qd"] * a for a in (1.0, 1.01, 0.99)], 1))
+    env = pkg.AdmmEnv("mp", 1e1, 1e3, verbose=0, grid=grid)
+    mod = pkg.ModelMpacopf(env, load, end_period=T, ramp_ratio=0.02)
+    mod.run_fixed(15, first_major_iter=1, beta=1e3)
+    mod.state_save()
+
+    def snap():
+        return [mod.download(n) for n in ("u_curr", "v_curr", "z_curr", "z_prev", "l_curr")] + [mod.download_ramp(n) for n in ("u_curr", "s_curr", "z_curr", "z_prev", "l_curr", "mu", "xi")] + [mod.membuf.copy()]
+
+    mod.run_fixed(9, first_major_iter=16, beta=1e3)
+    a = snap()
+    mod.run_fixed(20, first_major_iter=25, beta=1e3)
+    mod.state_restore()
+    mod.run_fixed(9, first_major_iter=16, beta=1e3)
+    b = snap()
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    mod.close()

@@ -56,7 +56,7 @@ struct exaadmm_dist {
     hipStream_t xstream = nullptr;
     std::vector<hipEvent_t> ev;        // fork / join and per-iteration hand-over events (also inside a captured batch)
     hipEvent_t xev[2] = {nullptr, nullptr};   // around one sampled exchange (group + unpack) per directly enqueued batch
-    bool xev_armed = false;
+    bool xev_armed = false, xev_recorded = false;   // armed: the next directly enqueued batch brackets one exchange; recorded: read them after a synchronisation
     double exchange_us_sum = 0.0;
     int64_t exchange_us_n = 0;
     // a batch of iterations INCLUDING its exchanges as one hipGraph: offered when the bound RCCL captured, instantiated and
@@ -166,8 +166,9 @@ static void dist_sample_exchange(exaadmm_handle* h, bool arm)
         d->xev_armed = true;
         return;
     }
-    if (!d->xev_armed) return;
     d->xev_armed = false;
+    if (!d->xev_recorded) return;
+    d->xev_recorded = false;
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, d->xev[0], d->xev[1]) == hipSuccess && ms > 0.f) {
         d->exchange_us_sum += 1e3 * (double)ms;
@@ -465,8 +466,13 @@ static int enqueue_dist_iterations(exaadmm_handle* h, Ctrl* c, int j0, int n, bo
         if (overlap) HIPCHK(hipEventRecord(e_bus, M));
         if (j + 1 < j0 + n) launch_int(j + 1);
         if (overlap) HIPCHK(hipStreamWaitEvent(X, e_bus, 0));
-        const bool sample = d->xev_armed && j == j0 + std::min(1, n - 1);
-        if (sample) (void)hipEventRecord(d->xev[0], X);
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        const bool sample = d->xev_armed && j == j0 + std::min(1, n - 1) && hipStreamIsCapturing(X, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;
+        if (sample) {   // (once per arming, never inside a capture)
+            d->xev_armed = false;
+            d->xev_recorded = true;
+            (void)hipEventRecord(d->xev[0], X);
+        }
         if ((rc = dist_exchange(h, dv, true, c, nullptr, has_sums ? 0 : 2, X))) break;
         if (sample) (void)hipEventRecord(d->xev[1], X);
         if (j + 1 < j0 + n) launch_cut(j + 1);

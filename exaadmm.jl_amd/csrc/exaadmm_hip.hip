@@ -2174,7 +2174,7 @@ extern "C" int exaadmm_run_fixed(exaadmm_handle* h, int iters, int first_major_i
                         dist_count_batch(h, true, DIST_BATCH);
                         continue;
                     }
-                    dist_sample_exchange(h, i0 == 0);
+                    if (i0 == 0) dist_sample_exchange(h, true);   // (one exchange of the first, directly enqueued batch is bracketed by events; read after the call's synchronisation)
                     if ((rc = enqueue_dist_iterations(h, h->d_ctrl, 0, n, i0 == 0, time_branch ? &h->ev[2 + 2 * i0] : nullptr))) return rc;
                     dist_count_batch(h, false, 0);
                 }

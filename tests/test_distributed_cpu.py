@@ -209,3 +209,19 @@ def test_weak_scaling_workload_is_n_areas_with_few_tie_lines():
     assert 0 < cut <= 0.03 * world * l1, cut                                        # tie lines only
     # the ACTIVSg70k-sized case carries its own generator options (market-scale costs, which the README's rho is tuned to)
     assert syn.CASE_KW["case_ACTIVSg70k"] == {"cost": "market"}
+
+
+def test_north_star_scaling_workload_of_70k_sized_areas_can_be_generated_and_cut():
+    """bench.py --gpus N --case case_ACTIVSg70k: N areas of 70 000 buses in one band.  The DC angles of such a band drift to the ACOPF's
+    +-2 pi bounds unless the generator removes the long-range trend (exaadmm.jl_amd/synthetic.py); the two-area grid must build, keep
+    |theta| < 3 and small angle differences, and be cut into two partitions with a handful of tie lines."""
+    syn = exaadmm_loader.load_submodule("synthetic")
+    dm = exaadmm_loader.load_submodule("distributed")
+    g = syn.sized_like("case_ACTIVSg70k", seed=0, areas=2)
+    assert (int(g["nbus"]), int(g["nline"])) == (140000, 176414)
+    lo, hi = np.asarray(g["FrVaBound"]).reshape(-1, 2).T
+    assert np.all(lo <= hi)
+    parts = [dm.Partition(g, 2, r) for r in range(2)]
+    ncut = sum(p.n_cut for p in parts)
+    assert 0 < ncut <= 200, ncut
+    assert abs(parts[0].Bl - parts[1].Bl) <= 1 and all(p.n_native > 80000 for p in parts)

@@ -303,7 +303,7 @@ def main():
     try:
         kr = json.load(open(os.path.join(ROOT, "exaadmm.jl_amd", "kernel_resources.json")))
         if kr.get("source_digest") and ("src:" + kr["source_digest"]) in lib_version:
-            kernel_resources = kr["kernels"].get("k_resident" if resident else (("k_branch_t<true,true>" if mod.loop_kind() == 1 else "k_branch_t<true,false>") if T > 1 else "k_branch_t<false,true>"))
+            kernel_resources = kr["kernels"].get(("k_resident_t<2>" if ((L + 63) // 64 + (G + 63) // 64 + 1 > 1016) else "k_resident") if resident else (("k_branch_t<true,true>" if mod.loop_kind() == 1 else "k_branch_t<true,false>") if T > 1 else "k_branch_t<false,true>"))
     except Exception:
         pass
     branch_bytes = BYTES_PER_BRANCH_SOLVE * L
@@ -332,13 +332,13 @@ def main():
                    "rho_va": params["rho_va"], "scale": params["scale"], "tight_factor": tight,
                    "mode": "fixed-count inner iterations, no early break", "parallelism": "1 GPU",
                    "state": "ADMM state after %d untimed preparation iterations from init_solution! (outer 1, beta %.0f)" % (args.prep, beta)},
-        "roofline": {"bound": "hbm", "kernel": ("k_resident (one launch = the K iterations of a region; figures per iteration)" if resident else
+        "roofline": {"bound": "hbm", "kernel": (("k_resident_t<2> (up to two tiles of 64 branches per resident wavefront; " if ((L + 63) // 64 + (G + 63) // 64 + 1 > 1016) else "k_resident (") + "one launch = the K iterations of a region; figures per iteration)" if resident else
                                                 "k_branch" + (" (with the fused z/l prologue)" if fused_zl else "")), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": branch_bytes, "kernel_ms": ms_branch,
                      "kernel_ms_measured_over": ("HIP events around the k_resident launch of the %d steps following the timed region, divided by %d" % (args.steps, args.steps)) if resident
                                                 else "HIP events around each k_branch launch of the %d steps following the timed region" % args.steps,
-                     "loop": "resident (one launch per batch of iterations)" if resident else "two launches per iteration",
+                     "loop": "resident (one launch per inner loop / per fixed-count run)" if resident else "two launches per iteration",
                      "iteration_bytes": BYTES_PER_ITER(G, L, B),
                      "iteration_frac": BYTES_PER_ITER(G, L, B) * its / 1e9 / HBM_PEAK_GBS,
                      # HBM is the wrong roof at the named sizes (state is Infinity-Cache resident, the kernel is the FP64

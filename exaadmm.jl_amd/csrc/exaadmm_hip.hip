@@ -135,6 +135,7 @@ struct exaadmm_handle {
     int resident_cap = -1;
     int resident_downgrades = 0;
     int resident_launches = 0;
+    bool resident_zeroed = false;   // the hand-over words were reset by the call's opening launch (k_resident_begin)
     bool resident_coop = false;
     int resident_cap2 = -1;      // the same for k_resident_t<2> (two tiles of 64 branches per wavefront)
     ResidentTiles rtiles = {nullptr, 0, 0, 0, 0};
@@ -1459,10 +1460,22 @@ __global__ void k_copy_list(CopyList c)
     for (int q = 0; q < c.n; q++)
         for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < c.words[q]; i += gridDim.x * blockDim.x) c.dst[q][i] = c.src[q][i];
 }
+// What a call that runs the resident loop does before its first launch, in ONE launch (it used to be a host-to-device copy of the
+// control block, two memsets and the guard's copy kernel, each with its own launch gap: ~50 us in front of every run, 5 % of a
+// 20-iteration run at 13 659 buses): the guard snapshot, `zero[0 .. nzero)` = 0 (arrive | ready | contrib, decided, stop | fail),
+// and -- if `ctrl` is not null -- the control block the loop starts from.
+__global__ void k_resident_begin(CopyList c, int* zero, unsigned int nzero, Ctrl* ctrl, Ctrl init)
+{
+    const unsigned int tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+    for (int q = 0; q < c.n; q++)
+        for (unsigned int i = tid; i < c.words[q]; i += nt) c.dst[q][i] = c.src[q][i];
+    for (unsigned int i = tid; i < nzero; i += nt) zero[i] = 0;
+    if (ctrl != nullptr && tid == 0) *ctrl = init;
+}
 
 // everything an inner loop changes that lives in the PRIMARY buffers (where every loop starts and ends): u, v, z, z_prev, l,
 // the line-limit multipliers and penalty, the per-branch counters
-static int resident_guard(exaadmm_handle* h, bool restore)
+static int resident_guard(exaadmm_handle* h, bool restore, const Ctrl* begin = nullptr)
 {
     int rc;
     if (h->guard.empty()) {
@@ -1490,12 +1503,21 @@ static int resident_guard(exaadmm_handle* h, bool restore)
         c.dst[q] = (unsigned long long*)(restore ? prim[q] : h->guard[q]);
         c.words[q] = (unsigned int)(q < 5 ? h->N : (q < 8 ? h->Lp : h->Lp / 2));
     }
-    hipLaunchKernelGGL(k_copy_list, dim3(std::min(1024, std::max(1, h->N / 256))), dim3(256), 0, h->stream, c);
+    if (begin != nullptr || !restore) {
+        // the snapshot rides in the call's first launch, with the reset of the hand-over words and (run_fixed) the control block
+        const ResidentSync& r = h->rsync;
+        Ctrl init;
+        memset(&init, 0, sizeof(init));
+        if (begin) init = *begin;
+        hipLaunchKernelGGL(k_resident_begin, dim3(std::min(1024, std::max(1, h->N / 256))), dim3(256), 0, h->stream, c, r.arrive,
+                           (unsigned int)(2 * (size_t)h->B + 4), begin ? h->d_ctrl : (Ctrl*)nullptr, init);
+    } else
+        hipLaunchKernelGGL(k_copy_list, dim3(std::min(1024, std::max(1, h->N / 256))), dim3(256), 0, h->stream, c);
     HIPCHK(hipGetLastError());
     return 0;
 }
 
-static int resident_prepare(exaadmm_handle* h)
+static int resident_prepare(exaadmm_handle* h, const Ctrl* begin = nullptr)
 {
     ResidentSync& r = h->rsync;
     int rc;
@@ -1528,16 +1550,19 @@ static int resident_prepare(exaadmm_handle* h)
         if ((rc = dev_alloc(h, &t, 2 * (size_t)h->rtiles.wb + (size_t)nb))) return rc;   // the table, then the tiles' keys
         h->rtiles.tiles = t;
     }
-    HIPCHK(hipMemsetAsync(r.fail, 0, sizeof(int), h->stream));
     h->h_base[1] = 0;
-    return resident_guard(h, false);   // the iterate the call starts from: what a failed batch falls back to
+    h->resident_zeroed = true;   // (the call's first launch finds its hand-over words reset: enqueue_resident)
+    // the iterate the call starts from -- what a failed batch falls back to --, the reset of arrive .. fail, the control block: one launch
+    return resident_guard(h, false, begin);
 }
 
 // one launch = `n` iterations of the loop (the batch); the loop control is read and advanced inside (k_resident)
 static int enqueue_resident(exaadmm_handle* h, int n)
 {
     const int nb = branch_blocks(h), ng = gen_blocks(h);
-    HIPCHK(hipMemsetAsync(h->rsync.arrive, 0, (2 * (size_t)h->B + 3) * sizeof(int), h->stream));
+    if (!h->resident_zeroed)   // (everything but `fail`: a later launch's reset must not erase what an earlier one reported)
+        HIPCHK(hipMemsetAsync(h->rsync.arrive, 0, (2 * (size_t)h->B + 3) * sizeof(int), h->stream));
+    h->resident_zeroed = false;
     h->resident_launches += 1;
     if (const char* e = getenv("EXAADMM_RESIDENT_TEST_FAIL"))   // tests: the n-th resident launch of a handle reports a failed wait
         if (atoi(e) == h->resident_launches) HIPCHK(hipMemsetAsync(h->rsync.fail, 0x01, 1, h->stream));
@@ -1873,7 +1898,7 @@ static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
     bool first = true;
     const bool resident = resident_eligible(h);
     if (resident && (rc = resident_prepare(h))) return rc;
-    bool downgrade = false;
+    bool downgrade = false, completed = false;
     while (enq < max_inner) {
         // resident: ONE launch (and one host visit) per 1 024 iterations -- normally the whole inner loop; the launch ends inside the
         // kernel at the iteration the stop test names, so its length only bounds the host visits (a launch has a fixed cost of
@@ -1897,6 +1922,12 @@ static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
                 (void)hipEventRecord(h->tev[3], h->stream);
             }
             if ((rc = resident_check_enqueue(h))) return rc;
+            if (enq + nb >= max_inner) {
+                // no batch can follow: the z / l pass and the reduction of the last iteration (they return at once if the loop stopped
+                // earlier) ride in front of this batch's ONE synchronisation
+                if ((rc = spec_complete_last(h, enq + nb))) return rc;
+                completed = true;
+            }
         } else if (peers && !first && nb == batch && dist_batch_graph(h)) {
             HIPCHK(hipGraphLaunch(h->spec_graph, h->stream));
             dist_count_batch(h, true, batch);
@@ -1947,9 +1978,11 @@ static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
         HIPCHK(hipStreamSynchronize(h->stream));
         return run_inner_spec(h, max_inner, hc);
     }
-    if ((rc = spec_complete_last(h, enq))) return rc;
-    HIPCHK(hipMemcpyAsync(hc, h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
-    if ((rc = sync_check(h, true))) return rc;
+    if (!completed) {
+        if ((rc = spec_complete_last(h, enq))) return rc;
+        HIPCHK(hipMemcpyAsync(hc, h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
+        if ((rc = sync_check(h, true))) return rc;
+    }
     if ((rc = spec_finish(h, hc->inner))) return rc;
     for (int q = 0; q < 3; q++) h->acc_ms[q] += (double)ms_sample[q] * hc->inner;
     return 0;
@@ -2152,9 +2185,11 @@ extern "C" int exaadmm_run_fixed(exaadmm_handle* h, int iters, int first_major_i
             hc->beta = beta;
             hc->base = first_major_iter - 1;
             hc->first_iter = first_major_iter;
-            HIPCHK(hipMemcpyAsync(h->d_ctrl, hc, sizeof(Ctrl), hipMemcpyHostToDevice, h->stream));   // (hc is pinned and not written again before the call's final synchronisation)
             const bool resident = resident_eligible(h);
-            if (resident && (rc = resident_prepare(h))) return rc;
+            if (resident) {   // (the control block travels in the opening launch)
+                if ((rc = resident_prepare(h, hc))) return rc;
+            } else
+                HIPCHK(hipMemcpyAsync(h->d_ctrl, hc, sizeof(Ctrl), hipMemcpyHostToDevice, h->stream));   // (hc is pinned and not written again before the call's final synchronisation)
             HIPCHK(hipEventRecord(h->ev[0], h->stream));
             bool refused = false;
             if (resident) {
@@ -2181,23 +2216,24 @@ extern "C" int exaadmm_run_fixed(exaadmm_handle* h, int iters, int first_major_i
             } else
                 for (int i = 0; i < iters; i++)
                     if ((rc = enqueue_iteration_spec(h, h->d_ctrl, i, false, time_branch ? &h->ev[2 + 2 * i] : nullptr))) return rc;
-            if (resident) {
-                // a batch that was not co-resident is not a state of the algorithm: back to the iterate the call was entered
-                // with, and once more with the two-launch loop (resident_eligible is false from here on)
-                if (!refused) {
-                    if ((rc = resident_check_enqueue(h))) return rc;
-                    if ((rc = sync_check(h, true))) return rc;
-                }
-                if (refused || resident_failed(h)) {
-                    if ((rc = resident_downgrade(h))) return rc;
-                    continue;
-                }
+            if (resident && refused) {   // the runtime says the grid is not co-resident
+                if ((rc = resident_downgrade(h))) return rc;
+                continue;
             }
             if ((rc = spec_complete_last(h, iters))) return rc;
             HIPCHK(hipEventRecord(h->ev[1], h->stream));
             if ((rc = spec_finish(h, iters))) return rc;
+            // the failure flag of a resident launch travels with the call's ONE synchronisation (what ran behind a failed launch
+            // worked on an iterate that is thrown away)
+            if (resident && (rc = resident_check_enqueue(h))) return rc;
             double s[4];
             if ((rc = fetch_sums(h, s, true))) return rc;
+            if (resident && resident_failed(h)) {
+                // a batch that was not co-resident is not a state of the algorithm: back to the iterate the call was entered
+                // with, and once more with the two-launch loop (resident_eligible is false from here on)
+                if ((rc = resident_downgrade(h))) return rc;
+                continue;
+            }
             if (dist_has_peers(h)) dist_sample_exchange(h, false);
             if (out)
                 for (int j = 0; j < 4; j++) out[j] = s[j];

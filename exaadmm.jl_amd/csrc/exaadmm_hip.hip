@@ -135,7 +135,7 @@ struct exaadmm_handle {
     int resident_cap = -1;
     int resident_downgrades = 0;
     int resident_launches = 0;
-    bool resident_zeroed = false;   // the hand-over words were reset by the call's opening launch (k_resident_begin)
+    bool resident_zeroed = false;   // the hand-over words were reset by the call's opening launch (k_loop_begin)
     bool resident_coop = false;
     int resident_cap2 = -1;      // the same for k_resident_t<2> (two tiles of 64 branches per wavefront)
     ResidentTiles rtiles = {nullptr, 0, 0, 0, 0};
@@ -1464,7 +1464,7 @@ __global__ void k_copy_list(CopyList c)
 // control block, two memsets and the guard's copy kernel, each with its own launch gap: ~50 us in front of every run, 5 % of a
 // 20-iteration run at 13 659 buses): the guard snapshot, `zero[0 .. nzero)` = 0 (arrive | ready | contrib, decided, stop | fail),
 // and -- if `ctrl` is not null -- the control block the loop starts from.
-__global__ void k_resident_begin(CopyList c, int* zero, unsigned int nzero, Ctrl* ctrl, Ctrl init)
+__global__ void k_loop_begin(CopyList c, int* zero, unsigned int nzero, Ctrl* ctrl, Ctrl init)
 {
     const unsigned int tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
     for (int q = 0; q < c.n; q++)
@@ -1509,7 +1509,7 @@ static int resident_guard(exaadmm_handle* h, bool restore, const Ctrl* begin = n
         Ctrl init;
         memset(&init, 0, sizeof(init));
         if (begin) init = *begin;
-        hipLaunchKernelGGL(k_resident_begin, dim3(std::min(1024, std::max(1, h->N / 256))), dim3(256), 0, h->stream, c, r.arrive,
+        hipLaunchKernelGGL(k_loop_begin, dim3(std::min(1024, std::max(1, h->N / 256))), dim3(256), 0, h->stream, c, r.arrive,
                            (unsigned int)(2 * (size_t)h->B + 4), begin ? h->d_ctrl : (Ctrl*)nullptr, init);
     } else
         hipLaunchKernelGGL(k_copy_list, dim3(std::min(1024, std::max(1, h->N / 256))), dim3(256), 0, h->stream, c);

@@ -28,7 +28,7 @@ for key, tag in (("k_branch", "k_branch"), ("k_bus", "k_bus_group")):
         if b > a:
             out[tag][n] = {"launches": int(b - a), "average_us": float(d[a:b].mean()), "min_us": float(d[a:b].min()), "max_us": float(d[a:b].max())}
 # resident loop: one k_resident launch per phase (preparation, warm-up, timed region, event-bracketed pass), `its` iterations each
-res = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if "k_resident" in r["Kernel_Name"]]
+res = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if "k_resident_t" in r["Kernel_Name"]]
 if res:
     out["k_resident"] = {"launches": len(res)}
     for n, its, d in zip(["preparation", "warm_up", "timed_region", "event_bracketed_pass"], [P, W, K, K], res):

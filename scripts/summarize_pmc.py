@@ -18,7 +18,7 @@ from collections import defaultdict
 
 out_dir, workload = sys.argv[1], sys.argv[2]
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 200
-short = {"k_branch_t": "k_branch", "k_bus_group": "k_bus_group", "k_fused_zl": "k_fused_zl", "k_resident": "k_resident"}
+short = {"k_branch_t": "k_branch", "k_bus_group": "k_bus_group", "k_fused_zl": "k_fused_zl", "k_resident_t": "k_resident"}
 # k_resident (resident loop): ONE launch does the `steps` iterations of a region; its last launch is the event-bracketed pass;
 # counters and duration are divided by `steps` -> per ITERATION figures
 acc = defaultdict(dict)

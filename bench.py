@@ -299,11 +299,15 @@ def main():
     occ = mod.branch_kernel_occupancy() if hasattr(mod, "branch_kernel_occupancy") else None
     # registers / spills / LDS of the dominant kernel, from the remarks of the library's own compile (csrc/Makefile ->
     # exaadmm.jl_amd/kernel_resources.json, which carries the digest of the sources it belongs to)
+    # which form of the resident kernel the timed regions ran (the library's own rule, exaadmm_hip.hip enqueue_resident: two tiles per
+    # wavefront above the chip's SIMD count; heavy wavefronts for launches that continue an inner loop beyond its 64th iteration)
+    two_tile = (L + 63) // 64 + (G + 63) // 64 + 1 > 1016
+    heavy = bool(resident and not two_tile and T == 1 and args.prep + args.warmup >= 64 and not os.environ.get("EXAADMM_NO_HEAVY"))
     kernel_resources = None
     try:
         kr = json.load(open(os.path.join(ROOT, "exaadmm.jl_amd", "kernel_resources.json")))
         if kr.get("source_digest") and ("src:" + kr["source_digest"]) in lib_version:
-            kernel_resources = kr["kernels"].get(("k_resident_t<2>" if ((L + 63) // 64 + (G + 63) // 64 + 1 > 1016) else "k_resident") if resident else (("k_branch_t<true,true>" if mod.loop_kind() == 1 else "k_branch_t<true,false>") if T > 1 else "k_branch_t<false,true>"))
+            kernel_resources = kr["kernels"].get(("k_resident_t<2>" if two_tile else ("k_resident_t<1,heavy>" if heavy else "k_resident")) if resident else (("k_branch_t<true,true>" if mod.loop_kind() == 1 else "k_branch_t<true,false>") if T > 1 else "k_branch_t<false,true>"))
     except Exception:
         pass
     branch_bytes = BYTES_PER_BRANCH_SOLVE * L
@@ -332,7 +336,7 @@ def main():
                    "rho_va": params["rho_va"], "scale": params["scale"], "tight_factor": tight,
                    "mode": "fixed-count inner iterations, no early break", "parallelism": "1 GPU",
                    "state": "ADMM state after %d untimed preparation iterations from init_solution! (outer 1, beta %.0f)" % (args.prep, beta)},
-        "roofline": {"bound": "hbm", "kernel": (("k_resident_t<2> (up to two tiles of 64 branches per resident wavefront; " if ((L + 63) // 64 + (G + 63) // 64 + 1 > 1016) else "k_resident (") + "one launch = the K iterations of a region; figures per iteration)" if resident else
+        "roofline": {"bound": "hbm", "kernel": (("k_resident_t<2> (up to two tiles of 64 branches per resident wavefront; " if two_tile else ("k_resident_t<1, heavy> (the branches with the most solver trips on wavefronts of their own; " if heavy else "k_resident (")) + "one launch = the K iterations of a region; figures per iteration)" if resident else
                                                 "k_branch" + (" (with the fused z/l prologue)" if fused_zl else "")), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": branch_bytes, "kernel_ms": ms_branch,

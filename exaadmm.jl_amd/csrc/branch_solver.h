@@ -507,9 +507,12 @@ struct BranchStats {
 // the same bits): sin/cos and the flows are evaluated once per point, by the objective evaluation
 // of the trial point, and carried with it (phi/scs accepted, phit/scst trial); f is recomputed only
 // when the multipliers changed (new subproblem).
-template <class D, class MA, class ML>
+// CLONES: all 64 lanes of the wavefront run THIS solve (same inputs in every lane: the heavy wavefronts of kernels.h k_resident);
+// search = 2 x 6 + 2 doubles of LDS for the Cauchy search's hand-over (tron_device.h cauchy_clones).
+template <bool CLONES = false, class D, class MA, class ML>
 EXA_HD void branch_solve(D& d, const BranchOptions& o, const MuPowTable& pw, double (&x)[6], const double (&xl)[6],
-                         const double (&xu)[6], MA& A, ML& L, double (&phi)[4], BranchStats& stats, double* park = nullptr)
+                         const double (&xu)[6], MA& A, ML& L, double (&phi)[4], BranchStats& stats, double* park = nullptr,
+                         double* search = nullptr)
 {
     d.park(park);
     TronState<6> st;
@@ -571,7 +574,7 @@ EXA_HD void branch_solve(D& d, const BranchOptions& o, const MuPowTable& pw, dou
         unsigned long long t1 = EXA_TICK();
         stats.cyc[0] += t1 - t0;
         if (fin == TRON_RUN) {
-            tron_compute<6>(st, x, xl, xu, A, L, g, o.cgtol, 6);
+            tron_compute<6, CLONES>(st, x, xl, xu, A, L, g, o.cgtol, 6, search);
             d.fetch(park);
             unsigned long long t2 = EXA_TICK();
             stats.cyc[1] += t2 - t1;

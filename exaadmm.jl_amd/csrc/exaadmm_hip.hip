@@ -139,6 +139,8 @@ struct exaadmm_handle {
     bool resident_coop = false;
     int resident_cap2 = -1;      // the same for k_resident_t<2> (two tiles of 64 branches per wavefront)
     ResidentTiles rtiles = {nullptr, 0, 0, 0, 0};
+    ResidentHeavy rheavy = {nullptr, nullptr, nullptr, nullptr, 0};   // heavy wavefronts of the resident launch (kernels.h); n = 0: none
+    int heavy_max = 0;
     std::vector<void*> guard;
     size_t nrec_slots = 0;
     ResidentSync rsync = {};
@@ -1540,6 +1542,19 @@ static int resident_prepare(exaadmm_handle* h, const Ctrl* begin = nullptr)
             HIPCHK(hipMemsetAsync(r.terms[q], 0, 4 * h->nrec_slots * sizeof(double), h->stream));
         }
     }
+    if (resident_mode(h) == 1 && !h->rheavy.list) {
+        // wavefronts of their own for the branches with the most solver trips: as many as the launch leaves SIMDs idle (at most 512)
+        const int spare = resident_capacity(h) - (branch_blocks(h) + gen_blocks(h) + 1);
+        h->heavy_max = std::max(0, std::min(512, spare));
+        int* t = nullptr;
+        if ((rc = dev_alloc(h, &t, (size_t)std::max(1, h->heavy_max) + (size_t)h->Lp))) return rc;
+        h->rheavy.list = t;
+        h->rheavy.flag = t + std::max(1, h->heavy_max);
+        double* hu = nullptr;
+        if ((rc = dev_alloc(h, &hu, 3 * 16 * (size_t)std::max(1, h->heavy_max)))) return rc;
+        h->rheavy.u = hu;
+        h->rheavy.init = hu + 2 * 16 * (size_t)std::max(1, h->heavy_max);
+    }
     if (resident_mode(h) == 2 && !h->rtiles.tiles) {
         const int nb = branch_blocks(h), ng = gen_blocks(h);
         int* t = nullptr;
@@ -1557,7 +1572,7 @@ static int resident_prepare(exaadmm_handle* h, const Ctrl* begin = nullptr)
 }
 
 // one launch = `n` iterations of the loop (the batch); the loop control is read and advanced inside (k_resident)
-static int enqueue_resident(exaadmm_handle* h, int n)
+static int enqueue_resident(exaadmm_handle* h, int n, int loop_iter0)
 {
     const int nb = branch_blocks(h), ng = gen_blocks(h);
     if (!h->resident_zeroed)   // (everything but `fail`: a later launch's reset must not erase what an earlier one reported)
@@ -1576,11 +1591,25 @@ static int enqueue_resident(exaadmm_handle* h, int n)
         hipLaunchKernelGGL(k_tile_assign, dim3(1), dim3(1024), 2 * (size_t)t.nb * sizeof(int), h->stream, (const int*)keys, t.nb, t.wb, const_cast<int*>(t.tiles));
         grid = t.wb + t.wg + 1;
     }
+    ResidentHeavy rh = h->rheavy;
+    rh.n = 0;
+    // Heavy wavefronts (kernels.h) serve launches that CONTINUE an inner loop beyond its 64th iteration: the branches they take
+    // are chosen from the trip counters of the iterations before the launch, and at the start of an inner loop (the penalties
+    // restart, the slowest branch changes from iteration to iteration) those say nothing -- a launch from there runs the kernel
+    // without them (profiles/r04_heavy_wavefronts.txt: +8.6 % in the steady state, -2.7 % over a whole solve if always on).
+    if (mode == 1 && loop_iter0 >= 64 && h->heavy_max > 0 && getenv("EXAADMM_NO_HEAVY") == nullptr) {
+        // which branches get a wavefront of their own in this launch: from the solver-trip counters of the last x-updates (both buffer sets)
+        rh.n = h->heavy_max;
+        hipLaunchKernelGGL(k_heavy_select, dim3(1), dim3(1024), 0, h->stream, (const int*)h->sets[0].st[2], (const int*)h->sets[1].st[2], h->L, h->Lp, rh.n,
+                           const_cast<int*>(rh.list), const_cast<int*>(rh.flag), (const double*)h->d.z, (const double*)h->d.l, 2 * h->Gp, const_cast<double*>(rh.init));
+        grid += rh.n;
+    }
     if (h->resident_coop) {
         const Dev *d0 = h->d_dspec[0][0], *d1 = h->d_dspec[1][0];
         double scale = h->par.scale, base = h->baseMVA;
-        void* args[] = {(void*)&d0, (void*)&d1, (void*)&h->bo, (void*)&scale, (void*)&h->d_ctrl, (void*)&ng, (void*)&base, (void*)&n, (void*)&h->rsync, (void*)&h->rtiles};
-        const hipError_t e = hipLaunchCooperativeKernel(mode == 2 ? (const void*)k_resident_t<2> : (const void*)k_resident_t<1>, dim3(grid), dim3(BR_BLOCK), args, 0, h->stream);
+        void* args[] = {(void*)&d0, (void*)&d1, (void*)&h->bo, (void*)&scale, (void*)&h->d_ctrl, (void*)&ng, (void*)&base, (void*)&n, (void*)&h->rsync, (void*)&h->rtiles, (void*)&rh};
+        const hipError_t e = hipLaunchCooperativeKernel(mode == 2 ? (const void*)k_resident_t<2> : (rh.n > 0 ? (const void*)k_resident_t<1, true> : (const void*)k_resident_t<1>), dim3(grid), dim3(BR_BLOCK), args, 0,
+                                                        h->stream);
         if (e == hipSuccess) return 0;
         (void)hipGetLastError();
         if (e != hipErrorCooperativeLaunchTooLarge) h->resident_coop = false;   // (not offered after all: plain launches from here on)
@@ -1588,10 +1617,13 @@ static int enqueue_resident(exaadmm_handle* h, int n)
     }
     if (mode == 2)
         hipLaunchKernelGGL(k_resident_t<2>, dim3(grid), dim3(BR_BLOCK), 0, h->stream, h->d_dspec[0][0], h->d_dspec[1][0], h->bo, h->par.scale, h->d_ctrl, ng,
-                           h->baseMVA, n, h->rsync, h->rtiles);
+                           h->baseMVA, n, h->rsync, h->rtiles, rh);
+    else if (rh.n > 0)
+        hipLaunchKernelGGL((k_resident_t<1, true>), dim3(grid), dim3(BR_BLOCK), 0, h->stream, h->d_dspec[0][0], h->d_dspec[1][0], h->bo, h->par.scale, h->d_ctrl, ng,
+                           h->baseMVA, n, h->rsync, h->rtiles, rh);
     else
         hipLaunchKernelGGL(k_resident_t<1>, dim3(grid), dim3(BR_BLOCK), 0, h->stream, h->d_dspec[0][0], h->d_dspec[1][0], h->bo, h->par.scale, h->d_ctrl, ng,
-                           h->baseMVA, n, h->rsync, h->rtiles);
+                           h->baseMVA, n, h->rsync, h->rtiles, rh);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1911,7 +1943,7 @@ static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
             // step timers of the reference cannot be told apart inside one launch: the sampled time of the first batch goes to
             // time_x_update.)
             if (first) (void)hipEventRecord(h->tev[0], h->stream);
-            if ((rc = enqueue_resident(h, nb)) < 0) return rc;
+            if ((rc = enqueue_resident(h, nb, enq)) < 0) return rc;
             if (rc > 0) {   // the runtime refused the cooperative launch
                 downgrade = true;
                 break;
@@ -2195,7 +2227,7 @@ extern "C" int exaadmm_run_fixed(exaadmm_handle* h, int iters, int first_major_i
             if (resident) {
                 // ONE launch for all `iters` iterations: every wavefront stays resident, a bus is updated by the last lane to arrive at it
                 if (time_branch) HIPCHK(hipEventRecord(h->ev[2], h->stream));
-                if ((rc = enqueue_resident(h, iters)) < 0) return rc;
+                if ((rc = enqueue_resident(h, iters, first_major_iter - 1)) < 0) return rc;
                 refused = rc > 0;
                 if (time_branch) HIPCHK(hipEventRecord(h->ev[3], h->stream));   // (one launch: its time / iters is reported)
             } else if (dist_has_peers(h)) {

@@ -1360,21 +1360,47 @@ struct ResidentTiles {
     int nb, ng, wb, wg;   // branch tiles, generator tiles, branch wavefronts, generator wavefronts
 };
 
-template <int TILES>
+// HEAVY WAVEFRONTS (TILES = 1: grids that leave SIMDs idle -- 13 659 buses use 385 of 1 024).  What sets the pace of an iteration is
+// its slowest branch: six solver trips, four or five of them with ONE active lane in its wavefront.  The branches that needed three
+// or more trips in the last iterations (k_heavy_select, in front of the launch; the set is persistent) get a wavefront of their
+// own, blocks [nwaves, nwaves + rh.n): all 64 lanes run THAT branch's solve as clones -- the same inputs, instructions and bits in
+// every lane -- except that in the Cauchy search every lane evaluates its own candidate step length (tron_device.h cauchy_clones:
+// 3.8 model evaluations one after the other become one).  The branch's lane in its tile still makes the z / l pass and the
+// residual contribution (the sums keep their order) and stores v, z, l; it neither solves nor arrives.  The heavy wavefront keeps
+// z, l and the multipliers of its branch in registers (it forms the same z / l values from the same inputs), solves, stores u
+// (agent scope: the tile's lane reads it for the next z / l pass, after its buses are ready -- which the heavy wavefront's
+// arrival precedes), pushes the bus terms and arrives at both buses.  Same arithmetic per branch, whoever solves it: bitwise the
+// two-launch loop (tests/test_gpu_resident.py).  This code shares no value with the solver loop of the ordinary lanes: inlined
+// into that loop the side-by-side search cost every trip of every lane 8 - 21 % (profiles/r04_lone_search.txt).
+struct ResidentHeavy {
+    const int* list;   // [n] storage slot of the branch of heavy wavefront w, -1: none
+    const int* flag;   // [Lp] w + 1: the branch is solved by heavy wavefront w in this launch, 0: by its lane
+    const double* init;   // [n][16] z, l of the heavy branches in front of the launch (k_heavy_select)
+    double* u;         // [2][n][16] hand-over of a heavy branch's u (8 of the 16) to its tile's lane, by iteration parity -- lines that
+                       //  only agent-scope accesses ever touch.  (NOT through the u plane: the tile's wavefront holds that line in its
+                       //  XCD's L2 for its plain accesses to the neighbouring branches, and an agent-scope load of such a line is
+                       //  served from there, stale -- seen, not assumed.)  No WORD is written by both wavefronts: one word dirty in
+                       //  two L2s leaves the result to the order of the write-backs (seen: v of the last index).
+    int n;
+};
+
+template <int TILES, bool HEAVY = false>
 __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restrict__ dp0, const Dev* __restrict__ dp1, BranchOptions o, double scale,
-                                                             Ctrl* ctrl, int gen_blocks, double baseMVA, int iters, ResidentSync rs, ResidentTiles rt)
+                                                             Ctrl* ctrl, int gen_blocks, double baseMVA, int iters, ResidentSync rs, ResidentTiles rt,
+                                                             ResidentHeavy rh)
 {
     if (ctrl->done) return;
     const int base_iter = ctrl->base;
     const double zl_beta = ctrl->beta;
     const bool first_has_zl = (base_iter + 1 != ctrl->first_iter);
-    const int nwaves = gridDim.x - 1;             // the last block is the control wavefront
+    const int nheavy = (TILES == 1 && HEAVY) ? rh.n : 0;   // (HEAVY = false: the kernel without a line of the heavy wavefronts' code)
+    const int nwaves = gridDim.x - 1 - nheavy;    // the last block is the control wavefront, the heavy wavefronts sit in front of it
     // contributions the control wavefront expects per z / l pass = tiles of the grid; wavefronts [0, nbr_waves) hold branches
     const int nwork = (TILES == 1) ? nwaves : rt.nb + rt.ng;
     const int nbr_waves = (TILES == 1) ? nwaves - gen_blocks : rt.wb;
     const int nbr_tiles = (TILES == 1) ? nbr_waves : rt.nb;
     const int lane = threadIdx.x;
-    if ((int)blockIdx.x == nwaves) {
+    if ((int)blockIdx.x == (int)gridDim.x - 1) {
         // ---------------- control wavefront: one decision per z / l pass
         const int npass = resident_passes(first_has_zl, iters - 1);
         for (int p = 1; p <= npass; p++) {
@@ -1406,6 +1432,156 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
             stop = __shfl(stop, 0, 64);
             if (stop) return;
         }
+        return;
+    }
+    __shared__ MuPowTable pw_lds;
+    __shared__ double park_lds[40 * BR_BLOCK];
+    if (TILES == 1 && HEAVY && (int)blockIdx.x >= nwaves) {
+        // ---------------- heavy wavefront: one branch, 64 clones
+        const int hw = (int)blockIdx.x - nwaves;
+        const int b = rh.list[hw];
+        if (b < 0) return;
+        if (lane < 24) reinterpret_cast<double*>(&pw_lds)[lane] = reinterpret_cast<const double*>(&c_mupow)[lane];
+        double* const park_h = park_lds;
+        double* const search_h = park_lds + 32 * BR_BLOCK;   // (entries 32 .. 39 hold z in the ordinary lanes' use of the area)
+        double* const keep = search_h + 16;                  // what the wavefront needs again behind the solve, not in it: bnd, lz | z, l
+        const MuPowTable& pw_h = pw_lds;
+        const Dev& d0 = *dp0;
+        const int Lp = d0.Lp, base = 2 * d0.Gp + b;
+        const int4 bus4 = reinterpret_cast<const int4*>(d0.br_bus4)[b];
+        const int rec_from = d0.rec_br[2 * b], rec_to = d0.rec_br[2 * b + 1];
+        BranchData bd;
+        double zc[8], lc[8], uc[8];
+        double x[6], phi[4];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int e = base + k * Lp;
+            bd.rho_[k] = d0.rho[e];
+            bd.Y_[k] = d0.Y[b + k * Lp];
+            if (lane == 0) {
+                keep[k] = d0.bnd[b + k * Lp];
+                keep[8 + k] = d0.lz[e];
+            }
+            zc[k] = rh.init[16 * hw + k];
+            lc[k] = rh.init[16 * hw + 8 + k];
+            uc[k] = (d0.u_in ? d0.u_in : d0.u)[e];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        bd.ls1 = (d0.ls1_in ? d0.ls1_in : d0.ls1)[b];
+        bd.ls2 = (d0.ls2_in ? d0.ls2_in : d0.ls2)[b];
+        bd.mu = (d0.mu_in ? d0.mu_in : d0.mu)[b];
+        bd.scale = scale;
+        const double rate_0 = d0.rateA[b];
+        for (int i = 0; i < iters; i++) {
+            if (i > 0 && !resident_go_on(rs, resident_passes(first_has_zl, i - 1))) return;   // (wave-uniform)
+            const Dev& d = (i & 1) ? *dp1 : *dp0;
+            const bool do_zl = (i > 0) || first_has_zl;
+            double vv[8];
+            if (i > 0) {
+                if (!resident_wait(rs.ready + bus4.x, i, rs.fail)) return;
+                if (!resident_wait(rs.ready + bus4.z, i, rs.fail)) return;
+                const double* pf = rs.busres[i & 1] + 4 * (size_t)bus4.x;
+                const double* pt = rs.busres[i & 1] + 4 * (size_t)bus4.z;
+                const double rf[4] = {ld_agent(pf), ld_agent(pf + 1), ld_agent(pf + 2), ld_agent(pf + 3)};
+                const double rt4[4] = {ld_agent(pt), ld_agent(pt + 1), ld_agent(pt + 2), ld_agent(pt + 3)};
+                vv[0] = (uc[0] + zc[0]) + (lc[0] + rf[0]) / bd.rho_[0];
+                vv[1] = (uc[1] + zc[1]) + (lc[1] + rf[1]) / bd.rho_[1];
+                vv[4] = rf[2];
+                vv[6] = rf[3];
+                vv[2] = (uc[2] + zc[2]) + (lc[2] + rt4[0]) / bd.rho_[2];
+                vv[3] = (uc[3] + zc[3]) + (lc[3] + rt4[1]) / bd.rho_[3];
+                vv[5] = rt4[2];
+                vv[7] = rt4[3];
+            } else {
+                const double* const vbuf = d.v_in ? d.v_in : d.v;
+#pragma unroll
+                for (int k = 0; k < 8; k++) vv[k] = vbuf[base + k * Lp];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (do_zl) {   // (the values the tile's lane forms, stores and adds to the residual sums)
+                    double zs[4] = {0.0, 0.0, 0.0, 0.0}, zn;
+                    zl_values(uc[k], vv[k], bd.rho_[k], zl_beta, keep[8 + k], zc[k], lc[k], zs, bd.lam_[k], zn);
+                    bd.xt_[k] = vv[k] - zn;
+                    zc[k] = zn;
+                    lc[k] = bd.lam_[k];
+                } else {
+                    bd.lam_[k] = lc[k];
+                    bd.xt_[k] = vv[k] - zc[k];
+                }
+            }
+            if (base_iter + i + 1 == 1) bd.mu = 10.0;
+            SymMat<6> A, L;
+            double xl[6], xu[6];
+            {
+                double bnd[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    bnd[k] = keep[k];
+                    if (lane == 0) {
+                        keep[16 + k] = zc[k];
+                        keep[24 + k] = lc[k];
+                    }
+                }
+                branch_start(uc, bnd, rate_0, x, xl, xu);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            BranchStats st;
+            st.tl = nullptr;
+            branch_solve<true>(bd, o, pw_h, x, xl, xu, A, L, phi, st, park_h + lane, search_h);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                zc[k] = keep[16 + k];
+                lc[k] = keep[24 + k];
+            }
+            uc[0] = phi[0];
+            uc[1] = phi[1];
+            uc[2] = phi[2];
+            uc[3] = phi[3];
+            uc[4] = x[0] * x[0];
+            uc[5] = x[1] * x[1];
+            uc[6] = x[2];
+            uc[7] = x[3];
+            if (lane == 0) {
+                double* const ho = rh.u + ((size_t)(i & 1) * nheavy + hw) * 16;   // (read by the tile's lane with its next z / l pass)
+#pragma unroll
+                for (int k = 0; k < 8; k++) st_agent(ho + k, uc[k]);
+                // (the planes' words of this branch are written here only: the tile's lane leaves them alone.  They share cache lines
+                //  with the neighbouring branches' words, which the tile's wavefront writes from another XCD -- different bytes of a
+                //  line dirty in two L2s, merged by the byte masks of the write-backs like the output of any two workgroups)
+#pragma unroll
+                for (int k = 0; k < 8; k++) d.u[base + k * Lp] = uc[k];
+                d.ls1[b] = bd.ls1;
+                d.ls2[b] = bd.ls2;
+                d.mu[b] = bd.mu;
+                d.st_auglag[b] = st.auglag_it;
+                d.st_minor[b] = st.minor_it;
+                d.st_ticks[b] = st.ticks;
+                double* const tm = rs.terms[(i + 1) & 1];
+                {
+                    double* q = tm + 4 * (size_t)rec_from;
+                    st_agent(q, (uc[0] + zc[0]) + (bd.lam_[0] / bd.rho_[0]));
+                    st_agent(q + 1, (uc[1] + zc[1]) + (bd.lam_[1] / bd.rho_[1]));
+                    st_agent(q + 2, bd.lam_[4] + bd.rho_[4] * (uc[4] + zc[4]));
+                    st_agent(q + 3, bd.lam_[6] + bd.rho_[6] * (uc[6] + zc[6]));
+                }
+                {
+                    double* q = tm + 4 * (size_t)rec_to;
+                    st_agent(q, (uc[2] + zc[2]) + (bd.lam_[2] / bd.rho_[2]));
+                    st_agent(q + 1, (uc[3] + zc[3]) + (bd.lam_[3] / bd.rho_[3]));
+                    st_agent(q + 2, bd.lam_[5] + bd.rho_[5] * (uc[5] + zc[5]));
+                    st_agent(q + 3, bd.lam_[7] + bd.rho_[7] * (uc[7] + zc[7]));
+                }
+            }
+            resident_order_stores();
+            if (lane == 0) {
+                resident_arrive(d, rs, bus4.x, bus4.y, i + 1);
+                resident_arrive(d, rs, bus4.z, bus4.w, i + 1);
+            }
+        }
+        // (v of the last index is written by the tile's lane, which wrote that word before: two XCDs with the same bytes dirty in their
+        //  L2s would leave the order of the write-backs to chance -- seen)
         return;
     }
     if ((int)blockIdx.x >= nbr_waves) {
@@ -1482,9 +1658,7 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
         return;
     }
     // ---------------- branch lanes
-    __shared__ MuPowTable pw_lds;
     if (lane < 24) reinterpret_cast<double*>(&pw_lds)[lane] = reinterpret_cast<const double*>(&c_mupow)[lane];
-    __shared__ double park_lds[40 * BR_BLOCK];
     const int Lp = dp0->Lp;
     const int my_tile0 = (TILES == 1) ? (int)blockIdx.x : rt.tiles[2 * blockIdx.x];
     const int my_tile1 = (TILES == 1) ? -1 : rt.tiles[2 * blockIdx.x + 1];
@@ -1503,7 +1677,11 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
             const int b = lane_on ? slot : 0;
             const int base = 2 * d.Gp + b;
             const int4 bus4 = reinterpret_cast<const int4*>(d.br_bus4)[b];
-            const int rec_from = d.rec_br[2 * b], rec_to = d.rec_br[2 * b + 1];
+            // (TILES = 1) the lane's branch is solved by a heavy wavefront in this launch: z / l pass, residual terms and v here, nothing
+            // else.  No value of its own across the solve: rec_from = -1 says so, rec_to holds the heavy wavefront's number.
+            const int hflag = (TILES == 1 && HEAVY && nheavy > 0) ? rh.flag[b] : 0;
+            const bool heavy_lane = lane_on && hflag != 0;
+            const int rec_from = heavy_lane ? -1 : d.rec_br[2 * b], rec_to = heavy_lane ? hflag - 1 : d.rec_br[2 * b + 1];
             const int major_iter = base_iter + i + 1;
             const bool do_zl = (i > 0) || first_has_zl;
             const bool v_from_bus = (i > 0);
@@ -1537,6 +1715,13 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
 #if defined(EXA_PROFILE_PHASES)
                 ts[2] = __builtin_amdgcn_s_memtime();   // both buses ready
 #endif
+                if (TILES == 1 && HEAVY && heavy_lane) {
+                    // the results of the last iteration were handed over by the branch's heavy wavefront before it arrived: u for this
+                    // z / l pass, and everything into the planes of the set that iteration wrote
+                    const double* const ho = rh.u + ((size_t)((i - 1) & 1) * nheavy + rec_to) * 16;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) ub[k] = ld_agent(ho + k);
+                }
                 const double* pf = rs.busres[i & 1] + 4 * (size_t)bus4.x;
                 const double* pt = rs.busres[i & 1] + 4 * (size_t)bus4.z;
                 const double rf[4] = {ld_agent(pf), ld_agent(pf + 1), ld_agent(pf + 2), ld_agent(pf + 3)};
@@ -1582,7 +1767,7 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
 #if defined(EXA_PROFILE_PHASES)
             asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts[3]) : : "memory");   // v, z / l pass, contribution done
 #endif
-            if (lane_on) {
+            if (lane_on && !(TILES == 1 && HEAVY && heavy_lane)) {
                 bd.mu = (major_iter == 1) ? 10.0 : mu_0;
                 bd.scale = scale;
                 SymMat<6> A, L;
@@ -1635,7 +1820,7 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
 #if defined(EXA_PROFILE_PHASES)
             ts[5] = __builtin_amdgcn_s_memtime();   // results and terms stored
 #endif
-            if (lane_on) {
+            if (lane_on && !(TILES == 1 && HEAVY && rec_from < 0)) {
                 resident_arrive(d, rs, bus4.x, bus4.y, i + 1);
                 resident_arrive(d, rs, bus4.z, bus4.w, i + 1);
             }
@@ -1672,6 +1857,12 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
             ll[k] = d.l[e];
             rr[k] = d.rho[e];
         }
+        const int hflag = (TILES == 1 && HEAVY && nheavy > 0) ? rh.flag[b] : 0;
+        if (hflag != 0) {   // (the results of the last iteration from the heavy wavefront's hand-over, as in the loop)
+            const double* const ho = rh.u + ((size_t)((iters - 1) & 1) * nheavy + (hflag - 1)) * 16;
+#pragma unroll
+            for (int k = 0; k < 8; k++) uu[k] = ld_agent(ho + k);
+        }
         d.v[base] = (uu[0] + zz[0]) + (ll[0] + rf[0]) / rr[0];
         d.v[base + Lp] = (uu[1] + zz[1]) + (ll[1] + rf[1]) / rr[1];
         d.v[base + 2 * Lp] = (uu[2] + zz[2]) + (ll[2] + rt4[0]) / rr[2];
@@ -1680,6 +1871,52 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
         d.v[base + 5 * Lp] = rt4[2];
         d.v[base + 6 * Lp] = rf[3];
         d.v[base + 7 * Lp] = rt4[3];
+    }
+}
+
+// Which branches get a heavy wavefront in the next resident launch (one block in front of it): those with the most solver trips in
+// the last accepted x-updates (both buffer sets), at least 3, at most `nmax` of them -- all branches with >= T trips, T the smallest
+// threshold that fits.  list[w] = the branch of heavy wavefront w (-1: none), flag[b] = w + 1 (0: the branch stays with its lane).
+// Which wavefront gets which branch is left to the order of the atomics: every branch is solved the same way wherever it runs.
+// init[w][0..7] = z, [8..15] = l of that branch as the launch finds them: the branch's lane overwrites both in place with the z / l pass
+// of the launch's first index, possibly before the heavy wavefront has looked (seen: ulp-level differences in a handful of branches).
+__global__ void __launch_bounds__(1024) k_heavy_select(const int* __restrict__ ticks0, const int* __restrict__ ticks1, int L, int Lp, int nmax,
+                                                       int* __restrict__ list, int* __restrict__ flag, const double* __restrict__ z,
+                                                       const double* __restrict__ l, int elem0, double* __restrict__ init)
+{
+    __shared__ int hist[64];
+    __shared__ int thr, count;
+    const int tid = threadIdx.x;
+    if (tid < 64) hist[tid] = 0;
+    if (tid == 0) count = 0;
+    __syncthreads();
+    for (int b = tid; b < L; b += 1024) atomicAdd(&hist[min(63, max(ticks0[b], ticks1[b]))], 1);
+    for (int w = tid; w < nmax; w += 1024) list[w] = -1;
+    __syncthreads();
+    if (tid == 0) {
+        int t = 64, acc = 0;
+        while (t > 3 && acc + hist[t - 1] <= nmax) {
+            t--;
+            acc += hist[t];
+        }
+        thr = t;   // (64: nobody)
+    }
+    __syncthreads();
+    const int T = thr;
+    for (int b = tid; b < Lp; b += 1024) {
+        int f = 0;
+        if (b < L && min(63, max(ticks0[b], ticks1[b])) >= T) {
+            const int pos = atomicAdd(&count, 1);
+            list[pos] = b;
+            f = pos + 1;
+        }
+        flag[b] = f;
+    }
+    __syncthreads();
+    const int n = count;
+    for (int q = tid; q < 16 * n; q += 1024) {
+        const int w = q >> 4, k = q & 7, e = elem0 + list[w] + k * Lp;
+        init[q] = (q & 8) ? l[e] : z[e];
     }
 }
 

@@ -310,6 +310,114 @@ EXA_BIG void cauchy(const double (&x)[N], const double (&xl)[N], const double (&
     }
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// ---- the Cauchy search of a branch whose solve runs on all 64 lanes of a wavefront as clones (kernels.h: the heavy wavefronts of k_resident)
+// The step lengths the search tries are known up front: alpha, then 0.1^k alpha (interpolation) or 10^k alpha (extrapolation); a
+// straggler makes 3.8 model evaluations per search one after the other (profiles/r02_solver_loop_trip_counts.txt).  Every lane holds
+// the same x, bounds, g, A, delta, alpha; lane 0 evaluates alpha, lanes 1..C the interpolation chain, lanes C+1..2C the extrapolation
+// chain -- gpstep_d / norm_exceeds / quad_model as the serial search calls them, on the operands the serial trip would see, so
+// every candidate carries the serial trip's bits -- and wavefront ballots replay the serial loop's decisions (first sufficient
+// decrease inside the region; last sufficient decrease before the step leaves the region or passes the last break point).  If a chain
+// of C candidates does not end the search the pass is repeated from its last alpha (C divides the serial loop's guard of 400 trips:
+// the guard falls on a pass boundary).  The winner's alpha, s, A s reach the other lanes through LDS (sh: 2 N + 2 doubles).
+#ifndef EXA_COOP_CHAIN
+#define EXA_COOP_CHAIN 8
+#endif
+__device__ __forceinline__ double lane_value(double v, int lane)   // lane: wave-uniform
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+template <int N, class MA>
+__device__ __forceinline__ void cauchy_clones(double* sh, const double (&x)[N], const double (&xl)[N], const double (&xu)[N], const MA& A,
+                                              const double (&g)[N], double delta, double& alpha, double (&s)[N], double (&as)[N],
+                                              bool& as_valid)
+{
+    constexpr int C = EXA_COOP_CHAIN;
+    static_assert(400 % C == 0 && 2 * C + 1 <= 64 && C < 32, "chain length");
+    const double mu0 = 0.01, interpf = 0.1, extrapf = 10.0;
+    const int lane = (int)(threadIdx.x & 63);
+    double dl[N], du[N];
+    EXA_UNROLL
+    for (int i = 0; i < N; i++) {
+        dl[i] = xl[i] - x[i];
+        du[i] = xu[i] - x[i];
+    }
+    const int k = (lane == 0 || lane > 2 * C) ? 0 : (lane <= C ? lane : lane - C);   // the lane's position in its chain
+    const double f = (lane > C) ? extrapf : interpf;
+    constexpr unsigned long long CM = (1ull << C) - 1;
+    bool interp = false;
+    double base = alpha, alphas = alpha, brptmax = 0.0;
+    for (int pass = 0;; pass++) {   // (wave-uniform)
+        double a = base, ap = base;   // the candidate and the one before it in the chain
+        EXA_UNROLL
+        for (int j = 1; j <= C; j++) {
+            const bool on = (j <= k);
+            ap = on ? a : ap;
+            a = on ? f * a : a;
+        }
+        gpstep_d<N>(x, xl, xu, dl, du, -a, g, s);
+        const bool ins = !norm_exceeds<N>(s, delta);
+        double q, gts;
+        quad_model<N>(A, g, s, q, gts, as);
+        const double thr = mu0 * gts;
+        const unsigned long long m_in = __ballot(ins), m_gt = __ballot(q > thr);
+        if (pass == 0) {
+            const unsigned long long m_ge = __ballot(q >= thr);
+            interp = !(m_in & 1ull) || (m_ge & 1ull);
+            if (!interp) {
+                double mg[N];
+                EXA_UNROLL
+                for (int i = 0; i < N; i++) mg[i] = -g[i];
+                double brptmin;
+                breakpt<N>(dl, du, mg, brptmin, brptmax);
+            }
+        }
+        const bool guard_end = (pass + 1) * C >= 400;
+        if (interp) {
+            const unsigned stop = (unsigned)(((m_in & ~m_gt) >> 1) & CM);   // inside the region and q <= mu0 g's
+            if (stop != 0u || guard_end) {
+                const int w = stop ? (__builtin_ctz(stop) + 1) : C;
+                if (lane == w) {
+                    EXA_UNROLL
+                    for (int i = 0; i < N; i++) {
+                        sh[i] = s[i];
+                        sh[N + i] = as[i];
+                    }
+                    sh[2 * N] = a;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                EXA_UNROLL
+                for (int i = 0; i < N; i++) {
+                    s[i] = sh[i];
+                    as[i] = sh[N + i];
+                }
+                alpha = sh[2 * N];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                as_valid = ((m_in >> w) & 1ull) != 0ull;
+                return;
+            }
+            base = lane_value(a, C);
+        } else {
+            const unsigned long long m_lt = __ballot(q < thr), m_val = __ballot(ap <= brptmax);
+            // trip j is made while the search is on and alpha_(j-1) <= brptmax; it ends the search when its step is outside
+            const unsigned end = (unsigned)((~(m_val & m_in) >> (C + 1)) & CM);
+            const int K = end ? (__builtin_ctz(end) + 1) : C + 1;
+            const unsigned lt = (unsigned)(((m_in & m_lt) >> (C + 1)) & ((1ull << (K - 1)) - 1ull));
+            if (lt != 0u) alphas = lane_value(a, C + (32 - __builtin_clz(lt)));
+            if (end != 0u || guard_end) {
+                alpha = alphas;
+                gpstep_d<N>(x, xl, xu, dl, du, -alpha, g, s);
+                as_valid = false;
+                return;
+            }
+            base = lane_value(a, 2 * C);
+        }
+    }
+}
+#endif
+
 template <int N, class ML>
 EXA_HD void trsol_n(const ML& L, const double (&id)[N], double (&r)[N])
 {
@@ -773,10 +881,18 @@ struct TronState {
 };
 
 // dtron, work = COMPUTE: model step from x (f, g, A valid at x).  x becomes the trial point.
-template <int N, class MA, class ML>
+// CLONES (device): the caller is a wavefront whose 64 lanes run the SAME solve; the Cauchy search then evaluates its candidate step
+// lengths side by side (cauchy_clones; search_area: 2 N + 2 doubles of LDS).
+template <int N, bool CLONES = false, class MA, class ML>
 EXA_HD void tron_compute(TronState<N>& st, double (&x)[N], const double (&xl)[N], const double (&xu)[N],
-                         const MA& A, ML& L, const double (&g)[N], double cgtol, int cg_itermax)
+                         const MA& A, ML& L, const double (&g)[N], double cgtol, int cg_itermax, double* search_area = nullptr)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+#define EXA_CAUCHY(...) do { if constexpr (CLONES) cauchy_clones<N>(search_area, __VA_ARGS__); else cauchy<N>(__VA_ARGS__); } while (0)
+#else
+#define EXA_CAUCHY(...) cauchy<N>(__VA_ARGS__)
+    (void)search_area;
+#endif
     st.fc = st.f;
     EXA_UNROLL
     for (int i = 0; i < N; i++) st.xc[i] = x[i];
@@ -784,15 +900,16 @@ EXA_HD void tron_compute(TronState<N>& st, double (&x)[N], const double (&xl)[N]
     bool wa_valid;  // same bits as recomputing them: two of a model step's ~ten matrix-vector products less)
 #if defined(EXA_PROFILE_PHASES)
     unsigned long long c0 = EXA_CLK();
-    cauchy<N>(x, xl, xu, A, g, st.delta, st.alphac, st.s, wa, wa_valid);
+    EXA_CAUCHY(x, xl, xu, A, g, st.delta, st.alphac, st.s, wa, wa_valid);
     unsigned long long c1 = EXA_CLK();
     spcg<N>(x, xl, xu, A, L, g, st.delta, cgtol, st.s, cg_itermax, wa, wa_valid, st.pc);
     st.pc[5] += c1 - c0;
     st.pc[6] += EXA_CLK() - c1;
 #else
-    cauchy<N>(x, xl, xu, A, g, st.delta, st.alphac, st.s, wa, wa_valid);
+    EXA_CAUCHY(x, xl, xu, A, g, st.delta, st.alphac, st.s, wa, wa_valid);
     spcg<N>(x, xl, xu, A, L, g, st.delta, cgtol, st.s, cg_itermax, wa, wa_valid);
 #endif
+#undef EXA_CAUCHY
     st.gts = dot<N>(st.s, g);
     st.prered = -(st.gts + 0.5 * dot<N>(st.s, wa));
 }

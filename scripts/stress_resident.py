@@ -14,7 +14,7 @@ syn = exaadmm_loader.load_submodule("synthetic")
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 
 
-def run(g, rho, two_launch, plan):
+def run(g, rho, two_launch, plan, long_inner=0):
     if two_launch:
         os.environ["EXAADMM_NO_RESIDENT"] = "1"
     else:
@@ -28,7 +28,10 @@ def run(g, rho, two_launch, plan):
         norms, _, _ = mod.run_fixed(K, first_major_iter=it, beta=1e3)
         it += K
         sig.append(norms.tobytes())
-    inner, res = mod.run_inner(2, 90, 1e3)
+    if long_inner:   # a convergence-tested loop that never converges: a SECOND resident launch, which starts with a z / l pass and has heavy wavefronts
+        inner, res = mod.run_inner(1000000, long_inner, 1e3)
+    else:
+        inner, res = mod.run_inner(2, 90, 1e3)
     s = mod.solution
     a, m, t = mod.branch_counters()
     sig += [res.tobytes(), bytes([inner % 256]), s.u_curr.tobytes(), s.v_curr.tobytes(), s.z_curr.tobytes(), s.l_curr.tobytes(),
@@ -46,32 +49,42 @@ cases = [(2, 64, 40, 0, "pegase"), (6, 200, 120, 1, "pegase"), (40, 700, 400, 2,
 for ngen, nline, nbus, seed, cost in cases:
     g = syn.synthetic_grid(ngen, nline, nbus, seed=seed, cost=cost)
     rho = (5e1, 5e3) if cost == "pegase" else (3e2, 3e3)
-    plan = (1, 2, 7, 30)
+    plan = (1, 2, 7, 30, 40, 3, 20)   # (from the loop's 65th iteration on: launches with heavy wavefronts)
     k0, ref = run(g, rho, True, plan)
     k1, first = run(g, rho, False, plan)
     same = (ref == first)
     print("grid %6d branches (seed %d, %s): loop kinds %d / %d, resident == two-launch: %s" % (nline, seed, cost, k0, k1, same), flush=True)
     bad += (not same)
 g = syn.sized_like("case13659pegase", seed=0)
-k0, ref = run(g, (5e1, 5e3), True, (1, 2, 7, 30))
+k0, ref = run(g, (5e1, 5e3), True, (1, 2, 7, 30, 40, 3, 20))
 nbad = 0
 for r in range(reps):
-    _, sig = run(g, (5e1, 5e3), False, (1, 2, 7, 30))
+    _, sig = run(g, (5e1, 5e3), False, (1, 2, 7, 30, 40, 3, 20))
     nbad += (sig != ref)
 print("13 659 buses: %d repetitions of the resident run, %d differ from the two-launch result" % (reps, nbad), flush=True)
 g = syn.sized_like("case1354pegase", seed=0)
-k0, ref = run(g, (1e1, 1e3), True, (1, 2, 7, 30))
+k0, ref = run(g, (1e1, 1e3), True, (1, 2, 7, 30, 40, 3, 20))
 nbad2 = 0
 for r in range(reps):
-    _, sig = run(g, (1e1, 1e3), False, (1, 2, 7, 30))
+    _, sig = run(g, (1e1, 1e3), False, (1, 2, 7, 30, 40, 3, 20))
     nbad2 += (sig != ref)
 print("1 354 buses: %d repetitions of the resident run, %d differ from the two-launch result" % (reps, nbad2), flush=True)
+repsL = max(1, reps // 10)
+for case, rho in (("case1354pegase", (1e1, 1e3)), ("case13659pegase", (5e1, 5e3))):
+    g = syn.sized_like(case, seed=0)
+    k0, ref = run(g, rho, True, (70,), 1040)
+    nb = 0
+    for r in range(repsL):
+        _, sig = run(g, rho, False, (70,), 1040)
+        nb += (sig != ref)
+    print("%s: %d repetitions of a 1 040-iteration inner loop (two resident launches), %d differ from the two-launch result" % (case, repsL, nb), flush=True)
+    nbad2 += nb
 g = syn.sized_like("case_ACTIVSg70k", seed=0)
-k0, ref = run(g, (3e4, 3e5), True, (1, 2, 7, 30))
+k0, ref = run(g, (3e4, 3e5), True, (1, 2, 7, 30, 40, 3, 20))
 nbad3 = 0
 reps3 = max(1, reps // 5)
 for r in range(reps3):
-    _, sig = run(g, (3e4, 3e5), False, (1, 2, 7, 30))
+    _, sig = run(g, (3e4, 3e5), False, (1, 2, 7, 30, 40, 3, 20))
     nbad3 += (sig != ref)
 print("88 207 branches (two tiles per wavefront): %d repetitions of the resident run, %d differ from the two-launch result" % (reps3, nbad3), flush=True)
 print("TOTAL mismatches: %d (%.0f s)" % (bad + nbad + nbad2 + nbad3, time.time() - t0))

@@ -62,7 +62,8 @@ def test_resident_loop_is_bitwise_the_two_launch_loop(pkg, case, rho):
             mod = pkg.ModelAcopf(env)
             assert mod.loop_kind() == (1 if two else 2)
             out, it = [], 1
-            for K in (1, 2, 13, 60, 33):            # odd and even lengths, odd and even starting iterations
+            for K in (1, 2, 13, 60, 33, 2, 5, 40):  # odd and even lengths, odd and even starting iterations; from the loop's 65th
+                                                    # iteration on the launches have heavy wavefronts (kernels.h k_resident_t<1, true>)
                 norms, _, _ = mod.run_fixed(K, first_major_iter=it, beta=1e3)
                 it += K
                 out.append(_state(mod) + [norms.copy()])
@@ -74,6 +75,45 @@ def test_resident_loop_is_bitwise_the_two_launch_loop(pkg, case, rho):
     for a, b in zip(runs[0], runs[1]):
         for x, y in zip(a, b):
             assert np.array_equal(x, y)
+
+
+@pytest.mark.skipif(SWITCHED_OFF or bool(os.environ.get("EXAADMM_NO_HEAVY")), reason="a switch of this run turns the resident loop / its heavy wavefronts off")
+@pytest.mark.parametrize("case,rho", [("case1354pegase", (1e1, 1e3)), ("case13659pegase", (5e1, 5e3))])
+def test_heavy_wavefronts_leave_every_bit_where_the_lanes_leave_it(pkg, case, rho):
+    """Launches that continue an inner loop beyond its 64th iteration give the branches with the most solver trips a wavefront of
+    their own (64 clones, the Cauchy search's candidates side by side; kernels.h k_resident_t<1, true>) -- against the same
+    resident loop without them (EXAADMM_NO_HEAVY=1): fixed-count runs of many lengths, and a convergence-tested loop that needs a
+    second launch (1 024 iterations per launch), everything bitwise equal."""
+    syn = exaadmm_loader.load_submodule("synthetic")
+    g = syn.sized_like(case, seed=0)
+    runs = []
+    for off in (True, False):
+        old = os.environ.get("EXAADMM_NO_HEAVY")
+        if off:
+            os.environ["EXAADMM_NO_HEAVY"] = "1"
+        try:
+            env = pkg.AdmmEnv(case, rho[0], rho[1], verbose=0, grid=g)
+            mod = pkg.ModelAcopf(env)
+            assert mod.loop_kind() == 2
+            out, it = [], 1
+            for K in (70, 1, 2, 3, 4, 5, 8, 31, 64):
+                norms, _, _ = mod.run_fixed(K, first_major_iter=it, beta=1e3)
+                it += K
+                out.append(_state(mod) + [norms.copy()])
+            inner, res = mod.run_inner(1000000, 1100, 1e3)   # (never converges by its test: two launches, the second one with heavy wavefronts)
+            out.append(_state(mod) + [res.copy(), np.array([inner])])
+            assert inner == 1100 and mod.loop_downgrades() == 0
+            runs.append(out)
+            mod.close()
+        finally:
+            if old is None:
+                os.environ.pop("EXAADMM_NO_HEAVY", None)
+            else:
+                os.environ["EXAADMM_NO_HEAVY"] = old
+    for a, b in zip(runs[0], runs[1]):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+    assert runs[0][-2][7].max() >= 3   # (there were branches with three and more trips to take)
 
 
 @pytest.mark.skipif(SWITCHED_OFF, reason="a switch of this run turns the resident loop off")

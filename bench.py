@@ -132,6 +132,51 @@ def cpu_full_solve(grid, params, budget_s=30.0, nthreads=1, outer_lim=20, outer_
             "sample": ("the whole solve" if finished else "the first %d inner iterations of the same solve (%.0f s budget)" % (cumul, budget_s))}
 
 
+def north_star_single(pkg, syn, args, gpu_seconds=2.0):
+    """The N = 1 point of north_star's weak-scaling configuration: ONE area of ACTIVSg70k's size (88 207 branches) on one GPU, same state
+    definition and timing as the headline line (fixed-count regions from the state after --prep iterations, median), bounded to a few
+    seconds of GPU time.  `bench.py --gpus N` carries the N-area value of the same workload in the same field."""
+    import torch
+    case = "case_ACTIVSg70k"
+    params = CASE_PARAMS[case]
+    t_all = time.perf_counter()
+    grid = syn.sized_like(case, seed=0)
+    env = pkg.AdmmEnv(case, params["rho_pq"], params["rho_va"], tight_factor=0.99, gpu_no=0, verbose=0, grid=grid)
+    mod = pkg.ModelAcopf(env)
+    env.params.scale = params["scale"]
+    mod.sync_params()
+    beta = env.params.initial_beta
+    mod.run_fixed(args.prep + args.warmup, first_major_iter=1, beta=beta) if args.prep + args.warmup > 0 else None
+    mod.state_save()
+    first = args.prep + args.warmup + 1
+
+    def region():
+        mod.state_restore()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        mod.run_fixed(args.steps, first_major_iter=first, beta=beta)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    regions = [region()]
+    for _ in range(max(0, min(2000, int(round(gpu_seconds / max(regions[0], 1e-6)))) - 1)):
+        regions.append(region())
+    dt = sorted(regions)[len(regions) // 2]
+    form = mod.resident_form()
+    G, L, B = int(grid["ngen"]), int(grid["nline"]), int(grid["nbus"])
+    its = args.steps / dt
+    out = {"metric": "ADMM inner iterations/sec", "value": its, "unit": "iterations/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": 1e3 * dt / args.steps, "scaling": "weak", "repeats": len(regions),
+           "config": {"workload": "synthetic-%s-sized" % case, "ngen": G, "nline": L, "nbus": B, "rho_pq": params["rho_pq"], "rho_va": params["rho_va"],
+                      "scale": params["scale"], "parallelism": "1 GPU", "resident_form": form, "loop_kind": mod.loop_kind()},
+           "roofline": {"bound": "hbm", "iteration_bytes": BYTES_PER_ITER(G, L, B), "iteration_frac": BYTES_PER_ITER(G, L, B) * its / 1e9 / HBM_PEAK_GBS},
+           "selfchecks": mod.resident_selfchecks(), "loop_downgrades": mod.loop_downgrades(),
+           "seconds_for_this_leg": None}
+    mod.close()
+    out["seconds_for_this_leg"] = time.perf_counter() - t_all
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -159,6 +204,14 @@ def main():
                          "driver's utilisation sampling to see them)")
     ap.add_argument("--periods", type=int, default=1,
                     help="T > 1: multi-period ACOPF (SURVEY.md §8 f4) over T load levels of the same grid, one time-expanded device model")
+    ap.add_argument("--no-north-star", action="store_true",
+                    help="skip the `north_star_scaling` block of the line (areas of ACTIVSg70k's size, north_star's weak-scaling configuration: "
+                         "one area on one GPU at N = 1, N areas over N GPUs otherwise; bounded to about a minute)")
+    ap.add_argument("--attempt-budget", type=float, default=240.0,
+                    help="N > 1: seconds a measuring child process may take before its supervisor ends it and starts the next, more "
+                         "conservative mode of the distributed loop (exaadmm.jl_amd/bench_supervisor.py)")
+    ap.add_argument("--north-star-budget", type=float, default=150.0, help="N > 1: the same for the north_star_scaling leg")
+    ap.add_argument("--leg", default="main", help=argparse.SUPPRESS)   # set by the supervisor for its children
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -180,6 +233,28 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d; launch with --nproc-per-node equal to --gpus" % (args.gpus, world))
     if args.gpus > 1 or world > 1 or args.force_dist:
         import exaadmm_loader
+        if os.environ.get("EXAADMM_BENCH_CHILD") != "1":
+            # This process -- one per rank, started by the launcher -- only SUPERVISES: it never touches the GPU, runs the measurement in a
+            # child process, ends a child that hangs or fails together with its peers' and starts fresh children in the next, more
+            # conservative mode of the distributed loop (graph -> direct -> one stream -> Python twin -> gloo); rank 0 prints the line of
+            # the first attempt that completes on every rank, with `attempts` and the `north_star_scaling` leg (N areas of ACTIVSg70k's size).
+            sup = exaadmm_loader.load_submodule("bench_supervisor")
+            legs = [{"name": "main", "budget_s": args.attempt_budget}]
+            if not args.no_north_star and args.case != "case_ACTIVSg70k" and args.periods == 1:
+                legs.append({"name": "north_star_scaling", "budget_s": args.north_star_budget})
+            me = os.path.abspath(__file__)
+
+            def make_cmd(leg):
+                cmd = [sys.executable, me] + sys.argv[1:]
+                if leg["name"] == "north_star_scaling":
+                    cmd += ["--case", "case_ACTIVSg70k", "--scaling", "weak", "--leg", "north_star_scaling", "--no-cpu-baseline"]
+                return cmd
+
+            line, rc = sup.supervise(make_cmd, rank, world, local_rank, legs, budget_s=args.attempt_budget)
+            if rank == 0 and line is not None:
+                sys.stdout.flush()
+                print(json.dumps(line), flush=True)
+            raise SystemExit(rc)
         dist_mod = exaadmm_loader.load_submodule("distributed")
         return dist_mod.bench_main(args, rank, world, local_rank)
 
@@ -267,6 +342,11 @@ def main():
     _, _, ms_branch = mod.run_fixed(args.steps, first_major_iter=done + 1, beta=beta, time_branch=True)
     torch.cuda.synchronize()
     dt_with_events = time.perf_counter() - t1
+    # what that run launched, as the library decided it (exaadmm_resident_form): tiles per resident wavefront, heavy wavefronts
+    form = mod.resident_form() if T == 1 else {"tiles": 0, "heavy": 0, "launches": 0, "wavefronts": 0}
+    # the largest number of solver-loop trips any branch made in the last x-update of that run: the launch is its slowest branch
+    # (roofline.critical_path below)
+    max_trips = int(mod.branch_counters()[2].max()) if T == 1 else None
 
     its = args.steps / dt
     if T > 1:
@@ -277,14 +357,14 @@ def main():
     # HBM traffic of the dominant kernel: rocprofv3 --pmc passes of THIS command (scripts/collect_pmc.sh; bench.py itself
     # cannot collect counters), summarised per workload in profiles/r03_pmc_summary.json together with the version string
     # of the library they were taken from.  An entry taken from other code than the library loaded now is refused.
-    traffic = valu_busy = None
+    traffic = valu_busy = insts_per_trip = None
     # which loop ran: 2 = the resident loop (ONE launch for the K steps of a region: branch solves, bus updates by the last lane
     # to arrive, residual sums and stop test inside; the figures below are per ITERATION of that launch), 1 = two launches per iteration
-    resident = (T == 1 and hasattr(mod, "loop_kind") and mod.loop_kind() == 2)
+    resident = (T == 1 and form["tiles"] > 0)
     lib_version = pkg.library().exaadmm_version().decode()
-    pmc_file = os.path.join("profiles", "r04_pmc_summary.json")
+    pmc_file = os.path.join("profiles", "r05_pmc_summary.json")
     if not os.path.exists(os.path.join(ROOT, pmc_file)):
-        pmc_file = os.path.join("profiles", "r03_pmc_summary.json")
+        pmc_file = os.path.join("profiles", "r04_pmc_summary.json")
     traffic_source = "none: %s has no entry for this workload" % pmc_file
     try:
         pmc = json.load(open(os.path.join(ROOT, pmc_file)))
@@ -293,16 +373,16 @@ def main():
             traffic_source = "refused: %s was collected with %r, the loaded library is %r" % (pmc_file, pmc.get("library_version"), lib_version)
         elif kb:
             traffic, valu_busy = kb.get("traffic_bytes"), kb.get("valu_busy")
+            insts_per_trip = kb.get("valu_insts_per_wave_trip")
             traffic_source = "%s (library %s, repository commit %s)" % (pmc_file, pmc.get("library_version"), pmc.get("commit"))
     except Exception as e:
         traffic_source = "none: %s unreadable (%s)" % (pmc_file, e)
     occ = mod.branch_kernel_occupancy() if hasattr(mod, "branch_kernel_occupancy") else None
     # registers / spills / LDS of the dominant kernel, from the remarks of the library's own compile (csrc/Makefile ->
     # exaadmm.jl_amd/kernel_resources.json, which carries the digest of the sources it belongs to)
-    # which form of the resident kernel the timed regions ran (the library's own rule, exaadmm_hip.hip enqueue_resident: two tiles per
-    # wavefront above the chip's SIMD count; heavy wavefronts for launches that continue an inner loop beyond its 64th iteration)
-    two_tile = (L + 63) // 64 + (G + 63) // 64 + 1 > 1016
-    heavy = bool(resident and not two_tile and T == 1 and args.prep + args.warmup >= 64 and not os.environ.get("EXAADMM_NO_HEAVY"))
+    # which form of the resident kernel ran: asked from the library (exaadmm_resident_form), not re-derived here
+    two_tile = form["tiles"] == 2
+    heavy = form["heavy"] > 0
     kernel_resources = None
     try:
         kr = json.load(open(os.path.join(ROOT, "exaadmm.jl_amd", "kernel_resources.json")))
@@ -311,7 +391,7 @@ def main():
     except Exception:
         pass
     branch_bytes = BYTES_PER_BRANCH_SOLVE * L
-    fused_zl = (not os.environ.get("EXAADMM_NO_SPEC") and os.environ.get("EXAADMM_BUS_KERNEL") != "lane" and (T == 1 or not os.environ.get("EXAADMM_MP_NO_SPEC")))
+    fused_zl = mod.loop_kind() >= 1
     if fused_zl:
         # the launch also carries the generator update (128 B per generator) and the z / l / residual pass of the previous
         # iteration; of the latter only what the branch loads do not already bring counts: lz read + z, z_prev, l writes
@@ -320,6 +400,26 @@ def main():
     if resident:
         branch_bytes = float(BYTES_PER_ITER(G, L, B))   # the launch does whole iterations
     achieved = branch_bytes / (ms_branch * 1e-3) / 1e9
+    # The roofline that BINDS at the named sizes.  The launch is its slowest branch: a chain of `max_trips` solver
+    # trips, each a dependent sequence of wave64 instructions -- a SIMD issues one FP64 instruction of a wavefront per 4 clocks whatever
+    # the number of active lanes -- so per iteration the launch cannot take less than
+    #     max_trips x (VALU instructions of one wavefront per solver trip) x 4 clocks / shader clock.
+    # instructions per trip: SQ_INSTS_VALU of the kernel / the wavefronts' trips, from the rocprofv3 --pmc pass summarised in
+    # profiles/r05_pmc_summary.json (scripts/summarize_pmc.py); shader clock: the device's (hipDeviceProp clockRate).
+    critical = None
+    if T == 1 and max_trips:
+        try:
+            clk_khz = float(torch.cuda.get_device_properties(0).clock_rate)
+        except Exception:
+            clk_khz = 2.4e6
+        if insts_per_trip:
+            floor_ms = max_trips * insts_per_trip * 4.0 / (clk_khz * 1e3) * 1e3
+            critical = {"bound": "fp64-issue chain of the slowest branch", "max_solver_trips": max_trips, "valu_insts_per_wave_trip": insts_per_trip,
+                        "clocks_per_instruction": 4, "shader_clock_mhz": clk_khz / 1e3, "floor_ms": floor_ms, "kernel_ms": ms_branch,
+                        "frac": floor_ms / ms_branch, "definition": "max_solver_trips x valu_insts_per_wave_trip x 4 clocks / shader clock, over kernel_ms (per iteration)"}
+        else:
+            critical = {"max_solver_trips": max_trips, "shader_clock_mhz": clk_khz / 1e3, "frac": None,
+                        "note": "no valu_insts_per_wave_trip for this workload / library in " + pmc_file}
     out = {
         "metric": "ADMM inner iterations/sec", "value": its, "unit": "iterations/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -348,13 +448,20 @@ def main():
                      # HBM is the wrong roof at the named sizes (state is Infinity-Cache resident, the kernel is the FP64
                      # dependent-issue chain of its slowest lane): occupancy and VALU utilisation say how it is bound
                      "waves_per_simd": occ, "waves_launched_per_simd": ((L + 63) // 64) / 1024.0,
-                     "kernel_resources": kernel_resources,
+                     "kernel_resources": kernel_resources, "resident_form": form, "critical_path": critical,
                      "valu_busy": valu_busy, "traffic_source": traffic_source, "library_version": lib_version,
                      "note": "latency/FP64-issue bound: state is Infinity-Cache resident; traffic / valu_busy come from the "
                              "rocprofv3 --pmc passes of this command (traffic_source); see DESIGN.md"},
         "solver": {"avg_auglag_it": a_it, "avg_tron_minor_it": m_it, "primres": float(norms[0]),
                    "device_ms_total": ms_total, "ms_per_step_with_kernel_events": 1e3 * dt_with_events / args.steps},
     }
+    out["solver"]["resident_selfchecks"] = list(mod.resident_selfchecks()) if T == 1 else None
+    out["solver"]["loop_downgrades"] = mod.loop_downgrades() if T == 1 else None
+    if T == 1 and not args.no_north_star and args.case != "case_ACTIVSg70k":
+        try:
+            out["north_star_scaling"] = north_star_single(pkg, syn, args)
+        except Exception as e:   # never lose the line over an extra
+            out["north_star_scaling"] = {"error": repr(e)}
     if not args.no_full_solve and T == 1:
         # the reference's own definition of the metric (print_statistics.jl:12): cumul / time_overall of a whole
         # solve_acopf with the README settings (outer 20, inner 1000, early breaks active; timer scope

@@ -172,6 +172,13 @@ def library():
     L.exaadmm_branch_kernel_occupancy.argtypes = [H, C.POINTER(C.c_int)]
     L.exaadmm_loop_kind.argtypes = [H, C.POINTER(C.c_int)]
     L.exaadmm_loop_downgrades.argtypes = [H, C.POINTER(C.c_int)]
+    L.exaadmm_resident_form.argtypes = [H, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.exaadmm_resident_selfcheck_stats.argtypes = [H, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.exaadmm_set_option.argtypes = [H, C.c_char_p, C.c_int64]
+    L.exaadmm_get_option.argtypes = [H, C.c_char_p, C.POINTER(C.c_int64)]
+    L.exaadmm_dist_set_rccl_library.argtypes = [C.c_char_p]
+    if hasattr(L, "exaadmm_test_hook"):   # the test build only (libexaadmm_hip_hooks.so, -DEXA_TEST_HOOKS)
+        L.exaadmm_test_hook.argtypes = [H, C.c_char_p, C.c_int64]
     L.exaadmm_run_inner.argtypes = [H, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int), c_double_p]
     L.exaadmm_solve_two_level.argtypes = [H, C.POINTER(Info)]
     L.exaadmm_run_fixed.argtypes = [H, C.c_int, C.c_int, C.c_double, c_double_p, c_double_p, c_double_p]
@@ -211,7 +218,90 @@ def library():
     L.exaadmm_case_grid.argtypes = [C.c_void_p, C.POINTER(Grid)]
     L.exaadmm_case_free.argtypes = [C.c_void_p]
     _LIB = L
+    # a site's own communication library / the tests' in-process stand-in (the library itself reads no environment variable)
+    if os.environ.get("EXAADMM_RCCL_LIB"):
+        _check_rc(L, L.exaadmm_dist_set_rccl_library(os.fsencode(os.environ["EXAADMM_RCCL_LIB"])), "exaadmm_dist_set_rccl_library")
     return L
+
+
+def _check_rc(L, rc, what):
+    if rc != 0:
+        raise ExaAdmmError("%s failed (status %d): %s" % (what, rc, L.exaadmm_last_error().decode()))
+
+
+# Options of a handle (include/exaadmm_hip.h, exaadmm_set_option) taken from the ENVIRONMENT -- a convenience of this host-side mirror
+# for A/B runs of the tests, the benchmark and the scripts (`EXAADMM_NO_RESIDENT=1 python bench.py`); the library itself reads none of
+# them.  (variable, option, value when the variable is set -- None: int(the variable's value)).  EXAADMM_OPT_<KEY>=<int> sets any option.
+_ENV_OPTIONS = (("EXAADMM_BUS_KERNEL", "bus_kernel_lane", lambda v: 1 if v == "lane" else 0), ("EXAADMM_NO_GRAPH", "graph", 0),
+                ("EXAADMM_NO_SPEC", "spec", 0), ("EXAADMM_MP_NO_SPEC", "mp_spec", 0), ("EXAADMM_NO_REC", "rec", 0),
+                ("EXAADMM_NO_RESIDENT", "resident", 0), ("EXAADMM_RESIDENT", "resident", None), ("EXAADMM_RESIDENT_TILES", "resident_tiles", None),
+                ("EXAADMM_RESIDENT_COOP", "resident_coop", None), ("EXAADMM_NO_HEAVY", "heavy", 0), ("EXAADMM_HEAVY_FROM", "heavy_from", None),
+                ("EXAADMM_DIST_OVERLAP", "dist_overlap", None), ("EXAADMM_DIST_GRAPH", "dist_graph", None),
+                ("EXAADMM_TRUST_RESIDENT", "trust_resident", None), ("EXAADMM_VERBOSE", "verbose", 1), ("EXAADMM_PROF_RESIDENT", "prof_resident", 1))
+_OPTION_DEFAULTS = {"bus_kernel_lane": 0, "graph": 1, "spec": 1, "mp_spec": 1, "rec": 1, "resident": 1, "resident_tiles": 1, "resident_coop": 1,
+                    "heavy": 1, "heavy_from": 64, "dist_overlap": 1, "dist_graph": 1, "trust_resident": 0, "verbose": 0, "prof_resident": 0}
+
+
+def options_from_environment(environ=None):
+    """the options the environment asks for (everything else at its default)"""
+    environ = os.environ if environ is None else environ
+    want = dict(_OPTION_DEFAULTS)
+    for var, key, val in _ENV_OPTIONS:
+        v = environ.get(var)
+        if v is None or v == "":
+            continue
+        want[key] = val(v) if callable(val) else (int(v) if val is None else val)
+    for var, v in environ.items():
+        if var.startswith("EXAADMM_OPT_") and v != "":
+            want[var[len("EXAADMM_OPT_"):].lower()] = int(v)
+    return want
+
+
+class _HandleOptions:
+    """mixin of the model classes: exaadmm_set_option / exaadmm_get_option, and the environment's switches applied to the handle
+    when the model is CREATED (apply_env_options() re-reads them on demand; set_option is the direct way)"""
+    _opt_applied = None
+
+    def set_option(self, key, value):
+        _check(library().exaadmm_set_option(self._h, key.encode(), int(value)), "exaadmm_set_option(%s)" % key)
+
+    def get_option(self, key):
+        v = C.c_int64()
+        _check(library().exaadmm_get_option(self._h, key.encode(), C.byref(v)), "exaadmm_get_option(%s)" % key)
+        return v.value
+
+    def apply_env_options(self):
+        want = options_from_environment()
+        hook = os.environ.get("EXAADMM_RESIDENT_TEST_FAIL", "")
+        sig = (tuple(sorted(want.items())), hook)
+        if sig == self._opt_applied:
+            return
+        for k, v in want.items():
+            self.set_option(k, v)
+        if hook != "" or (self._opt_applied is not None and self._opt_applied[1] != ""):
+            L = library()
+            if not hasattr(L, "exaadmm_test_hook"):
+                raise ExaAdmmError("EXAADMM_RESIDENT_TEST_FAIL needs the test build of the library (libexaadmm_hip_hooks.so, EXAADMM_HIP_LIB)")
+            _check(L.exaadmm_test_hook(self._h, b"fail_resident_launch", int(hook or 0)), "exaadmm_test_hook")
+        self._opt_applied = sig
+
+    def test_hook(self, key, value):
+        L = library()
+        if not hasattr(L, "exaadmm_test_hook"):
+            raise ExaAdmmError("test hooks exist only in the test build of the library (libexaadmm_hip_hooks.so, EXAADMM_HIP_LIB)")
+        _check(L.exaadmm_test_hook(self._h, key.encode(), int(value)), "exaadmm_test_hook(%s)" % key)
+
+    def resident_form(self):
+        """what the last loop call launched, as the library decided it: dict(tiles, heavy, launches, wavefronts); tiles = 0: not the resident loop"""
+        t, hv, n, w = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        _check(library().exaadmm_resident_form(self._h, C.byref(t), C.byref(hv), C.byref(n), C.byref(w)), "exaadmm_resident_form")
+        return {"tiles": t.value, "heavy": hv.value, "launches": n.value, "wavefronts": w.value}
+
+    def resident_selfchecks(self):
+        """(self checks made, self checks that found a difference) of the resident loops on this handle"""
+        a, b = C.c_int(), C.c_int()
+        _check(library().exaadmm_resident_selfcheck_stats(self._h, C.byref(a), C.byref(b)), "exaadmm_resident_selfcheck_stats")
+        return a.value, b.value
 
 
 def _check(rc, what):
@@ -309,7 +399,7 @@ class Solution:
             object.__setattr__(self, name, value)
 
 
-class ModelAcopf:
+class ModelAcopf(_HandleOptions):
     """ModelAcopf (models/acopf/acopf_model.jl:6-95) living on one MI355X."""
 
     def __init__(self, env):
@@ -330,6 +420,7 @@ class ModelAcopf:
             setattr(cg, k, g[k].ctypes.data_as(c_i64_p))
         self._h = C.c_void_p()
         _check(L.exaadmm_create(C.byref(cg), C.byref(env.params), env.gpu_no, C.byref(self._h)), "exaadmm_create")
+        self.apply_env_options()
         _check(L.exaadmm_init_solution(self._h, env.initial_rho_pq, env.initial_rho_va), "exaadmm_init_solution")
         self.info = Info()
         self.solution = Solution(self)
@@ -689,7 +780,7 @@ class _Period:
         self.gen_start, self.line_start = 1, 2 * mp.ngen + 1
 
 
-class ModelMpacopf:
+class ModelMpacopf(_HandleOptions):
     """ModelMpacopf (models/mpacopf/mpacopf_model.jl:40-112) on one MI355X: one time-expanded device
     model (include/exaadmm_hip.h, exaadmm_mp_create).  `load` = (pd, qd), nbus x T matrices as
     returned by get_load; periods start_period..end_period (1-based, inclusive) are used.
@@ -718,6 +809,7 @@ class ModelMpacopf:
         self._h = C.c_void_p()
         _check(L.exaadmm_mp_create(C.byref(cg), C.byref(env.params), T, _dp(self._pd), _dp(self._qd), self.ramp_ratio,
                                    env.gpu_no, C.byref(self._h)), "exaadmm_mp_create")
+        self.apply_env_options()
         _check(L.exaadmm_init_solution(self._h, env.initial_rho_pq, env.initial_rho_va), "exaadmm_init_solution")
         self.nvar = int(L.exaadmm_mp_nvar(self._h))              # mod.nvar of the reference
         self.nvar_expanded = int(L.exaadmm_nvar(self._h))        # length of the device vectors

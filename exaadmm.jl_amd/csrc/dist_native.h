@@ -68,7 +68,22 @@ struct exaadmm_dist {
 
 static RcclApi g_rccl;   // process-wide function table
 static std::string g_rccl_path;
+static std::string g_rccl_override;   // exaadmm_dist_set_rccl_library: tried first
 static std::mutex g_rccl_mutex;   // handles may be attached from different host threads
+
+// Which communication library to bind instead of the librccl next to the HIP runtime (a site's own build; the tests' in-process
+// stand-in).  Process-wide and only before the first bind: the function table is shared by every handle.
+extern "C" int exaadmm_dist_set_rccl_library(const char* path)
+{
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    const std::string want = path ? path : "";
+    if (g_rccl.lib && want != g_rccl_override) {
+        set_err("a communication library is already bound (%s): set the override before the first attach", g_rccl_path.c_str());
+        return EXAADMM_ERR_INVALID;
+    }
+    g_rccl_override = want;
+    return EXAADMM_OK;
+}
 
 // which RCCL the library bound (empty before the first exaadmm_dist_unique_id / multi-rank exaadmm_dist_prepare)
 extern "C" const char* exaadmm_dist_rccl_path(void) { return g_rccl_path.c_str(); }
@@ -78,7 +93,7 @@ static int rccl_bind(RcclApi* out)
     std::lock_guard<std::mutex> lock(g_rccl_mutex);
     if (!g_rccl.lib) {
         std::vector<std::string> names;
-        if (const char* e = getenv("EXAADMM_RCCL_LIB")) names.push_back(e);
+        if (!g_rccl_override.empty()) names.push_back(g_rccl_override);
         Dl_info info;
         if (dladdr((void*)&hipGetDeviceCount, &info) && info.dli_fname) {   // directory of the HIP runtime in use
             std::string dir(info.dli_fname);
@@ -99,7 +114,7 @@ static int rccl_bind(RcclApi* out)
                 break;
             }
         if (!lib) {
-            set_err("RCCL not found next to the HIP runtime (set EXAADMM_RCCL_LIB): %s", dlerror());
+            set_err("RCCL not found next to the HIP runtime (exaadmm_dist_set_rccl_library names another one): %s", dlerror());
             return EXAADMM_ERR_INVALID;
         }
         RcclApi b;
@@ -400,7 +415,11 @@ static int dist_exchange(exaadmm_handle* h, const Dev& dv, bool with_v, Ctrl* c,
         set_err("halo exchange failed: %s", d->api.GetErrorString(bad != ncclSuccess ? bad : ge));
         return EXAADMM_ERR_HIP;
     }
-    g_exchanges++;
+    {   // (counted when it is enqueued to run: a captured exchange runs -- and is counted, dist_count_batch -- with every replay of its graph)
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs == hipStreamCaptureStatusNone) g_exchanges++;
+        (void)hipGetLastError();
+    }
     const int nc = with_v ? d->n_cut : 0;
     hipLaunchKernelGGL(k_halo_unpack, grid_for(std::max(nc, 1), 256), dim3(256), 0, stream, dv, d->d_rcode, d->d_rpos, nc, c, out, sums_mode);
     return 0;
@@ -422,9 +441,8 @@ static int dist_exchange(exaadmm_handle* h, const Dev& dv, bool with_v, Ctrl* c,
 static int enqueue_dist_iterations(exaadmm_handle* h, Ctrl* c, int j0, int n, bool first_of_loop, hipEvent_t* bev)
 {
     exaadmm_dist* d = h->dist;
-    // EXAADMM_DIST_OVERLAP=0 (A/B switch): everything on ONE stream, in the same order -- same results, the exchange fully exposed
-    const char* sw = getenv("EXAADMM_DIST_OVERLAP");
-    const bool overlap = (sw == nullptr || atoi(sw) != 0);
+    // option "dist_overlap" = 0 (A/B switch): everything on ONE stream, in the same order -- same results, the exchange fully exposed
+    const bool overlap = h->opt.dist_overlap != 0;
     hipStream_t M = h->stream, X = overlap ? d->xstream : h->stream;
     const int nb = branch_blocks(h), ng = gen_blocks(h), nbi = interior_blocks(h), nbus = (int)grid_for(h->B, BUS_BLOCK / BUS_W).x;
     while ((int)d->ev.size() < 2 * n + 2) {
@@ -432,10 +450,12 @@ static int enqueue_dist_iterations(exaadmm_handle* h, Ctrl* c, int j0, int n, bo
         HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         d->ev.push_back(e);
     }
+    // (bev: exaadmm_run_fixed's ms_branch -- the INTERIOR launch only; the cut launch runs beside it on the exchange stream.  The pair is
+    //  recorded for every iteration, also when a partition has no whole interior block and no generators: an empty interval)
     auto launch_int = [&](int j) {
-        if (nbi + ng <= 0) return;
         if (bev) (void)hipEventRecord(bev[2 * (j - j0)], M);
-        hipLaunchKernelGGL((k_branch_t<false, true>), dim3(nbi + ng), dim3(BR_BLOCK), 0, M, h->d_dspec[j % 3][1], h->bo, h->par.scale, 0, c, ng, j, h->baseMVA);
+        if (nbi + ng > 0)
+            hipLaunchKernelGGL((k_branch_t<false, true>), dim3(nbi + ng), dim3(BR_BLOCK), 0, M, h->d_dspec[j % 3][1], h->bo, h->par.scale, 0, c, ng, j, h->baseMVA);
         if (bev) (void)hipEventRecord(bev[2 * (j - j0) + 1], M);
     };
     auto launch_cut = [&](int j) {
@@ -496,8 +516,9 @@ static int dist_probe(exaadmm_handle* h)
 {
     exaadmm_dist* d = h->dist;
     d->graph_ok = false;
-    d->probe_result = 0;
+    d->probe_result = -1;   // not run (one rank / no communicator)
     if (d->nranks <= 1 || d->comm == nullptr) return EXAADMM_OK;
+    d->probe_result = 0;
     hipStream_t X = d->xstream;
     const double mine[4] = {1.0 * (d->rank + 1), 2.0 * (d->rank + 1), 3.0 * (d->rank + 1), 4.0 * (d->rank + 1)};
     const double tri = 0.5 * d->nranks * (d->nranks + 1);
@@ -529,8 +550,7 @@ static int dist_probe(exaadmm_handle* h)
     if ((rc = one())) return rc;
     if ((rc = verify("direct"))) return rc;
     hipGraphExec_t exec = nullptr;
-    const char* sw = getenv("EXAADMM_DIST_GRAPH");   // (=0: A/B switch, every batch enqueued directly)
-    const bool want = h->use_graph && (sw == nullptr || atoi(sw) != 0);
+    const bool want = h->use_graph && h->opt.dist_graph != 0;   // (option "dist_graph" = 0: A/B switch, every batch enqueued directly)
     if (want && hipStreamBeginCapture(X, hipStreamCaptureModeThreadLocal) == hipSuccess) {
         const int crc = one();
         hipGraph_t g = nullptr;

@@ -65,8 +65,19 @@ struct HaloSlot {
 struct exaadmm_dist;   // RCCL communicator + halo buffers of a partition (dist_native.h)
 extern "C" int exaadmm_dist_detach(exaadmm_handle* h);
 
+// A/B switches and diagnostics of a handle (exaadmm_set_option; include/exaadmm_hip.h lists them).  The library reads no
+// environment variable of its own: a host that wants its switches from the environment translates them.
+struct Options {
+    int bus_kernel_lane = 0, graph = 1, spec = 1, mp_spec = 1, rec = 1;
+    int resident = 1, resident_tiles = 1, resident_coop = 1, heavy = 1, heavy_from = 64;
+    int dist_overlap = 1, dist_graph = 1;
+    int trust_resident = 0, verbose = 0;
+    int prof_resident = 0;   // diagnostic build (-DEXA_PROFILE_PHASES): phase clocks of the resident loop's lanes instead of k_branch_t's timelines
+};
+
 struct exaadmm_handle {
     exaadmm_dist* dist = nullptr;
+    Options opt;
     int device = 0;
     int G = 0, L = 0, B = 0, Gp = 0, Lp = 0, N = 0;
     int64_t nvar = 0;
@@ -137,6 +148,20 @@ struct exaadmm_handle {
     int resident_launches = 0;
     bool resident_zeroed = false;   // the hand-over words were reset by the call's opening launch (k_loop_begin)
     bool resident_coop = false;
+    // what the last loop call launched (exaadmm_resident_form) and the first-use self checks (exaadmm_resident_selfcheck_stats)
+    int form_tiles = 0, form_heavy = 0, form_launches = 0, form_grid = 0;
+    bool checked_resident = false, checked_heavy = false, in_selfcheck = false;
+    bool force_two_launch = false;   // self check: the comparison leg runs the two-launch loop on a handle that is resident-eligible
+    int force_heavy = -1;            // self check: -1 the library's own rule, 0 / 1 the kernel form the checked call used
+    unsigned form_used = 0;          // kernel forms the current call launched: bit 0 plain / two-tile, bit 1 heavy
+    int selfchecks = 0, selfcheck_mismatches = 0;
+    std::vector<void*> chk_e, chk_r; // self check: the iterate the checked call produced / what the resident leg made of it
+    unsigned long long* d_chk_diff = nullptr;
+    double* rec_alloc = nullptr;     // the pushed-records buffer (d.rec points at it unless option "rec" = 0)
+#if defined(EXA_TEST_HOOKS)
+    int hook_fail_launch = 0;        // test build only: the n-th resident launch of the handle reports a failed wait
+    int hook_flip_ulp = 0;           // test build only: the next resident launch's result gets one ulp added to one u entry
+#endif
     int resident_cap2 = -1;      // the same for k_resident_t<2> (two tiles of 64 branches per wavefront)
     ResidentTiles rtiles = {nullptr, 0, 0, 0, 0};
     ResidentHeavy rheavy = {nullptr, nullptr, nullptr, nullptr, 0};   // heavy wavefronts of the resident launch (kernels.h); n = 0: none
@@ -411,7 +436,12 @@ extern "C" int exaadmm_create(const exaadmm_grid* g, const exaadmm_params* p, in
         // in front of the first cut branch can start its next solve without waiting for the peers' halo (split launches)
         const int64_t la = g->nline_owned > 0 ? g->nline_owned : g->nline;
         std::vector<char> in_fr(h->L, 0), in_to(h->L, 0);
-        // (the CSR arrays are validated further down, by build_csr: no more than nline entries are looked at here)
+        // (the CSR arrays are validated in full further down, by build_csr; here: present, and no more than nline entries are looked at)
+        if (!(g->FrStart && g->FrIdx && g->ToStart && g->ToIdx && g->GenStart && (g->ngen == 0 || g->GenIdx) && g->brBusIdx)) {
+            set_err("null CSR / bus index array");
+            delete h;
+            return EXAADMM_ERR_INVALID;
+        }
         const int64_t nfr = std::min<int64_t>(std::max<int64_t>(g->FrStart[h->B] - g->index_base, 0), h->L);
         const int64_t nto = std::min<int64_t>(std::max<int64_t>(g->ToStart[h->B] - g->index_base, 0), h->L);
         for (int64_t k = 0; k < nfr; k++) {
@@ -453,13 +483,11 @@ extern "C" int exaadmm_create(const exaadmm_grid* g, const exaadmm_params* p, in
         return EXAADMM_ERR_HIP;
     }
     h->stream = h->own_stream;
-    {
-        const char* e = getenv("EXAADMM_BUS_KERNEL");
-        h->bus_lane_kernel = (e != nullptr && strcmp(e, "lane") == 0);
-        h->use_graph = (getenv("EXAADMM_NO_GRAPH") == nullptr);
-        // speculative two-launch loop (A/B switch; needs the lane-group bus kernel, which carries the reduction block)
-        h->spec_on = (getenv("EXAADMM_NO_SPEC") == nullptr) && !h->bus_lane_kernel;
-    }
+    // (defaults of the options: lane-group bus kernel, hipGraph batches, speculative two-launch loop -- which needs the lane-group
+    //  bus kernel: it carries the reduction block; exaadmm_set_option changes them)
+    h->bus_lane_kernel = false;
+    h->use_graph = true;
+    h->spec_on = true;
     TRY(upload_mupow_table());
 
     double** svecs[] = {&d.u, &d.v, &d.z, &d.zp, &d.l, &d.lz, &d.rho, &d.rp, &d.rd, &d.ax};
@@ -590,7 +618,7 @@ extern "C" int exaadmm_create(const exaadmm_grid* g, const exaadmm_params* p, in
             d.EndCount = dcn;
             // "push" records of the fused loop (kernels.h, Dev::rec): where every generator / branch end drops what the bus
             // update needs from it.  Component k of bus I: slot 8 I + k, from the 9th component on 8 B + (position in EndCode)
-            if (getenv("EXAADMM_NO_REC") == nullptr) {   // (A/B switch: the fused loop then gathers like the step-wise path)
+            {   // (option "rec" = 0, A/B switch: the fused loop then gathers like the step-wise path)
                 std::vector<int> rbr(2 * (size_t)h->Lp, -1), rgen(h->Gp, -1);
                 for (int I = 0; I < h->B; I++)
                     for (int k = 0; k < cnt[I]; k++) {
@@ -613,6 +641,7 @@ extern "C" int exaadmm_create(const exaadmm_grid* g, const exaadmm_params* p, in
                 d.rec_br = drb;
                 d.rec_gen = drg;
                 d.rec = drec;
+                h->rec_alloc = drec;
                 // resident loop: per branch (SoA index) its two buses and their counts, per generator its bus
                 std::vector<int> bb4(4 * (size_t)h->Lp, 0), gb2(2 * (size_t)h->Gp, 0);
                 bool all_local = true;
@@ -1415,8 +1444,8 @@ extern "C" int exaadmm_debug_wave_timeline(exaadmm_handle* h, unsigned long long
 // every cut branch + this rank's four residual sums -> grouped ncclSend / ncclRecv -> k_halo_unpack (scatter, add the
 // sums in rank order, advance the loop control).  The loop test of iteration k is known one launch late; the iterate is
 // double-buffered by iteration parity so that the stopping iteration's state survives its speculative successor.
-// (EXAADMM_MP_NO_SPEC=1: A/B switch, the multi-period model keeps the four-launch loop)
-static bool spec_eligible(const exaadmm_handle* h) { return h->spec_on && !h->ctrl_mode && (h->T == 1 || getenv("EXAADMM_MP_NO_SPEC") == nullptr); }
+// (option "mp_spec" = 0: A/B switch, the multi-period model keeps the four-launch loop)
+static bool spec_eligible(const exaadmm_handle* h) { return h->spec_on && !h->ctrl_mode && (h->T == 1 || h->opt.mp_spec != 0); }
 
 // resident loop: every wavefront of the launch must hold a SIMD for the whole launch (one wavefront per SIMD)
 static int resident_capacity(exaadmm_handle* h)
@@ -1438,10 +1467,9 @@ static int resident_capacity(exaadmm_handle* h)
         }
         (void)hipGetLastError();
         // a cooperative launch makes the runtime check co-residency against its own occupancy figure and refuse what does
-        // not fit (A/B switch EXAADMM_RESIDENT_COOP=0: plain launch; measured in profiles/r04_resident_hardening.txt)
+        // not fit (A/B switch, option "resident_coop" = 0: plain launch; measured in profiles/r04_resident_hardening.txt)
         int coop = 0;
-        const char* e = getenv("EXAADMM_RESIDENT_COOP");
-        h->resident_coop = (e == nullptr || atoi(e) != 0) &&
+        h->resident_coop = h->opt.resident_coop != 0 &&
                            hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, h->device) == hipSuccess && coop != 0;
         (void)hipGetLastError();
     }
@@ -1505,6 +1533,7 @@ static int resident_guard(exaadmm_handle* h, bool restore, const Ctrl* begin = n
         c.dst[q] = (unsigned long long*)(restore ? prim[q] : h->guard[q]);
         c.words[q] = (unsigned int)(q < 5 ? h->N : (q < 8 ? h->Lp : h->Lp / 2));
     }
+    if (!restore && h->in_selfcheck) c.n = 0;   // (a leg of the self check: the guard keeps the iterate of the call that is being checked)
     if (begin != nullptr || !restore) {
         // the snapshot rides in the call's first launch, with the reset of the hand-over words and (run_fixed) the control block
         const ResidentSync& r = h->rsync;
@@ -1579,8 +1608,10 @@ static int enqueue_resident(exaadmm_handle* h, int n, int loop_iter0)
         HIPCHK(hipMemsetAsync(h->rsync.arrive, 0, (2 * (size_t)h->B + 3) * sizeof(int), h->stream));
     h->resident_zeroed = false;
     h->resident_launches += 1;
-    if (const char* e = getenv("EXAADMM_RESIDENT_TEST_FAIL"))   // tests: the n-th resident launch of a handle reports a failed wait
-        if (atoi(e) == h->resident_launches) HIPCHK(hipMemsetAsync(h->rsync.fail, 0x01, 1, h->stream));
+#if defined(EXA_TEST_HOOKS)
+    // test build only (exaadmm_test_hook "fail_resident_launch"): the n-th resident launch of a handle reports a failed wait
+    if (h->hook_fail_launch != 0 && h->hook_fail_launch == h->resident_launches) HIPCHK(hipMemsetAsync(h->rsync.fail, 0x01, 1, h->stream));
+#endif
     const int mode = resident_mode(h);
     int grid = nb + ng + 1;
     if (mode == 2) {
@@ -1597,13 +1628,19 @@ static int enqueue_resident(exaadmm_handle* h, int n, int loop_iter0)
     // are chosen from the trip counters of the iterations before the launch, and at the start of an inner loop (the penalties
     // restart, the slowest branch changes from iteration to iteration) those say nothing -- a launch from there runs the kernel
     // without them (profiles/r04_heavy_wavefronts.txt: +8.6 % in the steady state, -2.7 % over a whole solve if always on).
-    if (mode == 1 && loop_iter0 >= 64 && h->heavy_max > 0 && getenv("EXAADMM_NO_HEAVY") == nullptr) {
+    const bool heavy_rule = (h->force_heavy >= 0) ? (h->force_heavy != 0) : (loop_iter0 >= h->opt.heavy_from && h->opt.heavy != 0);
+    if (mode == 1 && heavy_rule && h->heavy_max > 0) {
         // which branches get a wavefront of their own in this launch: from the solver-trip counters of the last x-updates (both buffer sets)
         rh.n = h->heavy_max;
         hipLaunchKernelGGL(k_heavy_select, dim3(1), dim3(1024), 0, h->stream, (const int*)h->sets[0].st[2], (const int*)h->sets[1].st[2], h->L, h->Lp, rh.n,
                            const_cast<int*>(rh.list), const_cast<int*>(rh.flag), (const double*)h->d.z, (const double*)h->d.l, 2 * h->Gp, const_cast<double*>(rh.init));
         grid += rh.n;
     }
+    h->form_tiles = mode;
+    h->form_heavy = rh.n;
+    h->form_grid = grid;
+    h->form_launches += 1;
+    h->form_used |= (rh.n > 0) ? 2u : 1u;
     if (h->resident_coop) {
         const Dev *d0 = h->d_dspec[0][0], *d1 = h->d_dspec[1][0];
         double scale = h->par.scale, base = h->baseMVA;
@@ -1631,17 +1668,14 @@ static int enqueue_resident(exaadmm_handle* h, int n, int loop_iter0)
 static int resident_mode(exaadmm_handle* h)
 {
 #if defined(EXA_PROFILE_PHASES)
-    // (the diagnostic build's per-wavefront timelines belong to k_branch_t; EXAADMM_PROF_RESIDENT=1: phase clocks of the resident loop's lanes)
-    if (getenv("EXAADMM_PROF_RESIDENT") == nullptr) return 0;
+    // (the diagnostic build's per-wavefront timelines belong to k_branch_t; option "prof_resident" = 1: phase clocks of the resident loop's lanes)
+    if (h->opt.prof_resident == 0) return 0;
 #endif
-    if (getenv("EXAADMM_NO_RESIDENT") != nullptr) return 0;
-    if (const char* e = getenv("EXAADMM_RESIDENT"))
-        if (atoi(e) == 0) return 0;
-    if (!(h->resident_ok && h->T == 1 && h->resident_downgrades == 0 && spec_eligible(h) && !dist_has_peers(h) && h->stream == h->own_stream)) return 0;
+    if (h->opt.resident == 0 || h->force_two_launch) return 0;
+    if (!(h->resident_ok && h->d.rec != nullptr && h->T == 1 && h->resident_downgrades == 0 && spec_eligible(h) && !dist_has_peers(h) && h->stream == h->own_stream)) return 0;
     const int nb = branch_blocks(h), ng = gen_blocks(h);
     if (nb + ng + 1 <= resident_capacity(h)) return 1;
-    if (const char* e = getenv("EXAADMM_RESIDENT_TILES"))
-        if (atoi(e) == 0) return 0;
+    if (h->opt.resident_tiles == 0) return 0;
     const int wg = (ng + 1) / 2, wb = h->resident_cap2 - wg - 1;
     return (wb > 0 && nb > wb && nb <= 2 * wb) ? 2 : 0;
 }
@@ -1665,7 +1699,7 @@ static int resident_downgrade(exaadmm_handle* h)
     if ((rc = sync_check(h, true))) return rc;
     if ((rc = resident_guard(h, true))) return rc;
     h->resident_downgrades += 1;
-    if (getenv("EXAADMM_VERBOSE") != nullptr)
+    if (h->opt.verbose != 0)
         fprintf(stderr, "exaadmm: resident loop not co-resident on device %d (shared GPU?): batch repeated with the two-launch loop\n", h->device);
     return sync_check(h, true);
 }
@@ -1916,6 +1950,8 @@ static bool dist_batch_graph(exaadmm_handle* h)
     return true;
 }
 
+static int resident_selfcheck(exaadmm_handle* h, int next_major_iter, double beta);
+
 static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
 {
     int rc = spec_prepare(h);
@@ -2001,6 +2037,22 @@ static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
         }
         if (hc->done) break;   // (a partition: every rank sees the same sums, added in the same order -> the same decision)
     }
+    if (!downgrade) {
+        if (!completed) {
+            if ((rc = spec_complete_last(h, enq))) return rc;
+            HIPCHK(hipMemcpyAsync(hc, h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
+            if ((rc = sync_check(h, true))) return rc;
+        }
+        if ((rc = spec_finish(h, hc->inner))) return rc;
+        if (resident && h->form_used != 0) {
+            // first use of a resident kernel form on this handle: the loop's result is only returned once 8 more iterations from it
+            // came out bit for bit the same with the resident and with the two-launch loop (resident_selfcheck)
+            if ((rc = sync_check(h, true))) return rc;
+            const int verdict = resident_selfcheck(h, hc->inner + 1, hc->beta);
+            if (verdict < 0) return verdict;
+            downgrade = verdict > 0;
+        }
+    }
     if (downgrade) {
         // the inner loop starts over from the iterate it was entered with, on the two-launch loop (same results, bit for bit:
         // tests/test_gpu_resident.py); the handle keeps that loop
@@ -2010,12 +2062,6 @@ static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
         HIPCHK(hipStreamSynchronize(h->stream));
         return run_inner_spec(h, max_inner, hc);
     }
-    if (!completed) {
-        if ((rc = spec_complete_last(h, enq))) return rc;
-        HIPCHK(hipMemcpyAsync(hc, h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
-        if ((rc = sync_check(h, true))) return rc;
-    }
-    if ((rc = spec_finish(h, hc->inner))) return rc;
     for (int q = 0; q < 3; q++) h->acc_ms[q] += (double)ms_sample[q] * hc->inner;
     return 0;
 }
@@ -2057,6 +2103,8 @@ extern "C" int exaadmm_run_inner(exaadmm_handle* h, int outer, int max_inner, do
     REQUIRE(h && outer >= 1 && max_inner >= 1, "bad argument");
     HIPCHK(hipSetDevice(h->device));
     REQUIRE(!dist_has_peers(h) || spec_eligible(h), "a partition with peers runs the speculative loop only (single-period model, EXAADMM_NO_SPEC / EXAADMM_BUS_KERNEL unset)");
+    h->form_tiles = h->form_heavy = h->form_launches = h->form_grid = 0;
+    h->form_used = 0;
     Ctrl* hc = h->h_ctrl;
     memset(hc, 0, sizeof(Ctrl));
     hc->max_inner = max_inner;
@@ -2188,11 +2236,34 @@ extern "C" int exaadmm_solve_two_level(exaadmm_handle* h, exaadmm_info* out)
     return EXAADMM_OK;
 }
 
+static int run_fixed_impl(exaadmm_handle* h, int iters, int first_major_iter, double beta, double out[4], double* ms_total, double* ms_branch);
+
 extern "C" int exaadmm_run_fixed(exaadmm_handle* h, int iters, int first_major_iter, double beta, double out[4],
                                  double* ms_total, double* ms_branch)
 {
     REQUIRE(h && iters >= 1 && first_major_iter >= 1, "bad argument");
     HIPCHK(hipSetDevice(h->device));
+    h->form_tiles = h->form_heavy = h->form_launches = h->form_grid = 0;
+    h->form_used = 0;
+    int rc = run_fixed_impl(h, iters, first_major_iter, beta, out, ms_total, ms_branch);
+    if (rc) return rc < 0 ? rc : EXAADMM_ERR_HIP;
+    if (h->form_used != 0) {   // first use of a resident kernel form on this handle (resident_selfcheck)
+        const int verdict = resident_selfcheck(h, first_major_iter + iters, beta);
+        if (verdict < 0) return verdict;
+        if (verdict > 0) {
+            // the resident loop did not reproduce the two-launch loop on this device: the call's own result is not returned either --
+            // back to the iterate it was entered with, and once more with the two-launch loop (which the handle keeps)
+            if ((rc = resident_downgrade(h))) return rc;
+            rc = run_fixed_impl(h, iters, first_major_iter, beta, out, ms_total, ms_branch);
+            if (rc) return rc < 0 ? rc : EXAADMM_ERR_HIP;
+        }
+    }
+    return EXAADMM_OK;
+}
+
+// returns 0, a negative status, or (a leg of the self check only) 1: the resident launch reported a failed wait / was refused
+static int run_fixed_impl(exaadmm_handle* h, int iters, int first_major_iter, double beta, double out[4], double* ms_total, double* ms_branch)
+{
     REQUIRE(!dist_has_peers(h) || spec_eligible(h), "a partition with peers runs the speculative loop only");
     const bool time_branch = (ms_branch != nullptr);
     const size_t need = 2 + (time_branch ? 2 * (size_t)iters : 0);
@@ -2249,6 +2320,7 @@ extern "C" int exaadmm_run_fixed(exaadmm_handle* h, int iters, int first_major_i
                 for (int i = 0; i < iters; i++)
                     if ((rc = enqueue_iteration_spec(h, h->d_ctrl, i, false, time_branch ? &h->ev[2 + 2 * i] : nullptr))) return rc;
             if (resident && refused) {   // the runtime says the grid is not co-resident
+                if (h->in_selfcheck) return 1;
                 if ((rc = resident_downgrade(h))) return rc;
                 continue;
             }
@@ -2263,6 +2335,7 @@ extern "C" int exaadmm_run_fixed(exaadmm_handle* h, int iters, int first_major_i
             if (resident && resident_failed(h)) {
                 // a batch that was not co-resident is not a state of the algorithm: back to the iterate the call was entered
                 // with, and once more with the two-launch loop (resident_eligible is false from here on)
+                if (h->in_selfcheck) return 1;
                 if ((rc = resident_downgrade(h))) return rc;
                 continue;
             }
@@ -2316,6 +2389,240 @@ extern "C" int exaadmm_run_fixed(exaadmm_handle* h, int iters, int first_major_i
     }
     return EXAADMM_OK;
 }
+
+// ------------------------------------------------------------------ first-use self check of the resident loops
+// The resident kernels hand values from wavefront to wavefront across XCDs; that this works rests on hardware behaviour (sc1
+// accesses are performed at the device's coherence point), and round 4 met three silent races there that only bitwise
+// comparisons found.  So nothing a resident kernel form has produced on a handle is returned before the form has reproduced the
+// two-launch loop ON THIS HANDLE: at the end of the first call that used a form (plain / two-tile: bit 0, heavy wavefronts: bit 1),
+// from the iterate E that call produced,
+//     E -> SELFCHECK_ITERS iterations, resident loop (the same form)   -> R
+//     E -> SELFCHECK_ITERS iterations, two launches per iteration      -> T
+// and R, T are compared on the device, word by word: u, v, z, z_prev, l, the line-limit multipliers and penalty, the per-branch
+// counters; the four norms on the host, bit for bit.  E is restored.  Returns 0 = equal (the form is marked checked), 1 = a
+// difference or a failed leg -- the caller restores the iterate its call STARTED from (the guard snapshot, which the legs leave alone)
+// and repeats the call with the two-launch loop, which the handle keeps --, < 0 = error.  Cost: 2 x 8 iterations + four copy launches,
+// ~1 ms at 13 659 buses, once per form and handle.  Option "trust_resident" = 1 skips it.
+constexpr int SELFCHECK_ITERS = 8;
+
+__global__ void k_compare_list(CopyList c, unsigned long long* __restrict__ ndiff)
+{
+    for (int q = 0; q < c.n; q++) {
+        unsigned long long cnt = 0;
+        for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < c.words[q]; i += gridDim.x * blockDim.x) cnt += (c.dst[q][i] != c.src[q][i]) ? 1ull : 0ull;
+        if (cnt) atomicAdd(&ndiff[q], cnt);
+    }
+}
+#if defined(EXA_TEST_HOOKS)
+__global__ void k_flip_ulp(double* p) { *reinterpret_cast<unsigned long long*>(p) += 1ull; }
+#endif
+
+static const char* const SELFCHECK_NAMES[12] = {"u", "v", "z", "z_prev", "l", "line-limit multiplier 1", "line-limit multiplier 2", "penalty",
+                                               "auglag counters", "minor-iteration counters", "solver-trip counters", "solver-trip counters (other set)"};
+
+// the iterate (+ counters) <-> a snapshot set; cmp != nullptr: compare instead of copying
+static int selfcheck_list(exaadmm_handle* h, std::vector<void*>& store, int mode /* 0 save, 1 restore, 2 compare */)
+{
+    int rc;
+    if (store.empty()) {
+        for (int q = 0; q < 12; q++) {
+            if (q < 8) {
+                double* p = nullptr;
+                if ((rc = dev_alloc(h, &p, q < 5 ? (size_t)h->N : (size_t)h->Lp))) return rc;
+                store.push_back(p);
+            } else {
+                int* p = nullptr;
+                if ((rc = dev_alloc(h, &p, (size_t)h->Lp))) return rc;
+                store.push_back(p);
+            }
+        }
+    }
+    void* prim[12] = {h->d.u, h->d.v, h->d.z, h->d.zp, h->d.l, h->d.ls1, h->d.ls2, h->d.mu, h->d.st_auglag, h->d.st_minor, h->d.st_ticks, h->sets[0].st[2]};
+    CopyList c;
+    c.n = 12;
+    for (int q = 0; q < 12; q++) {
+        c.src[q] = (const unsigned long long*)(mode == 1 ? store[q] : prim[q]);
+        c.dst[q] = (unsigned long long*)(mode == 1 ? prim[q] : store[q]);
+        c.words[q] = (unsigned int)(q < 5 ? h->N : (q < 8 ? h->Lp : h->Lp / 2));
+    }
+    const dim3 grid(std::min(1024, std::max(1, h->N / 256)));
+    if (mode == 2) {
+        HIPCHK(hipMemsetAsync(h->d_chk_diff, 0, 12 * sizeof(unsigned long long), h->stream));
+        hipLaunchKernelGGL(k_compare_list, grid, dim3(256), 0, h->stream, c, h->d_chk_diff);
+    } else
+        hipLaunchKernelGGL(k_copy_list, grid, dim3(256), 0, h->stream, c);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int resident_selfcheck(exaadmm_handle* h, int next_major_iter, double beta)
+{
+    const unsigned used = h->form_used;
+    h->form_used = 0;
+    if (h->in_selfcheck || h->opt.trust_resident != 0 || h->nsets != 2) return 0;
+    const unsigned todo = used & ~((h->checked_resident ? 1u : 0u) | (h->checked_heavy ? 2u : 0u));
+    if (todo == 0) return 0;
+    int rc;
+    if (!h->d_chk_diff && (rc = dev_alloc(h, &h->d_chk_diff, 12))) return rc;
+    std::vector<void*>&e_set = h->chk_e, &r_set = h->chk_r;
+    const Ctrl keep = *h->h_ctrl;   // (the caller reads its loop's outcome from the pinned block after we return)
+    const int form_keep[4] = {h->form_tiles, h->form_heavy, h->form_launches, h->form_grid};
+    h->in_selfcheck = true;
+    int verdict = 0;
+    std::string what;
+    if ((rc = selfcheck_list(h, e_set, 0))) goto out_rc;
+    for (int form = 0; form < 2 && verdict == 0; form++) {
+        if (!(todo & (1u << form))) continue;
+        double nr[4] = {0, 0, 0, 0}, nt[4] = {0, 0, 0, 0};
+        h->force_heavy = form;
+        rc = run_fixed_impl(h, SELFCHECK_ITERS, next_major_iter, beta, nr, nullptr, nullptr);
+        h->force_heavy = -1;
+        if (rc < 0) goto out_rc;
+        h->selfchecks += 1;
+        if (rc > 0) {   // the leg itself met a failed wait / a refused launch
+            verdict = 1;
+            what = "the resident leg of the self check was not co-resident";
+        }
+#if defined(EXA_TEST_HOOKS)
+        if (verdict == 0 && h->hook_flip_ulp != 0) {   // test build only: one ulp on one word of the resident leg's result
+            h->hook_flip_ulp = 0;
+            hipLaunchKernelGGL(k_flip_ulp, dim3(1), dim3(1), 0, h->stream, h->d.u + 2 * h->Gp + std::min(h->L - 1, 17));
+        }
+#endif
+        if (verdict == 0) {
+            if ((rc = selfcheck_list(h, r_set, 0))) goto out_rc;
+            if ((rc = selfcheck_list(h, e_set, 1))) goto out_rc;
+            h->force_two_launch = true;
+            rc = run_fixed_impl(h, SELFCHECK_ITERS, next_major_iter, beta, nt, nullptr, nullptr);
+            h->force_two_launch = false;
+            if (rc) { rc = rc < 0 ? rc : EXAADMM_ERR_HIP; goto out_rc; }
+            if ((rc = selfcheck_list(h, r_set, 2))) goto out_rc;
+            unsigned long long nd[12];
+            if (hipMemcpyAsync(nd, h->d_chk_diff, sizeof(nd), hipMemcpyDeviceToHost, h->stream) != hipSuccess) {
+                set_err("self check: download of the comparison failed");
+                rc = EXAADMM_ERR_HIP;
+                goto out_rc;
+            }
+            if ((rc = sync_check(h, true))) goto out_rc;
+            char buf[160];
+            for (int q = 0; q < 12; q++)
+                if (nd[q] != 0) {
+                    snprintf(buf, sizeof(buf), "%s%s: %llu word(s)", what.empty() ? "" : ", ", SELFCHECK_NAMES[q], nd[q]);
+                    what += buf;
+                }
+            if (memcmp(nr, nt, sizeof(nr)) != 0) what += what.empty() ? "the residual norms" : ", the residual norms";
+            if (!what.empty()) verdict = 1;
+        }
+        if ((rc = selfcheck_list(h, e_set, 1))) goto out_rc;
+        if ((rc = sync_check(h, true))) goto out_rc;
+        if (verdict == 0) (form == 0 ? h->checked_resident : h->checked_heavy) = true;
+    }
+    rc = 0;
+out_rc:
+    h->in_selfcheck = false;
+    h->force_heavy = -1;
+    h->force_two_launch = false;
+    *h->h_ctrl = keep;
+    h->form_tiles = form_keep[0]; h->form_heavy = form_keep[1]; h->form_launches = form_keep[2]; h->form_grid = form_keep[3];
+    if (rc) return rc;
+    if (verdict != 0) {
+        h->selfcheck_mismatches += 1;
+        set_err("resident loop self check: after %d iterations from the same iterate the resident loop and the two-launch loop differ in %s; "
+                "the handle keeps the two-launch loop", SELFCHECK_ITERS, what.c_str());
+        if (h->opt.verbose != 0) fprintf(stderr, "exaadmm: %s\n", g_err.c_str());
+    }
+    return verdict;
+}
+
+extern "C" int exaadmm_resident_selfcheck_stats(exaadmm_handle* h, int* checks, int* mismatches)
+{
+    REQUIRE(h, "null handle");
+    if (checks) *checks = h->selfchecks;
+    if (mismatches) *mismatches = h->selfcheck_mismatches;
+    return EXAADMM_OK;
+}
+
+extern "C" int exaadmm_resident_form(exaadmm_handle* h, int* tiles, int* heavy, int* launches, int* wavefronts)
+{
+    REQUIRE(h, "null handle");
+    if (tiles) *tiles = h->form_launches > 0 ? h->form_tiles : 0;
+    if (heavy) *heavy = h->form_launches > 0 ? h->form_heavy : 0;
+    if (launches) *launches = h->form_launches;
+    if (wavefronts) *wavefronts = h->form_launches > 0 ? h->form_grid : 0;
+    return EXAADMM_OK;
+}
+
+// ------------------------------------------------------------------ options
+namespace {
+struct OptKey {
+    const char* name;
+    int Options::*field;
+    int lo, hi;
+};
+const OptKey OPT_KEYS[] = {
+    {"bus_kernel_lane", &Options::bus_kernel_lane, 0, 1}, {"graph", &Options::graph, 0, 1}, {"spec", &Options::spec, 0, 1},
+    {"mp_spec", &Options::mp_spec, 0, 1}, {"rec", &Options::rec, 0, 1}, {"resident", &Options::resident, 0, 1},
+    {"resident_tiles", &Options::resident_tiles, 0, 1}, {"resident_coop", &Options::resident_coop, 0, 1}, {"heavy", &Options::heavy, 0, 1},
+    {"heavy_from", &Options::heavy_from, 0, 1 << 30}, {"dist_overlap", &Options::dist_overlap, 0, 1}, {"dist_graph", &Options::dist_graph, 0, 1},
+    {"trust_resident", &Options::trust_resident, 0, 1}, {"verbose", &Options::verbose, 0, 1}, {"prof_resident", &Options::prof_resident, 0, 1},
+};
+}  // namespace
+
+extern "C" int exaadmm_set_option(exaadmm_handle* h, const char* key, int64_t value)
+{
+    REQUIRE(h && key, "null argument");
+    for (const OptKey& k : OPT_KEYS) {
+        if (strcmp(k.name, key) != 0) continue;
+        if (value < k.lo || value > k.hi) {
+            set_err("option %s: value %lld out of range [%d, %d]", key, (long long)value, k.lo, k.hi);
+            return EXAADMM_ERR_INVALID;
+        }
+        if (h->opt.*(k.field) == (int)value) return EXAADMM_OK;
+        HIPCHK(hipSetDevice(h->device));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->opt.*(k.field) = (int)value;
+        // what the options feed: the bus kernel / loop selection, the records pointer inside every Dev copy, the graphs that bake them in
+        h->bus_lane_kernel = h->opt.bus_kernel_lane != 0;
+        h->use_graph = h->opt.graph != 0;
+        h->spec_on = h->opt.spec != 0 && !h->bus_lane_kernel;   // (the speculative loop needs the lane-group bus kernel: it carries the reduction block)
+        h->d.rec = h->opt.rec != 0 ? h->rec_alloc : nullptr;
+        h->dev_dirty = true;
+        h->resident_cap = -1;   // (resident_coop is looked at when the capacity is computed)
+        invalidate_graph(h);
+        return EXAADMM_OK;
+    }
+    set_err("unknown option %s", key);
+    return EXAADMM_ERR_INVALID;
+}
+
+extern "C" int exaadmm_get_option(exaadmm_handle* h, const char* key, int64_t* value)
+{
+    REQUIRE(h && key && value, "null argument");
+    for (const OptKey& k : OPT_KEYS)
+        if (strcmp(k.name, key) == 0) {
+            *value = h->opt.*(k.field);
+            return EXAADMM_OK;
+        }
+    set_err("unknown option %s", key);
+    return EXAADMM_ERR_INVALID;
+}
+
+#if defined(EXA_TEST_HOOKS)
+// Test build only (csrc/Makefile: libexaadmm_hip_hooks.so, -DEXA_TEST_HOOKS): fault injection for tests/test_gpu_resident.py.
+//   "fail_resident_launch" n : the n-th resident launch of the handle reports a failed wait (0: off)
+//   "flip_resident_ulp" 1    : the resident leg of the next self check gets one ulp added to one word of u
+extern "C" int exaadmm_test_hook(exaadmm_handle* h, const char* key, int64_t value)
+{
+    REQUIRE(h && key, "null argument");
+    if (strcmp(key, "fail_resident_launch") == 0) h->hook_fail_launch = (int)value;
+    else if (strcmp(key, "flip_resident_ulp") == 0) h->hook_flip_ulp = (int)value;
+    else {
+        set_err("unknown test hook %s", key);
+        return EXAADMM_ERR_INVALID;
+    }
+    return EXAADMM_OK;
+}
+#endif
 
 // ------------------------------------------------------------------ device-side snapshot of the iterate
 // exaadmm_state_save keeps a copy of everything an inner iteration reads and writes (u, v, z, z_prev, l, lz, the

@@ -530,13 +530,30 @@ def bench_main(args, rank, world, local_rank):
     import bench as B
 
     torch.cuda.set_device(local_rank)
+    # tests of the supervisor (bench_supervisor.py): "hang:<attempt>" / "fail:<attempt>" -- this child, having touched the GPU, never
+    # answers / exits non-zero in that attempt
+    inject = os.environ.get("EXAADMM_BENCH_INJECT", "")
+    if inject and inject.split(":")[1] == os.environ.get("EXAADMM_BENCH_ATTEMPT", "0"):
+        torch.zeros(8, device="cuda").sum().item()
+        if inject.startswith("hang"):
+            while True:
+                time.sleep(1.0)
+        raise SystemExit(3)
+    # python-gloo mode of the supervisor: no RCCL anywhere, device tensors staged through the host
+    backend = os.environ.get("EXAADMM_BENCH_BACKEND", "nccl")
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", str(rank))
         os.environ.setdefault("WORLD_SIZE", str(world))
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     world = dist.get_world_size()
+    red_dev = "cpu" if dist.get_backend() == "gloo" else "cuda"   # where the job's scalar reductions live
+    leg = getattr(args, "leg", "main")
+    light = (leg != "main")   # an extra leg of the line (north_star_scaling): bounded to about a minute, no CPU baseline
     params = B.CASE_PARAMS[args.case]
     g0, l0, b0 = syn.CASE_SIZES[args.case]
     sharded = (getattr(args, "scaling", "weak") == "strong")
@@ -551,7 +568,7 @@ def bench_main(args, rank, world, local_rank):
     be = HipBackend(pkg, part, params["rho_pq"], params["rho_va"], params={"scale": params["scale"]}, device_index=local_rank)
     be.mod.sync_params()
     model = DistributedAcopf(part, be, dist, st, dict(DEFAULT_PAR))
-    native = os.environ.get("EXAADMM_DIST_PYTHON_LOOP") is None
+    native = os.environ.get("EXAADMM_DIST_PYTHON_LOOP") is None and dist.get_backend() != "gloo"
     if native:
         native = bool(be.attach_native(dist))
     beta = DEFAULT_PAR["initial_beta"]
@@ -574,8 +591,7 @@ def bench_main(args, rank, world, local_rank):
         m._exchange(m.buf_send_v, m.buf_recv_v, p.plan_send_v[2], p.plan_recv_v[2])
         bk.unpack(1, m.buf_recv_v)
         sums = bk.update_zl_partial(beta)
-        if world > 1:
-            dist.all_reduce(sums)
+        m._all_reduce(sums)
 
     prep = max(0, getattr(args, "prep", 0))     # untimed preparation iterations that define the benchmark state
     run(prep, 1)
@@ -599,7 +615,7 @@ def bench_main(args, rank, world, local_rank):
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
-        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.cpu()[0])
 
@@ -607,7 +623,8 @@ def bench_main(args, rank, world, local_rank):
     regions = [region()]
     exch2 = int(be.lib.exaadmm_dist_exchange_count())
     want = getattr(args, "repeats", 0)
-    repeats = 1 if (want == 1 or not can_snapshot) else (want if want > 1 else max(1, min(4000, int(round(getattr(args, "gpu_seconds", 1.0) / max(regions[0], 1e-6))))))
+    gpu_seconds = min(2.0, getattr(args, "gpu_seconds", 1.0)) if light else getattr(args, "gpu_seconds", 1.0)
+    repeats = 1 if (want == 1 or not can_snapshot) else (want if want > 1 else max(1, min(4000, int(round(gpu_seconds / max(regions[0], 1e-6))))))
     for _ in range(repeats - 1):       # (the same count on every rank: regions[0] is the all-reduced maximum)
         regions.append(region())
     dt = sorted(regions)[len(regions) // 2]
@@ -615,7 +632,7 @@ def bench_main(args, rank, world, local_rank):
         res, _ = be.run_fixed_native(1, prep + args.warmup + args.steps + 1, beta)     # norms of one more iteration
     else:
         res = torch.sqrt(be.sums).cpu().numpy()
-    cuts = torch.tensor([part.n_cut, part.n_native], dtype=torch.float64, device="cuda")
+    cuts = torch.tensor([part.n_cut, part.n_native], dtype=torch.float64, device=red_dev)
     dist.all_reduce(cuts)
     # what the in-library loop did: ranks of the communicator as RCCL counts them, RCCL version, duration of the sampled exchanges
     # (grouped send / receive + unpack kernel, HIP events on the exchange stream), batches replayed from a hipGraph / enqueued directly
@@ -625,7 +642,7 @@ def bench_main(args, rank, world, local_rank):
         n_, v_, gb_, db_, pr_ = C.c_int(), C.c_int(), C.c_int64(), C.c_int64(), C.c_int()
         us_ = C.c_double()
         pkg._check(be.lib.exaadmm_dist_stats(be.mod.handle, C.byref(n_), C.byref(v_), C.byref(us_), C.byref(gb_), C.byref(db_), C.byref(pr_)), "exaadmm_dist_stats")
-        xs = torch.tensor([us_.value], dtype=torch.float64, device="cuda")
+        xs = torch.tensor([us_.value], dtype=torch.float64, device=red_dev)
         dist.all_reduce(xs, op=dist.ReduceOp.MAX)
         exchange_us = float(xs.cpu()[0]) or None
         rccl = {"nranks": n_.value, "version": v_.value, "path": be.lib.exaadmm_dist_rccl_path().decode(),
@@ -638,17 +655,16 @@ def bench_main(args, rank, world, local_rank):
     cpu_base = None
     if rank == 0 and (world > 1 or getattr(args, "force_dist", False)):
         try:
-            old = os.environ.get("EXAADMM_NO_RESIDENT")
-            os.environ["EXAADMM_NO_RESIDENT"] = "1"
             g1 = syn.sized_like(args.case, seed=0)
             env1 = pkg.AdmmEnv(args.case, params["rho_pq"], params["rho_va"], gpu_no=local_rank, verbose=0, grid=g1)
             m1 = pkg.ModelAcopf(env1)
+            m1.set_option("resident", 0)
             env1.params.scale = params["scale"]
             m1.sync_params()
             m1.run_fixed(prep + args.warmup, first_major_iter=1, beta=beta)
             m1.state_save()
             ts = []
-            for _ in range(30):
+            for _ in range(10 if light else 30):
                 m1.state_restore()
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
@@ -656,13 +672,9 @@ def bench_main(args, rank, world, local_rank):
                 torch.cuda.synchronize()
                 ts.append(time.perf_counter() - t0)
             n1_same_loop = {"iterations_per_s": args.steps / sorted(ts)[len(ts) // 2], "loop_kind": m1.loop_kind(),
-                            "what": "one case-sized area on one GPU, two launches per iteration (EXAADMM_NO_RESIDENT=1), same state, median of 30 regions"}
+                            "what": "one case-sized area on one GPU, two launches per iteration (option resident = 0), same state, median of %d regions" % len(ts)}
             m1.close()
-            if old is None:
-                os.environ.pop("EXAADMM_NO_RESIDENT", None)
-            else:
-                os.environ["EXAADMM_NO_RESIDENT"] = old
-            if not getattr(args, "no_cpu_baseline", False):
+            if not getattr(args, "no_cpu_baseline", False) and not light:
                 cpu_base = B.cpu_baseline(g1, params, budget_s=10.0, prep=min(prep, 100))
                 cpu_base["sample"] += " -- ONE case-sized area (what one GPU of the job iterates on)"
         except Exception as e:   # never lose the line over the extras
@@ -697,7 +709,8 @@ def bench_main(args, rank, world, local_rank):
                        "loop": "inside the library, RCCL from C++ (dist_native.h)" if native else "step-wise twin: Python-driven steps + torch collectives",
                        "exchanges_per_iteration_rank0": (exch2 - exch1) / float(max(args.steps, 1)) if native else None,
                        "overlap": "exchange + cut-branch solves on a second stream beside the interior branch solves of the next iteration"
-                                  if os.environ.get("EXAADMM_DIST_OVERLAP", "1") != "0" else "off (EXAADMM_DIST_OVERLAP=0): one stream",
+                                  if be.mod.get_option("dist_overlap") else "off (option dist_overlap = 0): one stream",
+                       "collectives": dist.get_backend(),
                        "parallelism": "bus/branch partition x%d (breadth-first bus ranges); cut branches solved on both owners; per "
                                       "iteration ONE grouped ncclSend/ncclRecv per peer (4 v entries per cut branch + 4 residual sums), "
                                       "sums added in rank order, no all-reduce" % world},

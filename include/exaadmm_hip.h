@@ -155,7 +155,7 @@ int exaadmm_download_branch_counters(exaadmm_handle *h, int32_t *auglag_it, int3
 int exaadmm_branch_kernel_occupancy(exaadmm_handle *h, int *waves_per_simd);
 /* which form of the inner loop exaadmm_run_inner / _run_fixed / _solve_two_level use on this handle (diagnostic):
  * 0 = four launches per iteration, 1 = two launches per iteration (speculative loop), 2 = resident loop (one launch per
- * batch of iterations, every wavefront resident; EXAADMM_NO_RESIDENT=1 selects 1) */
+ * batch of iterations, every wavefront resident; option "resident" = 0 selects 1) */
 int exaadmm_loop_kind(exaadmm_handle *h, int *kind);
 /* The resident loop needs every wavefront of its launch on the chip at once.  When that turns out not to hold (the GPU is
  * shared with other work: a capped wait inside the launch reports it, or the runtime refuses the cooperative launch) the
@@ -163,6 +163,41 @@ int exaadmm_loop_kind(exaadmm_handle *h, int *kind);
  * have returned -- the reference's loop cannot fail there either (admm_two_level.jl:34-63); the handle then stays on
  * that loop.  count = how often that has happened on this handle (0 or 1). */
 int exaadmm_loop_downgrades(exaadmm_handle *h, int *count);
+/* What the LAST loop call of this handle (exaadmm_run_inner / _run_fixed / _solve_two_level) actually launched, as the library
+ * decided it (occupancy figures of this device, co-residency, options) -- reporting tools ask instead of re-deriving the rule:
+ * tiles = tiles of 64 branches per resident wavefront (0: the call did not run the resident loop, 1, 2); heavy = heavy wavefronts
+ * in the call's last resident launch (0: none); launches = resident launches of the call; wavefronts = grid of the last one. */
+int exaadmm_resident_form(exaadmm_handle *h, int *tiles, int *heavy, int *launches, int *wavefronts);
+/* First-use self check of the resident loops (admm_two_level.jl:34-63: the loop must not return iterates the reference's loop
+ * cannot).  The cross-wavefront hand-overs of k_resident rest on hardware behaviour, so the first resident call of a handle -- and
+ * the first one with heavy wavefronts -- is preceded by a CHECK: from the iterate the call starts with, 8 iterations are run with the
+ * resident loop and with the two-launch loop, and u, v, z, z_prev, l, the line-limit multipliers / penalty, the branch counters and
+ * the four norms are compared bit for bit on the device; the iterate is restored either way.  A difference downgrades the handle
+ * to the two-launch loop (exaadmm_loop_downgrades counts it, exaadmm_last_error says what differed) before the call proper runs.
+ * checks = self checks made so far, mismatches = how many of them found a difference.  Option "trust_resident" = 1 skips them. */
+int exaadmm_resident_selfcheck_stats(exaadmm_handle *h, int *checks, int *mismatches);
+
+/* ---- options: A/B switches and diagnostics of a handle ----
+ * Every option has a default and none is needed in normal use; the library reads NO environment variable of its own (hosts that
+ * want switches from the environment translate them: exaadmm.jl_amd/__init__.py, tools/exaadmm_solve.c).  Set after create,
+ * between loop calls.  Keys (default):
+ *   "bus_kernel_lane" (0)  1: one lane per bus, the reference-order twin k_bus; implies the four-launch loop
+ *   "graph" (1)            batches of the two- / four-launch loops replayed from a hipGraph
+ *   "spec" (1)             the speculative two-launch loop (0: four launches per iteration)
+ *   "mp_spec" (1)          ... for a multi-period handle
+ *   "rec" (1)              pushed bus records in the fused loops (0: gathers like the step-wise path; no resident loop then)
+ *   "resident" (1)         the resident loop where the grid fits the chip
+ *   "resident_tiles" (1)   its two-tiles-per-wavefront form for grids up to twice the chip's SIMD count
+ *   "resident_coop" (1)    cooperative launch of the resident kernels (the runtime checks co-residency)
+ *   "heavy" (1)            heavy wavefronts (the branches with the most solver trips on wavefronts of their own)
+ *   "heavy_from" (64)      first iteration of an inner loop from which a resident launch may carry heavy wavefronts
+ *   "dist_overlap" (1)     partition with peers: the exchange on a second stream beside the interior solves
+ *   "dist_graph" (1)       ... and batches incl. their exchanges replayed from a hipGraph (read at exaadmm_dist_connect)
+ *   "trust_resident" (0)   1: no first-use self check of the resident loops
+ *   "verbose" (0)          1: downgrades are reported on stderr
+ * Unknown key: EXAADMM_ERR_INVALID. */
+int exaadmm_set_option(exaadmm_handle *h, const char *key, int64_t value);
+int exaadmm_get_option(exaadmm_handle *h, const char *key, int64_t *value);
 
 /* ---- fused: control stays on the device side ---- */
 /* Inner while-loop of admm_two_level (admm_two_level.jl:34-63) for outer iteration `outer`:
@@ -226,6 +261,9 @@ int exaadmm_dist_capture_selftest(exaadmm_handle *h, int64_t n, int *captured);
 int exaadmm_dist_stats(exaadmm_handle *h, int *comm_ranks, int *rccl_version, double *exchange_us, int64_t *graph_batches,
                        int64_t *direct_batches, int *probe);
 const char *exaadmm_dist_rccl_path(void); /* the RCCL the library bound (next to its own HIP runtime), "" before */
+/* process-wide, before the first bind: the communication library to load instead of the librccl next to the HIP runtime
+ * (a site's own build; the tests' in-process stand-in).  NULL / "" restores the default search. */
+int exaadmm_dist_set_rccl_library(const char *path);
 int64_t exaadmm_dist_exchange_count(void); /* grouped exchanges enqueued by the calling thread so far (tests) */
 
 /* Caller-driven variant (torch.distributed / gloo / debugging): the step-wise entry points plus these helpers. */

@@ -157,8 +157,8 @@ def test_grids_with_more_than_twice_as_many_tiles_as_simds_keep_the_two_launch_l
         env = pkg.AdmmEnv("case_ACTIVSg70k", 3e4, 3e5, verbose=0, grid=g)
         mod = pkg.ModelAcopf(env)
         assert mod.loop_kind() == 2
-        with _env(EXAADMM_RESIDENT_TILES="0"):
-            assert mod.loop_kind() == 1
+        mod.set_option("resident_tiles", 0)   # (A/B switch of the two-tile form)
+        assert mod.loop_kind() == 1
         mod.close()
 
 
@@ -179,59 +179,176 @@ class _env:
                 os.environ[k] = v
 
 
-@pytest.mark.skipif(SWITCHED_OFF, reason="a switch of this run turns the resident loop off")
-@pytest.mark.parametrize("fail_at", [1, 2])
-def test_a_failed_resident_batch_is_restored_and_repeated_with_the_two_launch_loop(pkg, fail_at):
-    """The resident loop's only failure mode -- a wavefront of the launch is not on the chip (shared GPU), a wait hits its cap --
-    must not surface: the call restores the iterate it started from, repeats its loop with two launches per iteration, returns
-    OK with exactly the two-launch loop's results, and the handle remembers the downgrade.  The failure is injected into the
-    fail_at-th resident launch of the handle (the first batch of a loop / a later batch of a convergence-tested loop)."""
-    syn = exaadmm_loader.load_submodule("synthetic")
-    g = syn.sized_like("case1354pegase", seed=0)
+# ---- fault injection: compiled into the TEST build of the library only (csrc/Makefile libexaadmm_hip_hooks.so, -DEXA_TEST_HOOKS:
+#      exaadmm_test_hook); the scenarios run in a worker process that loads that build
+_HOOKS_WORKER = r'''
+import json, os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import exaadmm_loader
+pkg = exaadmm_loader.load_package()
+L = pkg.library()
+assert hasattr(L, "exaadmm_test_hook") and "-DEXA_TEST_HOOKS" in L.exaadmm_version().decode()
+syn = exaadmm_loader.load_submodule("synthetic")
+
+def state(mod):
+    s = mod.solution
+    a, m, t = mod.branch_counters()
+    return [s.u_curr.copy(), s.v_curr.copy(), s.z_curr.copy(), s.l_curr.copy(), np.ascontiguousarray(mod.membuf).copy(), a, m, t]
+
+def same(x, y):
+    assert len(x) == len(y)
+    for p, q in zip(x, y):
+        assert np.array_equal(p, q)
+
+def model(grid, **opts):
+    env = pkg.AdmmEnv("case1354pegase", 1e1, 1e3, verbose=0, grid=grid)
+    mod = pkg.ModelAcopf(env)
+    for k, v in opts.items():
+        mod.set_option(k, v)
+    return mod
+
+report = {}
+g = syn.sized_like("case1354pegase", seed=0)
+# (1) a resident launch that reports a failed wait: the first batch of a loop / a later batch of a convergence-tested loop (a resident
+#     launch covers up to 1 024 iterations: the tolerance of a (hypothetical) millionth outer iteration keeps the loop going into a second
+#     launch, which is where fail_at = 2 strikes).  The call restores the iterate it started from, repeats its loop with two launches per
+#     iteration and returns what it would have returned; the handle keeps that loop.
+for fail_at in (1, 2):
     runs = []
     for inject in (False, True):
-        with _env(**({"EXAADMM_RESIDENT_TEST_FAIL": str(fail_at)} if inject else {"EXAADMM_NO_RESIDENT": "1"})):
-            env = pkg.AdmmEnv("case1354pegase", 1e1, 1e3, verbose=0, grid=g)
-            mod = pkg.ModelAcopf(env)
-            assert mod.loop_kind() == (2 if inject else 1) and mod.loop_downgrades() == 0
-            out = []
-            # (a resident launch covers up to 1 024 iterations: the tolerance of a (hypothetical) millionth outer iteration keeps the loop going into a
-            #  second launch, which is where fail_at = 2 strikes)
-            inner, res = mod.run_inner(1000000 if fail_at == 2 else 1, 1100 if fail_at == 2 else 150, 1e3)
-            assert fail_at == 1 or inner > 1024
-            out.append(_state(mod) + [res.copy(), np.array([inner])])
-            norms, _, _ = mod.run_fixed(21, first_major_iter=inner + 1, beta=1e3)
-            out.append(_state(mod) + [norms.copy()])
-            if inject:
-                assert mod.loop_downgrades() == 1 and mod.loop_kind() == 1
-            runs.append(out)
-            mod.close()
-    for a, b in zip(runs[0], runs[1]):
-        for x, y in zip(a, b):
-            assert np.array_equal(x, y)
+        mod = model(g, **({"trust_resident": 1} if inject else {"resident": 0}))
+        if inject:
+            mod.test_hook("fail_resident_launch", fail_at)
+        assert mod.loop_kind() == (2 if inject else 1) and mod.loop_downgrades() == 0
+        out = []
+        inner, res = mod.run_inner(1000000 if fail_at == 2 else 1, 1100 if fail_at == 2 else 150, 1e3)
+        assert fail_at == 1 or inner > 1024
+        out += state(mod) + [res.copy(), np.array([inner])]
+        norms, _, _ = mod.run_fixed(21, first_major_iter=inner + 1, beta=1e3)
+        out += state(mod) + [norms.copy()]
+        if inject:
+            assert mod.loop_downgrades() == 1 and mod.loop_kind() == 1
+        runs.append(out)
+        mod.close()
+    same(runs[0], runs[1])
+report["failed_batches"] = "ok"
+# (2) ... in a fixed-count run and in a whole solve
+g1 = syn.sized_like("case1354pegase", seed=1)
+res = []
+for inject in (False, True):
+    mod = model(g1, **({"trust_resident": 1} if inject else {"resident": 0}))
+    if inject:
+        mod.test_hook("fail_resident_launch", 1)
+    norms, _, _ = mod.run_fixed(37, first_major_iter=1, beta=1e3)
+    st = state(mod) + [norms.copy()]
+    assert mod.loop_downgrades() == (1 if inject else 0)
+    mod.close()
+    env2 = pkg.AdmmEnv("case1354pegase", 1e1, 1e3, verbose=0, grid=g1)
+    mod2 = pkg.ModelAcopf(env2)
+    mod2.set_option("trust_resident" if inject else "resident", 1 if inject else 0)
+    if inject:
+        mod2.test_hook("fail_resident_launch", 1)
+    env2.params.outer_iterlim, env2.params.inner_iterlim = 3, 200
+    pkg.admm_two_level(env2, mod2)
+    i = mod2.info
+    st += [np.array([i.outer, i.cumul]), np.array([i.objval, i.primres, i.mismatch]), mod2.solution.u_curr.copy(), mod2.solution.v_curr.copy()]
+    assert mod2.loop_downgrades() == (1 if inject else 0)
+    mod2.close()
+    res.append(st)
+same(res[0], res[1])
+report["failed_fixed_and_solve"] = "ok"
+# (3) the first-use self check (exaadmm_hip.h exaadmm_resident_selfcheck_stats): one ulp flipped in ONE word of the resident leg's u must be
+#     found -- the handle is downgraded, the error text names the vector, and the call returns the two-launch loop's bits
+for entry in ("run_fixed", "run_inner"):
+    runs = []
+    for inject in (False, True):
+        mod = model(g, **({} if inject else {"resident": 0}))
+        if inject:
+            mod.test_hook("flip_resident_ulp", 1)
+            assert mod.loop_kind() == 2
+        if entry == "run_fixed":
+            norms, _, _ = mod.run_fixed(30, first_major_iter=1, beta=1e3)
+            out = state(mod) + [norms.copy()]
+        else:
+            inner, r4 = mod.run_inner(1, 150, 1e3)
+            out = state(mod) + [r4.copy(), np.array([inner])]
+        if inject:
+            assert mod.resident_selfchecks() == (1, 1), mod.resident_selfchecks()
+            assert mod.loop_downgrades() == 1 and mod.loop_kind() == 1
+            msg = L.exaadmm_last_error().decode()
+            assert "self check" in msg and "u: 1 word" in msg, msg
+            report["message_" + entry] = msg
+        norms, _, _ = mod.run_fixed(9, first_major_iter=200, beta=1e3)   # ... and goes on with the two-launch loop
+        out += state(mod) + [norms.copy()]
+        runs.append(out)
+        mod.close()
+    same(runs[0], runs[1])
+report["flipped_ulp_found"] = "ok"
+print("RESULT " + json.dumps(report))
+'''
 
 
 @pytest.mark.skipif(SWITCHED_OFF, reason="a switch of this run turns the resident loop off")
-def test_injected_failure_in_a_fixed_count_run_and_in_a_whole_solve(pkg):
+def test_injected_failures_and_an_injected_ulp_are_caught__test_build_of_the_library():
+    """The resident loop's only failure mode -- a wavefront of the launch is not on the chip (shared GPU), a wait hits its cap -- must
+    not surface, and a resident kernel that does not reproduce the two-launch loop bit for bit on this device must be found by the
+    first-use self check before anything it produced is returned.  Both are INJECTED (a launch that reports a failed wait; one ulp
+    added to one word of the self check's resident leg) through exaadmm_test_hook, which exists only in the test build of the library:
+    the scenarios run in a worker process that loads libexaadmm_hip_hooks.so."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    lib = os.path.join(ROOT, "exaadmm.jl_amd", "libexaadmm_hip_hooks.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "exaadmm.jl_amd", "csrc"), "../libexaadmm_hip_hooks.so"])
+    env = dict(os.environ, EXAADMM_HIP_LIB=lib)
+    r = subprocess.run([sys.executable, "-c", _HOOKS_WORKER % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    rep = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    print(rep)
+    assert rep["failed_batches"] == rep["failed_fixed_and_solve"] == rep["flipped_ulp_found"] == "ok"
+
+
+@pytest.mark.skipif(SWITCHED_OFF, reason="a switch of this run turns the resident loop off")
+def test_first_use_self_check_runs_once_per_kernel_form_and_leaves_the_iterate_alone(pkg):
+    """Default library: the first call that used a resident kernel form is followed by ONE self check of that form (8 iterations from the
+    call's result with the resident and with the two-launch loop, compared on the device, the iterate restored): no mismatch on this
+    hardware, the results of the checked calls bitwise those of a handle that trusts the loop (option "trust_resident"), and no
+    further checks afterwards."""
     syn = exaadmm_loader.load_submodule("synthetic")
-    g = syn.sized_like("case1354pegase", seed=1)
-    res = []
-    for inject in (False, True):
-        with _env(**({"EXAADMM_RESIDENT_TEST_FAIL": "1"} if inject else {"EXAADMM_NO_RESIDENT": "1"})):
-            env = pkg.AdmmEnv("case1354pegase", 1e1, 1e3, verbose=0, grid=g)
-            mod = pkg.ModelAcopf(env)
-            norms, _, _ = mod.run_fixed(37, first_major_iter=1, beta=1e3)
-            st = _state(mod) + [norms.copy()]
-            assert mod.loop_downgrades() == (1 if inject else 0)
-            mod.close()
-            env2, mod2 = pkg.solve_acopf("case1354pegase", grid=g, rho_pq=1e1, rho_va=1e3, outer_iterlim=3, inner_iterlim=200, verbose=0)
-            i = mod2.info
-            st += [np.array([i.outer, i.cumul]), np.array([i.objval, i.primres, i.mismatch]), mod2.solution.u_curr.copy(), mod2.solution.v_curr.copy()]
-            assert mod2.loop_downgrades() == (1 if inject else 0)
-            mod2.close()
-            res.append(st)
-    for x, y in zip(res[0], res[1]):
+    g = syn.sized_like("case13659pegase", seed=0)
+    runs, checks = [], []
+    for trust in (0, 1):
+        env = pkg.AdmmEnv("case13659pegase", 5e1, 5e3, verbose=0, grid=g)
+        mod = pkg.ModelAcopf(env)
+        mod.set_option("trust_resident", trust)
+        assert mod.loop_kind() == 2
+        out, seen = [], []
+        n1, _, _ = mod.run_fixed(40, first_major_iter=1, beta=1e3)      # the plain kernel form
+        out += _state(mod) + [n1.copy()]
+        seen.append(mod.resident_selfchecks())
+        f1 = mod.resident_form()
+        n2, _, _ = mod.run_fixed(30, first_major_iter=80, beta=1e3)     # a launch that continues beyond the 64th iteration: heavy wavefronts
+        out += _state(mod) + [n2.copy()]
+        seen.append(mod.resident_selfchecks())
+        f2 = mod.resident_form()
+        n3, _, _ = mod.run_fixed(30, first_major_iter=110, beta=1e3)
+        inner, res = mod.run_inner(1, 60, 1e3)
+        out += _state(mod) + [n3.copy(), res.copy(), np.array([inner])]
+        seen.append(mod.resident_selfchecks())
+        assert mod.loop_downgrades() == 0 and mod.loop_kind() == 2
+        assert f1["tiles"] == 1 and f1["heavy"] == 0 and f1["launches"] == 1 and f1["wavefronts"] >= 385
+        if not os.environ.get("EXAADMM_NO_HEAVY"):
+            assert f2["heavy"] > 0 and f2["wavefronts"] == f1["wavefronts"] + f2["heavy"]
+        runs.append(out)
+        checks.append(seen)
+        mod.close()
+    for x, y in zip(runs[0], runs[1]):
         assert np.array_equal(x, y)
+    assert checks[1] == [(0, 0)] * 3
+    assert checks[0] == ([(1, 0), (2, 0), (2, 0)] if not os.environ.get("EXAADMM_NO_HEAVY") else [(1, 0), (1, 0), (1, 0)]), checks[0]
 
 
 _CONTENDER = r'''

@@ -9,11 +9,13 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -2404,6 +2406,20 @@ static int run_fixed_impl(exaadmm_handle* h, int iters, int first_major_iter, do
 // and repeats the call with the two-launch loop, which the handle keeps --, < 0 = error.  Cost: 2 x 8 iterations + four copy launches,
 // ~1 ms at 13 659 buses, once per form and handle.  Option "trust_resident" = 1 skips it.
 constexpr int SELFCHECK_ITERS = 8;
+// What a check establishes is a property of (device, kernel form, launch geometry) -- how this chip's coherence machinery treats the
+// hand-over sequence of that kernel at that size -- not of the handle: a form that has passed for a geometry in this process is not
+// checked again for another handle of the same geometry (a second solve_acopf of the same case, the periods of a rolling horizon).
+static std::mutex g_selfcheck_mutex;
+static std::vector<std::array<int, 6>> g_selfcheck_passed;   // device, form, G, L, B, resident capacity
+static bool selfcheck_known(const exaadmm_handle* h, int form, bool record)
+{
+    const std::array<int, 6> key = {h->device, form, h->G, h->L, h->B, h->resident_cap};
+    std::lock_guard<std::mutex> lock(g_selfcheck_mutex);
+    for (const auto& k : g_selfcheck_passed)
+        if (k == key) return true;
+    if (record) g_selfcheck_passed.push_back(key);
+    return false;
+}
 
 __global__ void k_compare_list(CopyList c, unsigned long long* __restrict__ ndiff)
 {
@@ -2460,6 +2476,8 @@ static int resident_selfcheck(exaadmm_handle* h, int next_major_iter, double bet
     const unsigned used = h->form_used;
     h->form_used = 0;
     if (h->in_selfcheck || h->opt.trust_resident != 0 || h->nsets != 2) return 0;
+    if (!h->checked_resident && selfcheck_known(h, 0, false)) h->checked_resident = true;
+    if (!h->checked_heavy && selfcheck_known(h, 1, false)) h->checked_heavy = true;
     const unsigned todo = used & ~((h->checked_resident ? 1u : 0u) | (h->checked_heavy ? 2u : 0u));
     if (todo == 0) return 0;
     int rc;
@@ -2515,7 +2533,10 @@ static int resident_selfcheck(exaadmm_handle* h, int next_major_iter, double bet
         }
         if ((rc = selfcheck_list(h, e_set, 1))) goto out_rc;
         if ((rc = sync_check(h, true))) goto out_rc;
-        if (verdict == 0) (form == 0 ? h->checked_resident : h->checked_heavy) = true;
+        if (verdict == 0) {
+            (form == 0 ? h->checked_resident : h->checked_heavy) = true;
+            (void)selfcheck_known(h, form, true);
+        }
     }
     rc = 0;
 out_rc:

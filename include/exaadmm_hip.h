@@ -174,7 +174,9 @@ int exaadmm_resident_form(exaadmm_handle *h, int *tiles, int *heavy, int *launch
  * resident loop and with the two-launch loop, and u, v, z, z_prev, l, the line-limit multipliers / penalty, the branch counters and
  * the four norms are compared bit for bit on the device; the iterate is restored either way.  A difference downgrades the handle
  * to the two-launch loop (exaadmm_loop_downgrades counts it, exaadmm_last_error says what differed) before the call proper runs.
- * checks = self checks made so far, mismatches = how many of them found a difference.  Option "trust_resident" = 1 skips them. */
+ * A form that has passed on this device for a grid of this size in this process is not checked again for another handle of the same
+ * size (the check is about the chip's treatment of that kernel at that launch geometry, not about the handle).
+ * checks = self checks this handle made so far, mismatches = how many of them found a difference.  Option "trust_resident" = 1 skips them. */
 int exaadmm_resident_selfcheck_stats(exaadmm_handle *h, int *checks, int *mismatches);
 
 /* ---- options: A/B switches and diagnostics of a handle ----

@@ -260,23 +260,44 @@ def test_1M_branch_grid_sharded_eight_ways_is_bitwise_the_single_handle_loop():
     assert groups == 21 * 8 and sends == recvs == 21 * 8 * 7, out
 
 
-def test_bench_under_the_launcher_one_rank_dist_path():
-    """The driver's multi-GPU command line with one rank: python -m torch.distributed.run --nproc-per-node 1 bench.py
-    --gpus 1 --force-dist ...; the LAST stdout line must be the JSON record (so that the first real 8-GPU run does not
-    die on plumbing)."""
+def _launcher_bench(extra_args=(), timeout=900, **extra_env):
     import socket
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "5", "--warmup", "2",
-           "--prep", "20", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+           "--prep", "20", "--no-cpu-baseline"] + list(extra_args)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=dict(os.environ, **extra_env))
+    return r
+
+
+def test_bench_under_the_launcher_one_rank_dist_path():
+    """The driver's multi-GPU command line with one rank: python -m torch.distributed.run --nproc-per-node 1 bench.py
+    --gpus 1 --force-dist ...; the LAST stdout line must be the JSON record (so that the first real 8-GPU run does not
+    die on plumbing).  The rank's process supervises (bench_supervisor.py): the measurement runs in a child of it, the line says
+    which attempts it took and carries the north_star_scaling leg (areas of ACTIVSg70k's size) from a second child."""
+    r = _launcher_bench()
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     rec = json.loads(r.stdout.strip().splitlines()[-1])
     assert rec["n_gpus"] == 1 and rec["steps"] == 5 and rec["warmup"] == 2 and rec["value"] > 0
     want = "step-wise twin" if os.environ.get("EXAADMM_DIST_PYTHON_LOOP") else "inside the library"
     assert rec["scaling"] == "weak" and want in rec["config"]["loop"]
+    assert [a["mode"] for a in rec["attempts"]] == ["graph+overlap"] and rec["attempts"][0]["ok"]
+    ns = rec["north_star_scaling"]
+    assert ns["value"] > 0 and "case_ACTIVSg70k" in ns["config"]["workload"] and ns["n_gpus"] == 1 and ns["attempts"][0]["ok"]
+
+
+def test_a_child_that_hangs_after_touching_the_gpu_costs_an_attempt_not_the_line():
+    """the first attempt's measuring child initialises the GPU and then never answers (injected: what a rank stuck
+    inside a collective looks like from outside).  Its supervisor -- which has not touched the GPU -- ends it at the attempt's budget and
+    starts a FRESH child in the next mode; the line arrives with attempts[0].rc != 0."""
+    r = _launcher_bench(["--attempt-budget", "45", "--no-north-star"], EXAADMM_BENCH_INJECT="hang:0")
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    a = rec["attempts"]
+    assert len(a) == 2 and a[0]["rc"] != 0 and a[0]["timed_out"] and not a[0]["ok"] and a[1]["ok"], a
+    assert a[1]["mode"] == "overlap" and rec["value"] > 0 and "north_star_scaling" not in rec
 
 
 def _probe(case, iters, **extra_env):

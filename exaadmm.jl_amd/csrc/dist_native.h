@@ -24,6 +24,7 @@
 #pragma once
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <unistd.h>
 #include <mutex>
 
 struct RcclApi {
@@ -62,6 +63,13 @@ struct exaadmm_dist {
     // a batch of iterations INCLUDING its exchanges as one hipGraph: offered when the bound RCCL captured, instantiated and
     // replayed a sums exchange with every peer at connect time (dist_probe); otherwise every batch is enqueued directly
     bool graph_ok = false;
+    // mailboxes of the resident loop (kernels.h ResidentPeers): ours (fine-grained device memory the peers write into over xGMI) and
+    // the peers', mapped here -- by IPC handle across processes, by address between handles of one process
+    double* box = nullptr;
+    size_t box_entries = 0;
+    int *d_cut_code = nullptr;
+    unsigned long long* d_twin = nullptr;
+    std::vector<void*> ipc_opened;
     int64_t graph_batches = 0, direct_batches = 0;
     int probe_result = -1;   // -1 not run, 0 capture refused (direct enqueue), 1 captured exchange replayed correctly
 };
@@ -218,9 +226,12 @@ extern "C" int exaadmm_dist_detach(exaadmm_handle* h)
     for (hipEvent_t e : d->xev)
         if (e) (void)hipEventDestroy(e);
     if (d->xstream) (void)hipStreamDestroy(d->xstream);
-    void* bufs[] = {d->send, d->recv, d->local, d->d_pos, d->d_off, d->d_rcode, d->d_rpos};
+    void* bufs[] = {d->send, d->recv, d->local, d->d_pos, d->d_off, d->d_rcode, d->d_rpos, d->box, d->d_cut_code, d->d_twin};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
+    for (void* q : d->ipc_opened) (void)hipIpcCloseMemHandle(q);
+    h->p2p_ready = false;
+    h->rpeers = ResidentPeers{};
     delete d;
     h->dist = nullptr;
     Dev& dv = h->d;
@@ -300,6 +311,32 @@ static int dist_prepare_impl(exaadmm_handle* h, int nranks, int rank, int64_t nv
     HIPCHK(hipMemcpy(d->d_off, offs.data(), offs.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d->d_rcode, rcode.data(), rcode.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d->d_rpos, rpos.data(), rpos.size() * sizeof(int), hipMemcpyHostToDevice));
+    if (nranks <= P2P_MAX_RANKS) {
+        // the mailbox of the resident loop: one 128-byte entry per cut branch (in the order of the cut lists), then one per rank for the
+        // residual sums and one per rank for the end-of-launch status.  Fine-grained device memory: stores from a peer GPU become
+        // visible to a running kernel here.  cut_code[storage slot] = (entry << 1) | (1: the TO end's bus is the peer's)
+        d->box_entries = (size_t)total + 2 * (size_t)nranks;
+        void* bx = nullptr;
+        hipError_t e = hipExtMallocWithFlags(&bx, d->box_entries * P2P_ENTRY * sizeof(double), hipDeviceMallocFinegrained);
+        if (e != hipSuccess) {   // (no fine-grained memory on this system: the partition keeps the two-launch loop)
+            (void)hipGetLastError();
+            bx = nullptr;
+            d->box_entries = 0;
+        }
+        d->box = static_cast<double*>(bx);
+        if (d->box) {
+            HIPCHK(hipMemset(d->box, 0, d->box_entries * P2P_ENTRY * sizeof(double)));
+            std::vector<int> code(h->Lp, -1);
+            for (int64_t c = 0; c < total; c++) {
+                const int slot = rcode[(size_t)c] & END_INDEX;
+                const bool remote_is_to = ((rcode[(size_t)c] >> 28) & 3) == END_TO;   // (rcode names the half that ARRIVES: the end on the peer's bus)
+                code[slot] = (int)(c << 1) | (remote_is_to ? 1 : 0);
+            }
+            HIPCHK(hipMalloc((void**)&d->d_cut_code, code.size() * sizeof(int)));
+            HIPCHK(hipMemcpy(d->d_cut_code, code.data(), code.size() * sizeof(int), hipMemcpyHostToDevice));
+            HIPCHK(hipMalloc((void**)&d->d_twin, (size_t)std::max<int64_t>(total, 1) * sizeof(unsigned long long)));
+        }
+    }
     Dev& dv = h->d;
     dv.nranks = nranks;
     dv.rank = rank;
@@ -389,6 +426,119 @@ extern "C" int exaadmm_dist_attach(exaadmm_handle* h, int nranks, int rank, cons
     if (rc) return rc;
     if (nranks > 1 || unique_id != nullptr) rc = exaadmm_dist_connect(h, unique_id, id_bytes);   // (one rank: optional)
     return rc;
+}
+
+// ---- mailboxes of the resident loop: who can write where
+// exaadmm_dist_p2p_export: 256 bytes that describe this rank's mailbox -- process id, device, address, IPC handle, its cut counts per
+// peer; the caller hands every rank's blob to every rank (torch.distributed.all_gather, MPI; the thread-rank tests: a shared list);
+// exaadmm_dist_p2p_import(all blobs in rank order): maps every peer's mailbox (same process: by address; another process:
+// hipIpcOpenMemHandle + peer access) and computes where each local cut branch's twin lane and each peer's sums entry for this rank
+// live.  From then on exaadmm_run_inner / _run_fixed / _solve_two_level use the resident loop on this partition when its wavefronts
+// fit the chip (exaadmm_loop_kind says 2).  Local: nothing here talks to a peer; callers agree on the outcome before they rely on it.
+struct P2PBlob {
+    unsigned long long magic;
+    long long pid;
+    int device, nranks, rank, has_box;
+    unsigned long long address;
+    hipIpcMemHandle_t ipc;
+    int ncut[P2P_MAX_RANKS];
+};
+static_assert(sizeof(P2PBlob) <= 256, "blob size is part of the ABI (EXAADMM_P2P_BLOB_BYTES)");
+constexpr unsigned long long P2P_MAGIC = 0x6578616164326d70ull;
+
+extern "C" int exaadmm_dist_p2p_export(exaadmm_handle* h, void* blob, int64_t nbytes)
+{
+    REQUIRE(h && h->dist && blob && nbytes >= 256, "needs a prepared partition and 256 bytes");
+    exaadmm_dist* d = h->dist;
+    HIPCHK(hipSetDevice(h->device));
+    P2PBlob b;
+    memset(&b, 0, sizeof(b));
+    b.magic = P2P_MAGIC;
+    b.pid = (long long)getpid();
+    b.device = h->device;
+    b.nranks = d->nranks;
+    b.rank = d->rank;
+    b.has_box = (d->box != nullptr && d->nranks <= P2P_MAX_RANKS) ? 1 : 0;
+    b.address = (unsigned long long)(uintptr_t)d->box;
+    if (b.has_box) {
+        if (hipIpcGetMemHandle(&b.ipc, d->box) != hipSuccess) {
+            (void)hipGetLastError();
+            memset(&b.ipc, 0, sizeof(b.ipc));   // (peers in this process use the address; peers in other processes will find no usable handle)
+        }
+        for (int p = 0; p < d->nranks; p++) b.ncut[p] = (int)d->ncut[p];
+    }
+    memset(blob, 0, 256);
+    memcpy(blob, &b, sizeof(b));
+    return EXAADMM_OK;
+}
+
+extern "C" int exaadmm_dist_p2p_import(exaadmm_handle* h, const void* blobs, int64_t nbytes_each)
+{
+    REQUIRE(h && h->dist && blobs && nbytes_each >= 256, "needs a prepared partition and every rank's 256-byte blob");
+    exaadmm_dist* d = h->dist;
+    h->p2p_ready = false;
+    REQUIRE(d->nranks > 1 && d->nranks <= P2P_MAX_RANKS, "mailboxes serve 2 .. 16 ranks");
+    REQUIRE(d->box != nullptr, "this rank has no mailbox (no fine-grained device memory)");
+    HIPCHK(hipSetDevice(h->device));
+    std::vector<P2PBlob> bl((size_t)d->nranks);
+    for (int p = 0; p < d->nranks; p++) {
+        memcpy(&bl[p], static_cast<const char*>(blobs) + (size_t)p * nbytes_each, sizeof(P2PBlob));
+        REQUIRE(bl[p].magic == P2P_MAGIC && bl[p].rank == p && bl[p].nranks == d->nranks, "blob of the wrong rank / job");
+        REQUIRE(bl[p].has_box == 1, "a peer has no mailbox");
+    }
+    REQUIRE(bl[d->rank].address == (unsigned long long)(uintptr_t)d->box, "our own blob does not describe this handle");
+    std::vector<unsigned long long> base((size_t)d->nranks, 0ull);
+    for (int p = 0; p < d->nranks; p++) {
+        if (p == d->rank) continue;
+        REQUIRE(bl[p].ncut[d->rank] == (int)d->ncut[p], "the two sides of a cut disagree about its size");
+        if (bl[p].pid == (long long)getpid()) {
+            base[p] = bl[p].address;   // a handle of this process (thread ranks; several GPUs driven by one process)
+            if (bl[p].device != h->device) {
+                const hipError_t e = hipDeviceEnablePeerAccess(bl[p].device, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+                    set_err("hipDeviceEnablePeerAccess(%d) failed: %s", bl[p].device, hipGetErrorString(e));
+                    return EXAADMM_ERR_HIP;
+                }
+                (void)hipGetLastError();
+            }
+        } else {
+            void* q = nullptr;
+            const hipError_t e = hipIpcOpenMemHandle(&q, bl[p].ipc, hipIpcMemLazyEnablePeerAccess);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                set_err("hipIpcOpenMemHandle for rank %d's mailbox failed: %s", p, hipGetErrorString(e));
+                return EXAADMM_ERR_HIP;
+            }
+            d->ipc_opened.push_back(q);
+            base[p] = (unsigned long long)(uintptr_t)q;
+        }
+    }
+    // entry of cut (p, k) on rank p: its cut list is peer-major in rank order as well -- (cuts with ranks < us) + k
+    std::vector<unsigned long long> twin((size_t)std::max(d->n_cut, 1), 0ull);
+    ResidentPeers rp = {};
+    int64_t c = 0;
+    for (int p = 0; p < d->nranks; p++) {
+        int64_t before = 0, total_p = 0;
+        for (int q = 0; q < d->nranks; q++) {
+            if (q < d->rank) before += bl[p].ncut[q];
+            total_p += bl[p].ncut[q];
+        }
+        for (int64_t k = 0; k < d->ncut[p]; k++, c++) twin[(size_t)c] = base[p] + (unsigned long long)(before + k) * P2P_ENTRY * sizeof(double);
+        rp.sums_at[p] = (p == d->rank) ? 0ull : base[p] + (unsigned long long)(total_p + d->rank) * P2P_ENTRY * sizeof(double);
+    }
+    HIPCHK(hipMemcpy(d->d_twin, twin.data(), twin.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+    rp.cut_code = d->d_cut_code;
+    rp.twin = d->d_twin;
+    rp.box = d->box;
+    rp.nranks = d->nranks;
+    rp.rank = d->rank;
+    rp.ncut = d->n_cut;
+    rp.epoch = 0;
+    h->rpeers = rp;
+    h->p2p_epoch = 0;
+    h->p2p_ready = true;
+    invalidate_graph(h);
+    return EXAADMM_OK;
 }
 
 // number of grouped exchanges this handle has enqueued since it was attached (tests: exactly one per inner iteration)

@@ -72,7 +72,7 @@ extern "C" int exaadmm_dist_detach(exaadmm_handle* h);
 struct Options {
     int bus_kernel_lane = 0, graph = 1, spec = 1, mp_spec = 1, rec = 1;
     int resident = 1, resident_tiles = 1, resident_coop = 1, heavy = 1, heavy_from = 64;
-    int dist_overlap = 1, dist_graph = 1;
+    int dist_overlap = 1, dist_graph = 1, dist_p2p = 1;
     int trust_resident = 0, verbose = 0;
     int prof_resident = 0;   // diagnostic build (-DEXA_PROFILE_PHASES): phase clocks of the resident loop's lanes instead of k_branch_t's timelines
 };
@@ -165,6 +165,12 @@ struct exaadmm_handle {
     int hook_flip_ulp = 0;           // test build only: the next resident launch's result gets one ulp added to one u entry
 #endif
     int resident_cap2 = -1;      // the same for k_resident_t<2> (two tiles of 64 branches per wavefront)
+    // resident loop of a partition WITH PEERS (kernels.h ResidentPeers; dist_native.h "mailboxes"): what crosses GPUs goes by direct
+    // stores into the peer's mailbox.  p2p_ready: every peer's mailbox is mapped (exaadmm_dist_p2p_import); resident_peers_ok: the
+    // grid's bus tables fit the loop's counters
+    bool resident_peers_ok = false, p2p_ready = false;
+    ResidentPeers rpeers = {};
+    int p2p_epoch = 0;
     ResidentTiles rtiles = {nullptr, 0, 0, 0, 0};
     ResidentHeavy rheavy = {nullptr, nullptr, nullptr, nullptr, 0};   // heavy wavefronts of the resident launch (kernels.h); n = 0: none
     int heavy_max = 0;
@@ -673,6 +679,9 @@ extern "C" int exaadmm_create(const exaadmm_grid* g, const exaadmm_params* p, in
                 d.gen_bus2 = dgb;
                 h->nrec_slots = (size_t)BUS_W * h->B + ec.size();
                 h->resident_ok = all_local && h->T == 1;
+                bool counts_ok = true;
+                for (int I = 0; I < h->B; I++) counts_ok = counts_ok && cnt[I] <= 0xffff;
+                h->resident_peers_ok = counts_ok && h->T == 1;
             }
         }
     }
@@ -1466,6 +1475,11 @@ static int resident_capacity(exaadmm_handle* h)
                 h->resident_cap = std::max(0, std::min(blocks, 4) * prop.multiProcessorCount - 8);
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_resident_t<2>, BR_BLOCK, 0) == hipSuccess)
                 h->resident_cap2 = std::max(0, std::min(blocks, 4) * prop.multiProcessorCount - 8);
+            // (the forms a partition with peers runs must be resident as well: the smaller figure counts)
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, (k_resident_t<1, false, true>), BR_BLOCK, 0) == hipSuccess)
+                h->resident_cap = std::min(h->resident_cap, std::max(0, std::min(blocks, 4) * prop.multiProcessorCount - 8));
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, (k_resident_t<2, false, true>), BR_BLOCK, 0) == hipSuccess)
+                h->resident_cap2 = std::min(h->resident_cap2, std::max(0, std::min(blocks, 4) * prop.multiProcessorCount - 8));
         }
         (void)hipGetLastError();
         // a cooperative launch makes the runtime check co-residency against its own occupancy figure and refuse what does
@@ -1573,7 +1587,7 @@ static int resident_prepare(exaadmm_handle* h, const Ctrl* begin = nullptr)
             HIPCHK(hipMemsetAsync(r.terms[q], 0, 4 * h->nrec_slots * sizeof(double), h->stream));
         }
     }
-    if (resident_mode(h) == 1 && !h->rheavy.list) {
+    if (resident_mode(h) == 1 && !h->rheavy.list && !dist_has_peers(h)) {
         // wavefronts of their own for the branches with the most solver trips: as many as the launch leaves SIMDs idle (at most 512)
         const int spare = resident_capacity(h) - (branch_blocks(h) + gen_blocks(h) + 1);
         h->heavy_max = std::max(0, std::min(512, spare));
@@ -1631,7 +1645,8 @@ static int enqueue_resident(exaadmm_handle* h, int n, int loop_iter0)
     // restart, the slowest branch changes from iteration to iteration) those say nothing -- a launch from there runs the kernel
     // without them (profiles/r04_heavy_wavefronts.txt: +8.6 % in the steady state, -2.7 % over a whole solve if always on).
     const bool heavy_rule = (h->force_heavy >= 0) ? (h->force_heavy != 0) : (loop_iter0 >= h->opt.heavy_from && h->opt.heavy != 0);
-    if (mode == 1 && heavy_rule && h->heavy_max > 0) {
+    const bool peers = dist_has_peers(h);
+    if (mode == 1 && heavy_rule && h->heavy_max > 0 && !peers) {
         // which branches get a wavefront of their own in this launch: from the solver-trip counters of the last x-updates (both buffer sets)
         rh.n = h->heavy_max;
         hipLaunchKernelGGL(k_heavy_select, dim3(1), dim3(1024), 0, h->stream, (const int*)h->sets[0].st[2], (const int*)h->sets[1].st[2], h->L, h->Lp, rh.n,
@@ -1643,26 +1658,35 @@ static int enqueue_resident(exaadmm_handle* h, int n, int loop_iter0)
     h->form_grid = grid;
     h->form_launches += 1;
     h->form_used |= (rh.n > 0) ? 2u : 1u;
-    if (h->resident_coop) {
-        const Dev *d0 = h->d_dspec[0][0], *d1 = h->d_dspec[1][0];
-        double scale = h->par.scale, base = h->baseMVA;
-        void* args[] = {(void*)&d0, (void*)&d1, (void*)&h->bo, (void*)&scale, (void*)&h->d_ctrl, (void*)&ng, (void*)&base, (void*)&n, (void*)&h->rsync, (void*)&h->rtiles, (void*)&rh};
-        const hipError_t e = hipLaunchCooperativeKernel(mode == 2 ? (const void*)k_resident_t<2> : (rh.n > 0 ? (const void*)k_resident_t<1, true> : (const void*)k_resident_t<1>), dim3(grid), dim3(BR_BLOCK), args, 0,
-                                                        h->stream);
-        if (e == hipSuccess) return 0;
-        (void)hipGetLastError();
-        if (e != hipErrorCooperativeLaunchTooLarge) h->resident_coop = false;   // (not offered after all: plain launches from here on)
-        else return 1;   // the runtime says the grid is not co-resident: the caller takes the two-launch loop
+    ResidentPeers rp = h->rpeers;
+    if (peers) {
+        h->p2p_epoch = (h->p2p_epoch + 1) & 0x7ffff;   // (the same count on every rank: they make the same calls)
+        rp.epoch = h->p2p_epoch;
     }
-    if (mode == 2)
-        hipLaunchKernelGGL(k_resident_t<2>, dim3(grid), dim3(BR_BLOCK), 0, h->stream, h->d_dspec[0][0], h->d_dspec[1][0], h->bo, h->par.scale, h->d_ctrl, ng,
-                           h->baseMVA, n, h->rsync, h->rtiles, rh);
-    else if (rh.n > 0)
-        hipLaunchKernelGGL((k_resident_t<1, true>), dim3(grid), dim3(BR_BLOCK), 0, h->stream, h->d_dspec[0][0], h->d_dspec[1][0], h->bo, h->par.scale, h->d_ctrl, ng,
-                           h->baseMVA, n, h->rsync, h->rtiles, rh);
-    else
-        hipLaunchKernelGGL(k_resident_t<1>, dim3(grid), dim3(BR_BLOCK), 0, h->stream, h->d_dspec[0][0], h->d_dspec[1][0], h->bo, h->par.scale, h->d_ctrl, ng,
-                           h->baseMVA, n, h->rsync, h->rtiles, rh);
+    const void* const kernel = peers ? (mode == 2 ? (const void*)k_resident_t<2, false, true> : (const void*)k_resident_t<1, false, true>)
+                                     : (mode == 2 ? (const void*)k_resident_t<2> : (rh.n > 0 ? (const void*)k_resident_t<1, true> : (const void*)k_resident_t<1>));
+    const Dev *d0 = h->d_dspec[0][0], *d1 = h->d_dspec[1][0];
+    double scale = h->par.scale, base = h->baseMVA;
+    void* args[] = {(void*)&d0, (void*)&d1, (void*)&h->bo, (void*)&scale, (void*)&h->d_ctrl, (void*)&ng, (void*)&base, (void*)&n, (void*)&h->rsync, (void*)&h->rtiles, (void*)&rh, (void*)&rp};
+    bool launched = false;
+    if (h->resident_coop) {
+        const hipError_t e = hipLaunchCooperativeKernel(kernel, dim3(grid), dim3(BR_BLOCK), args, 0, h->stream);
+        launched = (e == hipSuccess);
+        if (!launched) {
+            (void)hipGetLastError();
+            if (e != hipErrorCooperativeLaunchTooLarge) h->resident_coop = false;   // (not offered after all: plain launches from here on)
+            else if (!peers) return 1;   // the runtime says the grid is not co-resident: the caller takes the two-launch loop
+            else {
+                // a partition must not leave its peers waiting: the refusal becomes a failed launch that the agreement kernel reports to everybody
+                HIPCHK(hipMemsetAsync(h->rsync.fail, 0x01, 1, h->stream));
+                launched = true;
+            }
+        }
+    }
+    if (!launched) {
+        HIPCHK(hipLaunchKernel(kernel, dim3(grid), dim3(BR_BLOCK), args, 0, h->stream));
+    }
+    if (peers) hipLaunchKernelGGL(k_p2p_agree, dim3(1), dim3(64), 0, h->stream, rp, h->rsync.fail);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1674,7 +1698,10 @@ static int resident_mode(exaadmm_handle* h)
     if (h->opt.prof_resident == 0) return 0;
 #endif
     if (h->opt.resident == 0 || h->force_two_launch) return 0;
-    if (!(h->resident_ok && h->d.rec != nullptr && h->T == 1 && h->resident_downgrades == 0 && spec_eligible(h) && !dist_has_peers(h) && h->stream == h->own_stream)) return 0;
+    const bool peers = dist_has_peers(h);
+    if (!((peers ? (h->resident_peers_ok && h->p2p_ready && h->opt.dist_p2p != 0) : h->resident_ok) && h->d.rec != nullptr && h->T == 1 && h->resident_downgrades == 0 &&
+          spec_eligible(h) && h->stream == h->own_stream))
+        return 0;
     const int nb = branch_blocks(h), ng = gen_blocks(h);
     if (nb + ng + 1 <= resident_capacity(h)) return 1;
     if (h->opt.resident_tiles == 0) return 0;
@@ -1708,10 +1735,13 @@ static int resident_downgrade(exaadmm_handle* h)
 
 static int interior_blocks(const exaadmm_handle* h) { return h->n_interior / BR_BLOCK; }   // whole blocks in front of the first cut branch
 
+static int resident_mode(exaadmm_handle* h);
 static int spec_prepare(exaadmm_handle* h)
 {
     int rc;
-    const int want = dist_has_peers(h) ? 3 : 2;
+    // (a partition with peers on the two-launch loop runs two launches ahead of its stop test: three sets; the resident loop of a
+    //  partition whose peers' mailboxes are mapped keeps the one-iteration speculation of the single-GPU loops: two)
+    const int want = (dist_has_peers(h) && resident_mode(h) == 0) ? 3 : 2;
     // alternate buffer sets: one for the two-set loop, a second one (and alternates of z, l; a sink for the z_prev the kernels
     // write) once the handle has peers
     for (int q = 0; q < want - 1; q++) {
@@ -2475,7 +2505,7 @@ static int resident_selfcheck(exaadmm_handle* h, int next_major_iter, double bet
 {
     const unsigned used = h->form_used;
     h->form_used = 0;
-    if (h->in_selfcheck || h->opt.trust_resident != 0 || h->nsets != 2) return 0;
+    if (h->in_selfcheck || h->opt.trust_resident != 0 || h->nsets != 2 || dist_has_peers(h)) return 0;   // (a partition's loop is checked against the single handle by the tests)
     if (!h->checked_resident && selfcheck_known(h, 0, false)) h->checked_resident = true;
     if (!h->checked_heavy && selfcheck_known(h, 1, false)) h->checked_heavy = true;
     const unsigned todo = used & ~((h->checked_resident ? 1u : 0u) | (h->checked_heavy ? 2u : 0u));
@@ -2584,7 +2614,7 @@ const OptKey OPT_KEYS[] = {
     {"bus_kernel_lane", &Options::bus_kernel_lane, 0, 1}, {"graph", &Options::graph, 0, 1}, {"spec", &Options::spec, 0, 1},
     {"mp_spec", &Options::mp_spec, 0, 1}, {"rec", &Options::rec, 0, 1}, {"resident", &Options::resident, 0, 1},
     {"resident_tiles", &Options::resident_tiles, 0, 1}, {"resident_coop", &Options::resident_coop, 0, 1}, {"heavy", &Options::heavy, 0, 1},
-    {"heavy_from", &Options::heavy_from, 0, 1 << 30}, {"dist_overlap", &Options::dist_overlap, 0, 1}, {"dist_graph", &Options::dist_graph, 0, 1},
+    {"heavy_from", &Options::heavy_from, 0, 1 << 30}, {"dist_overlap", &Options::dist_overlap, 0, 1}, {"dist_graph", &Options::dist_graph, 0, 1}, {"dist_p2p", &Options::dist_p2p, 0, 1},
     {"trust_resident", &Options::trust_resident, 0, 1}, {"verbose", &Options::verbose, 0, 1}, {"prof_resident", &Options::prof_resident, 0, 1},
 };
 }  // namespace

@@ -1384,11 +1384,103 @@ struct ResidentHeavy {
     int n;
 };
 
-template <int TILES, bool HEAVY = false>
+// RESIDENT LOOP OF A PARTITION WITH PEERS (PEERS = true; one process per GPU).  The loop keeps its form -- every
+// wavefront resident, a bus updated by the last lane to arrive at it, a control wavefront that makes the stop test -- and what has to
+// cross GPUs goes by DIRECT STORES over xGMI into the peer's mailbox (fine-grained device memory the peer has mapped for us), from
+// inside the launch: no kernel boundary, no collective call, no host in the loop.
+//   * a cut branch is solved on both of its owners (bit-identical replicas, as in the two-launch loop).  Its lane arrives at its LOCAL
+//     bus only; what it is missing for its next iteration is the update of the bus at its other end, which the peer's lanes make.  The
+//     twin lane on the peer waits for that bus anyway: as soon as it is ready the twin forwards the bus result (mu1, mu2, w, theta: 4
+//     doubles) into our mailbox entry of that branch, and we do the same for it -- send first, then wait: no cycle;
+//   * the control wavefronts exchange their four partial residual sums the same way and add them IN RANK ORDER (the order of
+//     k_halo_unpack: the same bits and therefore the same decision in the same iteration on every rank).
+// Mailbox words are SELF-VALIDATING: 16 bytes = (value, sequence number), written and read as one 16-byte access that bypasses the
+// caches (sc0 sc1); a reader polls until the word carries the sequence number it waits for.  No flag, no fence, no ordering
+// assumption between stores -- only that an aligned 16-byte store arrives as a unit (what the LL protocols of the collective
+// libraries build on as well).  An entry is one 128-byte line: 4 words per iteration parity; a sender reuses a parity only after the
+// receiver has consumed it (its next send depends on our answer to this one).
+// Waits are capped like every wait of the loop; a failed wait ends the launch with rs.fail set, the host agrees on the outcome with
+// its peers (exaadmm_hip.hip) and every rank repeats the call with the two-launch loop.
+constexpr int P2P_MAX_RANKS = 16;
+constexpr int P2P_ENTRY = 16;   // doubles per mailbox entry (128 bytes)
+struct ResidentPeers {
+    const int* cut_code;                        // [Lp] -1: both buses local; else (mailbox entry << 1) | (1: the TO end's bus is the peer's, 0: the FROM end's)
+    const unsigned long long* twin;             // [ncut] address of the twin lane's entry in the PEER's mailbox
+    double* box;                                // this rank's mailbox: ncut branch entries, then one entry per rank (residual sums)
+    unsigned long long sums_at[P2P_MAX_RANKS];  // address of OUR sums entry in rank q's mailbox
+    int nranks, rank, ncut;
+    int epoch;   // launches of this kind so far, the same on every rank: sequence numbers are (epoch << 12) | iteration -- unique across launches
+};
+typedef unsigned int p2p_word __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void p2p_put(unsigned long long addr, double v, int seq)
+{
+    p2p_word w;
+    w.x = (unsigned)__double2loint(v);
+    w.y = (unsigned)__double2hiint(v);
+    w.z = (unsigned)seq;
+    w.w = 0u;
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(addr), "v"(w) : "memory");
+}
+__device__ __forceinline__ bool p2p_get(const double* p, int seq, double& v)
+{
+    p2p_word w;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(w) : "v"(p) : "memory");
+    v = __hiloint2double((int)w.y, (int)w.x);
+    return (int)w.z == seq;
+}
+// the 4 words of `entry` (parity seq & 1) carry `seq`: their values; false = the wait was capped / another wavefront has failed
+__device__ __forceinline__ bool p2p_wait4(const double* entry, int seq, int* fail, double (&out)[4])
+{
+    const double* q = entry + 8 * (seq & 1);
+    int spins = 0;
+    for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < 4; k++) ok = p2p_get(q + 2 * k, seq, out[k]) && ok;
+        if (ok) return true;
+        ++spins;
+        if (spins > (1 << 20) || (fail != nullptr && (spins & 255) == 0 && __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            if (fail != nullptr) __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(24);
+    }
+}
+__device__ __forceinline__ void p2p_send4(unsigned long long entry_addr, int seq, const double (&v)[4])
+{
+    const unsigned long long q = entry_addr + 64ull * (unsigned)(seq & 1);
+#pragma unroll
+    for (int k = 0; k < 4; k++) p2p_put(q + 16ull * k, v[k], seq);
+}
+
+// One wavefront behind every resident launch of a partition with peers: the ranks tell each other how their launch ended (lane q talks
+// to rank q: our rs.fail into its status entry, its into ours) and a rank that hears of a failure -- or hears nothing within the cap --
+// marks its own launch failed: every rank then restores the iterate its call started from and repeats the call with the two-launch
+// loop.  (A failure INSIDE the launch already spreads by itself: a rank that stops sending starves the twins of its cut lanes and
+// the peers' control wavefronts, whose waits are capped.  This closes the window at the very end of a launch.)
+__global__ void __launch_bounds__(64) k_p2p_agree(ResidentPeers rp, int* fail)
+{
+    const int lane = threadIdx.x;
+    const bool peer_lane = lane < rp.nranks && lane != rp.rank;
+    const int seq = (rp.epoch << 12) | 0xfff;
+    const int mine = __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double v[4] = {(double)mine, 0.0, 0.0, 0.0};
+    double got[4] = {0.0, 0.0, 0.0, 0.0};
+    bool bad = false;
+    if (peer_lane) {
+        p2p_send4(rp.sums_at[lane] + 128ull * (unsigned)rp.nranks, seq, v);
+        // (no flag to watch: the launch's own must not cut this wait short)
+        bad = !p2p_wait4(rp.box + (size_t)P2P_ENTRY * (rp.ncut + rp.nranks + lane), seq, nullptr, got) || got[0] != 0.0;
+    }
+    if (__ballot(bad) != 0ull && lane == 0) __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int TILES, bool HEAVY = false, bool PEERS = false>
 __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restrict__ dp0, const Dev* __restrict__ dp1, BranchOptions o, double scale,
                                                              Ctrl* ctrl, int gen_blocks, double baseMVA, int iters, ResidentSync rs, ResidentTiles rt,
-                                                             ResidentHeavy rh)
+                                                             ResidentHeavy rh, ResidentPeers rp)
 {
+    static_assert(!(PEERS && HEAVY), "heavy wavefronts are not offered to a partition with peers");
     if (ctrl->done) return;
     const int base_iter = ctrl->base;
     const double zl_beta = ctrl->beta;
@@ -1420,6 +1512,28 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
                     for (int off = 32; off > 0; off >>= 1) sj[j] += __shfl_down(sj[j], off, 64);
                     tot[j] += sj[j];   // (lane 0: 0 + wave 0 + wave 1 + ... as block_reduce4 adds them)
                 }
+            }
+            if (PEERS) {
+                // this rank's sums to every peer, the peers' sums from our mailbox (lane q talks to rank q), added in rank order
+#pragma unroll
+                for (int j = 0; j < 4; j++) tot[j] = __shfl(tot[j], 0, 64);
+                double got[4] = {0.0, 0.0, 0.0, 0.0};
+                const bool peer_lane = lane < rp.nranks && lane != rp.rank;
+                const int seq = (rp.epoch << 12) | p;
+                if (peer_lane) p2p_send4(rp.sums_at[lane], seq, tot);
+                bool ok = true;
+                if (peer_lane) ok = p2p_wait4(rp.box + (size_t)P2P_ENTRY * (rp.ncut + lane), seq, rs.fail, got);
+                if (__ballot(!ok) != 0ull) return;
+                double sum[4] = {0.0, 0.0, 0.0, 0.0};
+                for (int q = 0; q < rp.nranks; q++) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const double gq = __shfl(got[j], q, 64);
+                        sum[j] += (q == rp.rank) ? tot[j] : gq;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) tot[j] = sum[j];
             }
             int stop = 0;
             if (lane == 0) {
@@ -1709,7 +1823,46 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
 #if defined(EXA_PROFILE_PHASES)
             asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts[1]) : "v"(rate_0) : "memory");   // loads landed
 #endif
-            if (v_from_bus && lane_on) {
+            // (PEERS) a cut branch: the bus of one of its ends is the peer's -- its update arrives through the mailbox, from the twin lane
+            const int ccode = PEERS ? rp.cut_code[b] : -1;
+            const bool rem_f = PEERS && ccode >= 0 && (ccode & 1) == 0, rem_t = PEERS && ccode >= 0 && (ccode & 1) == 1;
+            if (PEERS && v_from_bus && lane_on) {
+                double rf[4] = {0.0, 0.0, 0.0, 0.0}, rt4[4] = {0.0, 0.0, 0.0, 0.0};
+                if (!rem_f) {
+                    if (!resident_wait(rs.ready + bus4.x, i, rs.fail)) return;
+                    const double* pf = rs.busres[i & 1] + 4 * (size_t)bus4.x;
+#pragma unroll
+                    for (int m = 0; m < 4; m++) rf[m] = ld_agent(pf + m);
+                }
+                if (!rem_t) {
+                    if (!resident_wait(rs.ready + bus4.z, i, rs.fail)) return;
+                    const double* pt = rs.busres[i & 1] + 4 * (size_t)bus4.z;
+#pragma unroll
+                    for (int m = 0; m < 4; m++) rt4[m] = ld_agent(pt + m);
+                }
+                if (ccode >= 0) {   // our bus's update to the twin lane first, then the twin's to us
+                    const int seq = (rp.epoch << 12) | i;
+                    const double* const mine = rp.box + (size_t)P2P_ENTRY * (ccode >> 1);
+                    if (rem_f) {
+                        p2p_send4(rp.twin[ccode >> 1], seq, rt4);
+                        if (!p2p_wait4(mine, seq, rs.fail, rf)) return;
+                    } else {
+                        p2p_send4(rp.twin[ccode >> 1], seq, rf);
+                        if (!p2p_wait4(mine, seq, rs.fail, rt4)) return;
+                    }
+                }
+                vv[0] = (ub[0] + zo[0]) + (lo[0] + rf[0]) / bd.rho_[0];
+                vv[1] = (ub[1] + zo[1]) + (lo[1] + rf[1]) / bd.rho_[1];
+                vv[4] = rf[2];
+                vv[6] = rf[3];
+                vv[2] = (ub[2] + zo[2]) + (lo[2] + rt4[0]) / bd.rho_[2];
+                vv[3] = (ub[3] + zo[3]) + (lo[3] + rt4[1]) / bd.rho_[3];
+                vv[5] = rt4[2];
+                vv[7] = rt4[3];
+#pragma unroll
+                for (int k = 0; k < 8; k++) vbuf[base + k * Lp] = vv[k];
+            }
+            if (!PEERS && v_from_bus && lane_on) {
                 if (!resident_wait(rs.ready + bus4.x, i, rs.fail)) return;
                 if (!resident_wait(rs.ready + bus4.z, i, rs.fail)) return;
 #if defined(EXA_PROFILE_PHASES)
@@ -1792,14 +1945,14 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
                 for (int k = 0; k < 8; k++) zz[k] = park_lds[(32 + k) * BR_BLOCK + lane];
                 const double un[8] = {phi[0], phi[1], phi[2], phi[3], x[0] * x[0], x[1] * x[1], x[2], x[3]};
                 double* const tm = rs.terms[(i + 1) & 1];
-                {
+                if (!PEERS || !rem_f) {   // (the end on a peer's bus has no slot here: the peer's replica of the branch pushes it there)
                     double* q = tm + 4 * (size_t)rec_from;
                     st_agent(q, (un[0] + zz[0]) + (bd.lam_[0] / bd.rho_[0]));
                     st_agent(q + 1, (un[1] + zz[1]) + (bd.lam_[1] / bd.rho_[1]));
                     st_agent(q + 2, bd.lam_[4] + bd.rho_[4] * (un[4] + zz[4]));
                     st_agent(q + 3, bd.lam_[6] + bd.rho_[6] * (un[6] + zz[6]));
                 }
-                {
+                if (!PEERS || !rem_t) {
                     double* q = tm + 4 * (size_t)rec_to;
                     st_agent(q, (un[2] + zz[2]) + (bd.lam_[2] / bd.rho_[2]));
                     st_agent(q + 1, (un[3] + zz[3]) + (bd.lam_[3] / bd.rho_[3]));
@@ -1820,7 +1973,10 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
 #if defined(EXA_PROFILE_PHASES)
             ts[5] = __builtin_amdgcn_s_memtime();   // results and terms stored
 #endif
-            if (lane_on && !(TILES == 1 && HEAVY && rec_from < 0)) {
+            if (PEERS) {
+                if (lane_on && !rem_f) resident_arrive(d, rs, bus4.x, bus4.y, i + 1);
+                if (lane_on && !rem_t) resident_arrive(d, rs, bus4.z, bus4.w, i + 1);
+            } else if (lane_on && !(TILES == 1 && HEAVY && rec_from < 0)) {
                 resident_arrive(d, rs, bus4.x, bus4.y, i + 1);
                 resident_arrive(d, rs, bus4.z, bus4.w, i + 1);
             }
@@ -1842,12 +1998,44 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
         if (slot >= d.L) continue;
         const int b = slot, base = 2 * d.Gp + b;
         const int4 bus4 = reinterpret_cast<const int4*>(d.br_bus4)[b];
-        if (!resident_wait(rs.ready + bus4.x, iters, rs.fail)) return;
-        if (!resident_wait(rs.ready + bus4.z, iters, rs.fail)) return;
-        const double* pf = rs.busres[iters & 1] + 4 * (size_t)bus4.x;
-        const double* pt = rs.busres[iters & 1] + 4 * (size_t)bus4.z;
-        const double rf[4] = {ld_agent(pf), ld_agent(pf + 1), ld_agent(pf + 2), ld_agent(pf + 3)};
-        const double rt4[4] = {ld_agent(pt), ld_agent(pt + 1), ld_agent(pt + 2), ld_agent(pt + 3)};
+        double rf[4] = {0.0, 0.0, 0.0, 0.0}, rt4[4] = {0.0, 0.0, 0.0, 0.0};
+        if (PEERS) {
+            const int ccode = rp.cut_code[b];
+            const bool rem_f = ccode >= 0 && (ccode & 1) == 0, rem_t = ccode >= 0 && (ccode & 1) == 1;
+            if (!rem_f) {
+                if (!resident_wait(rs.ready + bus4.x, iters, rs.fail)) return;
+                const double* pf = rs.busres[iters & 1] + 4 * (size_t)bus4.x;
+#pragma unroll
+                for (int m = 0; m < 4; m++) rf[m] = ld_agent(pf + m);
+            }
+            if (!rem_t) {
+                if (!resident_wait(rs.ready + bus4.z, iters, rs.fail)) return;
+                const double* pt = rs.busres[iters & 1] + 4 * (size_t)bus4.z;
+#pragma unroll
+                for (int m = 0; m < 4; m++) rt4[m] = ld_agent(pt + m);
+            }
+            if (ccode >= 0) {
+                const int seq = (rp.epoch << 12) | iters;
+                const double* const mine = rp.box + (size_t)P2P_ENTRY * (ccode >> 1);
+                if (rem_f) {
+                    p2p_send4(rp.twin[ccode >> 1], seq, rt4);
+                    if (!p2p_wait4(mine, seq, rs.fail, rf)) return;
+                } else {
+                    p2p_send4(rp.twin[ccode >> 1], seq, rf);
+                    if (!p2p_wait4(mine, seq, rs.fail, rt4)) return;
+                }
+            }
+        } else {
+            if (!resident_wait(rs.ready + bus4.x, iters, rs.fail)) return;
+            if (!resident_wait(rs.ready + bus4.z, iters, rs.fail)) return;
+            const double* pf = rs.busres[iters & 1] + 4 * (size_t)bus4.x;
+            const double* pt = rs.busres[iters & 1] + 4 * (size_t)bus4.z;
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                rf[m] = ld_agent(pf + m);
+                rt4[m] = ld_agent(pt + m);
+            }
+        }
         double uu[8], zz[8], ll[8], rr[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) {

@@ -298,6 +298,33 @@ class HipBackend:
             if not all_ok(err is None):
                 return fail("exaadmm_dist_connect", err)
         self.native = True
+        # phase 4 (optional): the mailboxes of the resident loop.  Every rank's 256-byte description of its mailbox goes to every rank;
+        # a rank maps its peers' (same process: by address; other processes: IPC handle + peer access).  Only if EVERY rank could map
+        # EVERY peer does the partition run the resident loop (what crosses GPUs then goes by direct stores over xGMI from inside the
+        # launch); otherwise all keep two launches per iteration + the RCCL exchange.
+        self.p2p = False
+        if world > 1 and os.environ.get("EXAADMM_DIST_P2P", "1") != "0" and self.mod.get_option("dist_p2p"):
+            err, blobs = None, [None] * world
+            mine = C.create_string_buffer(256)
+            try:
+                pkg._check(lib.exaadmm_dist_p2p_export(h, mine, 256), "exaadmm_dist_p2p_export")
+            except pkg.ExaAdmmError as e:
+                err = e
+            dist.all_gather_object(blobs, mine.raw if err is None else None)
+            if err is None and all(b is not None for b in blobs):
+                try:
+                    pkg._check(lib.exaadmm_dist_p2p_import(h, b"".join(blobs), 256), "exaadmm_dist_p2p_import")
+                except pkg.ExaAdmmError as e:
+                    err = e
+            else:
+                err = err or pkg.ExaAdmmError("a peer has no mailbox")
+            self.p2p = all_ok(err is None)
+            if not self.p2p:
+                if err is not None and rank == 0:
+                    sys.stderr.write("exaadmm: rank %d: no mailboxes between the ranks (%s): two launches per iteration + RCCL exchange\n" % (rank, err))
+                self.mod.set_option("dist_p2p", 0)
+        else:
+            self.mod.set_option("dist_p2p", 0)
         return True
 
     def run_inner_native(self, outer, max_inner, beta):
@@ -706,7 +733,11 @@ def bench_main(args, rank, world, local_rank):
                        "cut_branches": int(cuts.cpu()[0]), "cut_fraction": float(cuts.cpu()[0] / max(cuts.cpu()[1], 1.0)),
                        "mode": "fixed-count inner iterations, no early break",
                        "state": "ADMM state after %d untimed preparation iterations from init_solution!" % prep,
-                       "loop": "inside the library, RCCL from C++ (dist_native.h)" if native else "step-wise twin: Python-driven steps + torch collectives",
+                       "loop": ("inside the library: resident loop, one launch per run, what crosses GPUs by direct stores into the peers' mailboxes (kernels.h ResidentPeers)"
+                                if (native and getattr(be, "p2p", False) and be.mod.loop_kind() == 2) else
+                                "inside the library, RCCL from C++ (dist_native.h)" if native else "step-wise twin: Python-driven steps + torch collectives"),
+                       "loop_kind": be.mod.loop_kind(), "mailboxes_mapped": bool(getattr(be, "p2p", False)), "loop_downgrades": be.mod.loop_downgrades(),
+                       "resident_form": be.mod.resident_form(),
                        "exchanges_per_iteration_rank0": (exch2 - exch1) / float(max(args.steps, 1)) if native else None,
                        "overlap": "exchange + cut-branch solves on a second stream beside the interior branch solves of the next iteration"
                                   if be.mod.get_option("dist_overlap") else "off (option dist_overlap = 0): one stream",

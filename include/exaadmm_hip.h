@@ -195,6 +195,7 @@ int exaadmm_resident_selfcheck_stats(exaadmm_handle *h, int *checks, int *mismat
  *   "heavy_from" (64)      first iteration of an inner loop from which a resident launch may carry heavy wavefronts
  *   "dist_overlap" (1)     partition with peers: the exchange on a second stream beside the interior solves
  *   "dist_graph" (1)       ... and batches incl. their exchanges replayed from a hipGraph (read at exaadmm_dist_connect)
+ *   "dist_p2p" (1)         partition with peers whose mailboxes are mapped (exaadmm_dist_p2p_import): the resident loop
  *   "trust_resident" (0)   1: no first-use self check of the resident loops
  *   "verbose" (0)          1: downgrades are reported on stderr
  * Unknown key: EXAADMM_ERR_INVALID. */
@@ -249,6 +250,19 @@ int exaadmm_dist_connect(exaadmm_handle *h, const void *unique_id, int64_t id_by
 int exaadmm_dist_attach(exaadmm_handle *h, int nranks, int rank, const void *unique_id, int64_t id_bytes,
                         int64_t nvar_global, const int64_t *ncut_per_peer, const int64_t *cut_branch);
 int exaadmm_dist_detach(exaadmm_handle *h);
+/* Resident loop of a partition with peers: the in-library loop above keeps ONE launch per inner loop (exaadmm_loop_kind = 2) when the
+ * ranks can write into each other's device memory -- what crosses GPUs (per cut branch the update of the bus at its far end, 4 doubles
+ * each way; the four residual sums) then goes by direct stores over xGMI into the peer's MAILBOX from inside the launch, no kernel
+ * boundary and no collective call per iteration.
+ *   exaadmm_dist_p2p_export  after exaadmm_dist_prepare: 256 bytes describing this rank's mailbox (process, device, address, IPC handle)
+ *   exaadmm_dist_p2p_import  every rank's blob, in rank order (the caller's all-gather): maps the peers' mailboxes.  Local; the ranks agree
+ *                            on the outcome before they rely on it (a rank that cannot map a peer keeps two launches per iteration,
+ *                            and so must the others: option "dist_p2p" = 0).
+ * A launch whose waits run into their cap on any rank is reported to every rank by the launch's last kernel; all then restore the
+ * iterate the call started from and repeat it with two launches per iteration + the RCCL exchange (exaadmm_loop_downgrades). */
+#define EXAADMM_P2P_BLOB_BYTES 256
+int exaadmm_dist_p2p_export(exaadmm_handle *h, void *blob, int64_t nbytes);
+int exaadmm_dist_p2p_import(exaadmm_handle *h, const void *blobs, int64_t nbytes_each);
 /* the sums exchange + a ring send / receive of n doubles on the handle's stream; max_err = deviation from the
  * expected values.  Checks that RCCL and the library share one HIP runtime. */
 int exaadmm_dist_selftest(exaadmm_handle *h, int64_t n, double *max_err);

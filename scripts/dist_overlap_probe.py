@@ -53,6 +53,11 @@ class Stub:
         v = min(Stub.slots)
         Stub.barrier.wait()
         t[0] = v
+    def all_gather_object(self, out, obj):
+        Stub.slots[self.rank] = obj
+        Stub.barrier.wait()
+        for i in range(world): out[i] = Stub.slots[i]
+        Stub.barrier.wait()
 
 
 bes = [dm.HipBackend(pkg, p, params["rho_pq"], params["rho_va"], params={"scale": params["scale"]}, device_index=0) for p in parts]

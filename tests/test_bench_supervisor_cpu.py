@@ -36,7 +36,7 @@ if what == "ok":
     if rank == "0":
         print("some library banner")
         print(json.dumps({"metric": "ADMM inner iterations/sec", "value": 100.0 + 10 * int(attempt), "leg": leg,
-                          "graph": os.environ.get("EXAADMM_OPT_DIST_GRAPH", "1"), "overlap": os.environ.get("EXAADMM_OPT_DIST_OVERLAP", "1"),
+                          "p2p": os.environ.get("EXAADMM_DIST_P2P", "1"), "graph": os.environ.get("EXAADMM_OPT_DIST_GRAPH", "1"), "overlap": os.environ.get("EXAADMM_OPT_DIST_OVERLAP", "1"),
                           "python_loop": os.environ.get("EXAADMM_DIST_PYTHON_LOOP", ""), "port": os.environ["MASTER_PORT"]}))
 '''
 
@@ -65,28 +65,28 @@ def _run1(sup, tmp_path, plan, legs=None, budget=4.0):
 
 def test_first_attempt_succeeds(sup, tmp_path):
     line, rc, dt, _ = _run1(sup, tmp_path, {})
-    assert rc == 0 and line["value"] == 100.0 and line["graph"] == "1"
-    assert [a["mode"] for a in line["attempts"]] == ["graph+overlap"] and line["attempts"][0]["ok"]
+    assert rc == 0 and line["value"] == 100.0 and line["graph"] == "1" and line["p2p"] == "1"
+    assert [a["mode"] for a in line["attempts"]] == ["resident+xgmi"] and line["attempts"][0]["ok"]
 
 
 def test_a_hanging_child_costs_one_attempt_not_the_line(sup, tmp_path):
     line, rc, dt, logs = _run1(sup, tmp_path, {"main:0:0": "hang"}, budget=2.0)
     assert rc == 0 and line["value"] == 110.0
     a = line["attempts"]
-    assert [x["mode"] for x in a] == ["graph+overlap", "overlap"]
+    assert [x["mode"] for x in a] == ["resident+xgmi", "graph+overlap"]
     assert a[0]["rc"] != 0 and a[0]["timed_out"] and not a[0]["ok"] and a[1]["ok"]
-    assert line["graph"] == "0" and line["overlap"] == "1"        # the second mode's switches reached the fresh child
+    assert line["p2p"] == "0" and line["graph"] == "1"        # the second mode's switches reached the fresh child
     assert 2.0 <= dt < 20.0
 
 
 def test_failures_walk_down_the_modes_and_the_stderr_tail_is_kept(sup, tmp_path):
-    line, rc, dt, _ = _run1(sup, tmp_path, {"main:0:0": "fail", "main:1:0": "fail", "main:2:0": "noline"})
+    line, rc, dt, _ = _run1(sup, tmp_path, {"main:0:0": "fail", "main:1:0": "fail", "main:2:0": "noline", "main:3:0": "fail"})
     assert rc == 0
     a = line["attempts"]
-    assert [x["mode"] for x in a] == ["graph+overlap", "overlap", "one-stream", "python-twin"]
+    assert [x["mode"] for x in a] == ["resident+xgmi", "graph+overlap", "overlap", "one-stream", "python-twin"]
     assert a[0]["rc"] == 3 and "boom on rank 0" in a[0]["stderr_tail"]
     assert not a[2]["ok"] and "without a result line" in a[2]["stderr_tail"]
-    assert line["python_loop"] == "1" and line["value"] == 130.0
+    assert line["python_loop"] == "1" and line["value"] == 140.0
 
 
 def test_nothing_works_gives_a_line_that_says_so(sup, tmp_path):
@@ -101,8 +101,8 @@ def test_an_extra_leg_is_merged_and_its_failure_costs_nothing_else(sup, tmp_path
     line, rc, _, _ = _run1(sup, tmp_path, {"main:0:0": "fail"}, legs=legs)
     assert rc == 0 and line["value"] == 110.0
     ns = line["north_star_scaling"]
-    assert ns["leg"] == "north_star_scaling" and ns["graph"] == "0"     # starts in the mode the main leg succeeded in
-    assert [x["mode"] for x in ns["attempts"]] == ["overlap"]
+    assert ns["leg"] == "north_star_scaling" and ns["p2p"] == "0"     # starts in the mode the main leg succeeded in
+    assert [x["mode"] for x in ns["attempts"]] == ["graph+overlap"]
     line, rc, _, _ = _run1(sup, tmp_path, {"north_star_scaling:0:0": "hang", "north_star_scaling:1:0": "fail"}, legs=legs)
     assert rc == 0 and line["value"] == 100.0
     assert "error" in line["north_star_scaling"] and len(line["north_star_scaling"]["attempts"]) == 2
@@ -150,7 +150,7 @@ def test_world_two__one_rank_fails_and_the_other_is_not_left_hanging(tmp_path):
     r0, r1 = outs
     assert r0["rc"] == 0 and r1["rc"] == 0
     a = r0["line"]["attempts"]
-    assert [x["mode"] for x in a] == ["graph+overlap", "overlap"] and a[1]["ok"]
+    assert [x["mode"] for x in a] == ["resident+xgmi", "graph+overlap"] and a[1]["ok"]
     assert a[0].get("ended_because_a_peer_failed") and a[0]["failed_ranks"] == 1
     assert r0["line"]["value"] == 110.0 and r0["seconds"] < 30.0 and r1["seconds"] < 30.0
     assert r1["line"] == {}            # only rank 0 carries the line

@@ -73,6 +73,11 @@ class Stub:
         v = min(Stub.slots)
         Stub.barrier.wait()
         t[0] = v
+    def all_gather_object(self, out, obj):
+        Stub.slots[self.rank] = obj
+        Stub.barrier.wait()
+        for i in range(world): out[i] = Stub.slots[i]
+        Stub.barrier.wait()
 
 par = dict(dm.DEFAULT_PAR); par.update(par_over)
 if not fixed_only:
@@ -89,7 +94,9 @@ def run(r):
         n, v, gb, db, pr = C.c_int(), C.c_int(), C.c_int64(), C.c_int64(), C.c_int()
         us = C.c_double()
         pkg._check(pkg.library().exaadmm_dist_stats(bes[r].mod.handle, C.byref(n), C.byref(v), C.byref(us), C.byref(gb), C.byref(db), C.byref(pr)), "dist_stats")
-        dstats[r] = {"graph_batches": gb.value, "direct_batches": db.value, "probe": pr.value, "exchange_us": us.value}
+        dstats[r] = {"graph_batches": gb.value, "direct_batches": db.value, "probe": pr.value, "exchange_us": us.value,
+                     "p2p": bool(bes[r].p2p), "loop_kind": bes[r].mod.loop_kind(), "downgrades": bes[r].mod.loop_downgrades(),
+                     "form": bes[r].mod.resident_form()}
     except BaseException as ex:
         errs[r] = repr(ex)
 out = {"cut": int(sum(p.n_cut for p in parts)), "err": {}}
@@ -116,6 +123,7 @@ for p, be in zip(parts, bes2):
         be.upload(name, p.slice_global(st[name]))
 errs = [None] * world
 exch = [None] * world
+kinds = [None] * world
 def run2(r):
     try:
         assert bes2[r].attach_native(Stub(r))
@@ -123,8 +131,10 @@ def run2(r):
         if r == 0: out["shim_counts_before"] = shim_counts()
         Stub.barrier.wait()
         e0 = pkg.library().exaadmm_dist_exchange_count()
+        kinds[r] = [bes2[r].mod.loop_kind()]
         bes2[r].run_fixed_native(NFIX, 1, 1e3)
         exch[r] = pkg.library().exaadmm_dist_exchange_count() - e0
+        kinds[r] += [bes2[r].mod.loop_kind(), bes2[r].mod.loop_downgrades(), bes2[r].mod.resident_form()]
     except BaseException as ex:
         errs[r] = repr(ex)
 ths = [threading.Thread(target=run2, args=(r,)) for r in range(world)]
@@ -133,6 +143,7 @@ assert not any(t.is_alive() for t in ths), "a rank hung"
 assert not any(errs), errs
 out["shim_counts_after"] = shim_counts()
 out["exchanges_in_60_iterations"] = exch
+out["fixed_loop"] = kinds   # per rank: loop kind before, after, downgrades, what the run launched
 out["nfix"] = NFIX
 env3 = pkg.AdmmEnv("single", rho[0], rho[1], verbose=0, grid=g)
 m3 = pkg.ModelAcopf(env3)
@@ -170,7 +181,9 @@ def _shim():
 def _run_worker(world, case, **extra_env):
     if os.environ.get("EXAADMM_NO_SPEC") or os.environ.get("EXAADMM_BUS_KERNEL") == "lane":
         pytest.skip("the in-library loop of a partition with peers IS the two-launch speculative loop; this A/B switch turns that loop off")
-    env = dict(os.environ, EXAADMM_RCCL_LIB=_shim(), **extra_env)
+    # (the mailboxes of the resident loop -- what a partition runs when its peers can write into its memory -- are the subject of the
+    #  tests at the end of this file; everything else here is about the two-launch loop with its RCCL exchange)
+    env = dict(os.environ, EXAADMM_RCCL_LIB=_shim(), **dict({"EXAADMM_DIST_P2P": "0"}, **extra_env))
     r = subprocess.run([sys.executable, "-c", WORKER % {"root": ROOT, "world": world, "case": case}], env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
@@ -283,7 +296,7 @@ def test_bench_under_the_launcher_one_rank_dist_path():
     assert rec["n_gpus"] == 1 and rec["steps"] == 5 and rec["warmup"] == 2 and rec["value"] > 0
     want = "step-wise twin" if os.environ.get("EXAADMM_DIST_PYTHON_LOOP") else "inside the library"
     assert rec["scaling"] == "weak" and want in rec["config"]["loop"]
-    assert [a["mode"] for a in rec["attempts"]] == ["graph+overlap"] and rec["attempts"][0]["ok"]
+    assert [a["mode"] for a in rec["attempts"]] == ["resident+xgmi"] and rec["attempts"][0]["ok"]
     ns = rec["north_star_scaling"]
     assert ns["value"] > 0 and "case_ACTIVSg70k" in ns["config"]["workload"] and ns["n_gpus"] == 1 and ns["attempts"][0]["ok"]
 
@@ -297,7 +310,7 @@ def test_a_child_that_hangs_after_touching_the_gpu_costs_an_attempt_not_the_line
     rec = json.loads(r.stdout.strip().splitlines()[-1])
     a = rec["attempts"]
     assert len(a) == 2 and a[0]["rc"] != 0 and a[0]["timed_out"] and not a[0]["ok"] and a[1]["ok"], a
-    assert a[1]["mode"] == "overlap" and rec["value"] > 0 and "north_star_scaling" not in rec
+    assert a[1]["mode"] == "graph+overlap" and rec["value"] > 0 and "north_star_scaling" not in rec
 
 
 def _probe(case, iters, **extra_env):
@@ -321,3 +334,26 @@ def test_a_slow_exchange_hides_behind_the_interior_solves_of_70k_sized_areas():
     assert all(st["probe"] == 1 and st["graph_batches"] > 0 for st in base["stats"]), base
     assert slow["ms_per_iteration"] <= 1.10 * base["ms_per_iteration"], (base, slow)
     assert base["ms_per_iteration"] <= 0.95 * serial["ms_per_iteration"], (base, serial)
+
+
+# ---- the resident loop of a partition with peers (kernels.h ResidentPeers): one launch per inner loop, what crosses the ranks goes by
+#      direct stores into the peer's mailbox.  Ranks = host threads, each launching its resident kernel on the ONE GPU of this box at the same
+#      time (the sizes below fit the chip together); a peer's mailbox is mapped by address (same process; across processes: by IPC handle).
+@pytest.mark.parametrize("world,case", [(2, ""), (3, ""), (3, os.path.join(ROOT, "tests", "golden", "case118.m"))])
+def test_resident_loop_with_peers_is_the_single_handle_solve(world, case):
+    """Convergence-tested solves (same outer / cumulative iteration counts as the single handle, u / v / z / l to 1e-10, the case118
+    anchor 20 / 1232) and the fixed-count run BITWISE the single handle, replicas of the cut branches bit-identical on both owners -- with
+    every rank on the resident loop (loop kind 2 before and after, no downgrade) and NO exchange per iteration: the RCCL stand-in sees
+    one sums-only group at the end of a loop."""
+    out = _run_worker(world, case, EXAADMM_DIST_P2P="1", EXAADMM_RESIDENT_COOP="0")
+    assert out["cut"] > 0
+    assert all(st["p2p"] and st["loop_kind"] == 2 and st["downgrades"] == 0 for st in out["dist_stats"]), out["dist_stats"]
+    assert all(c == out["single"][1] for c in out["cumul"]) and all(o == out["single"][0] for o in out["outer"]), out
+    if case:
+        assert out["single"][:2] == [20, 1232], out
+    assert all(abs(m - out["single"][2]) <= 1e-10 * out["single"][2] for m in out["mismatch"]), out
+    assert all(e <= 1e-10 for e in out["err"].values()), out
+    assert all(n == 0 for n in out["fixed_nonzero_differences"].values()), out
+    assert out["n_replica_entries"] == 8 * out["cut"] and all(n == 0 for n in out["replica_differences"].values()), out
+    assert all(k[0] == 2 and k[1] == 2 and k[2] == 0 and k[3]["tiles"] == 1 and k[3]["launches"] == 1 for k in out["fixed_loop"]), out["fixed_loop"]
+    assert out["exchanges_in_60_iterations"] == [1] * world, out       # (the z / l pass that completes the last iteration: sums only)

@@ -334,7 +334,7 @@ static int dist_prepare_impl(exaadmm_handle* h, int nranks, int rank, int64_t nv
             }
             HIPCHK(hipMalloc((void**)&d->d_cut_code, code.size() * sizeof(int)));
             HIPCHK(hipMemcpy(d->d_cut_code, code.data(), code.size() * sizeof(int), hipMemcpyHostToDevice));
-            HIPCHK(hipMalloc((void**)&d->d_twin, (size_t)std::max<int64_t>(total, 1) * sizeof(unsigned long long)));
+            HIPCHK(hipMalloc((void**)&d->d_twin, (size_t)(total + nranks) * sizeof(unsigned long long)));
         }
     }
     Dev& dv = h->d;
@@ -514,7 +514,8 @@ extern "C" int exaadmm_dist_p2p_import(exaadmm_handle* h, const void* blobs, int
         }
     }
     // entry of cut (p, k) on rank p: its cut list is peer-major in rank order as well -- (cuts with ranks < us) + k
-    std::vector<unsigned long long> twin((size_t)std::max(d->n_cut, 1), 0ull);
+    // (twin addresses [0, n_cut), then this rank's sums entry in every peer's mailbox [n_cut, n_cut + nranks): one device table)
+    std::vector<unsigned long long> twin((size_t)d->n_cut + (size_t)d->nranks, 0ull);
     ResidentPeers rp = {};
     int64_t c = 0;
     for (int p = 0; p < d->nranks; p++) {
@@ -524,11 +525,12 @@ extern "C" int exaadmm_dist_p2p_import(exaadmm_handle* h, const void* blobs, int
             total_p += bl[p].ncut[q];
         }
         for (int64_t k = 0; k < d->ncut[p]; k++, c++) twin[(size_t)c] = base[p] + (unsigned long long)(before + k) * P2P_ENTRY * sizeof(double);
-        rp.sums_at[p] = (p == d->rank) ? 0ull : base[p] + (unsigned long long)(total_p + d->rank) * P2P_ENTRY * sizeof(double);
+        twin[(size_t)d->n_cut + p] = (p == d->rank) ? 0ull : base[p] + (unsigned long long)(total_p + d->rank) * P2P_ENTRY * sizeof(double);
     }
     HIPCHK(hipMemcpy(d->d_twin, twin.data(), twin.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
     rp.cut_code = d->d_cut_code;
     rp.twin = d->d_twin;
+    rp.sums_at = d->d_twin + d->n_cut;
     rp.box = d->box;
     rp.nranks = d->nranks;
     rp.rank = d->rank;
@@ -538,6 +540,29 @@ extern "C" int exaadmm_dist_p2p_import(exaadmm_handle* h, const void* blobs, int
     h->p2p_epoch = 0;
     h->p2p_ready = true;
     invalidate_graph(h);
+    return EXAADMM_OK;
+}
+
+// diagnostics (scripts/p2p_debug.py): this rank's mailbox as it is now, 16 doubles per entry
+extern "C" int exaadmm_debug_p2p_box(exaadmm_handle* h, double* out, int64_t n_doubles)
+{
+    REQUIRE(h && h->dist && h->dist->box && out, "no mailbox");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t n = std::min<size_t>((size_t)n_doubles, h->dist->box_entries * P2P_ENTRY);
+    HIPCHK(hipMemcpy(out, h->dist->box, n * sizeof(double), hipMemcpyDeviceToHost));
+    return (int)(h->dist->box_entries);
+}
+
+// diagnostics: when the last resident launch of a partition with peers started and ended on the GPU (constant 100 MHz clock)
+extern "C" int exaadmm_debug_resident_window(exaadmm_handle* h, unsigned long long* out2)
+{
+    REQUIRE(h && h->rsync.fail && out2, "no resident launch yet");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpy(out2, h->rsync.fail + 1, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    int w[4];
+    HIPCHK(hipMemcpy(w, h->rsync.contrib, sizeof(w), hipMemcpyDeviceToHost));   // contrib, decided, stop, fail
+    out2[2] = ((unsigned long long)(unsigned)w[0] << 32) | (unsigned)w[1];
+    out2[3] = ((unsigned long long)(unsigned)w[2] << 32) | (unsigned)w[3];
     return EXAADMM_OK;
 }
 

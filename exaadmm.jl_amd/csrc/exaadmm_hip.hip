@@ -1572,7 +1572,7 @@ static int resident_prepare(exaadmm_handle* h, const Ctrl* begin = nullptr)
         // arrive[B] | ready[B] | contrib, decided, stop | fail: ONE int buffer; everything but `fail` is reset in front of every
         // launch, `fail` once per call (a later launch's reset must not erase what an earlier one reported)
         int* ints = nullptr;
-        if ((rc = dev_alloc(h, &ints, 2 * (size_t)h->B + 4))) return rc;
+        if ((rc = dev_alloc(h, &ints, 2 * (size_t)h->B + 4 + 8))) return rc;   // (+ 8: diagnostics behind `fail`)
         r.arrive = ints;
         r.ready = ints + h->B;
         r.contrib = ints + 2 * (size_t)h->B;
@@ -1728,8 +1728,11 @@ static int resident_downgrade(exaadmm_handle* h)
     if ((rc = sync_check(h, true))) return rc;
     if ((rc = resident_guard(h, true))) return rc;
     h->resident_downgrades += 1;
-    if (h->opt.verbose != 0)
-        fprintf(stderr, "exaadmm: resident loop not co-resident on device %d (shared GPU?): batch repeated with the two-launch loop\n", h->device);
+    if (h->h_base && h->h_base[1] != 0)   // (a downgrade after a self check keeps that check's message)
+        set_err("resident launch did not complete on device %d (wait code %d: 1 a bus / decision of this GPU -- shared GPU? --, 2 a cut branch's twin on a peer, 3 a peer's "
+            "residual sums, 4 reported by a peer at the end of the launch, 5 a twin in the launch's last step): the call was repeated with two launches per iteration",
+                h->device, h->h_base[1]);
+    if (h->opt.verbose != 0) fprintf(stderr, "exaadmm: %s\n", g_err.c_str());
     return sync_check(h, true);
 }
 
@@ -2309,9 +2312,10 @@ static int run_fixed_impl(exaadmm_handle* h, int iters, int first_major_iter, do
     flush_bus_const(h);
     if (spec_eligible(h)) {
         // same kernels as the fused loop, with a control block that never stops
-        int rc = spec_prepare(h);
-        if (rc) return rc;
+        int rc;
         for (int attempt = 0; attempt < 2; attempt++) {
+            // (inside the loop: a partition with peers that falls back from the resident loop changes from two buffer sets to three)
+            if ((rc = spec_prepare(h))) return rc;
             Ctrl* hc = h->h_ctrl;
             memset(hc, 0, sizeof(Ctrl));
             hc->max_inner = 0x7fffffff;

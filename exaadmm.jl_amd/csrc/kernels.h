@@ -1275,7 +1275,7 @@ __device__ __forceinline__ void bus_from_rec4(const Dev& d, const double* __rest
     ti = ct / rhosum_t;
 }
 
-__device__ __forceinline__ bool resident_wait(const int* flag, int want, int* fail)
+__device__ __forceinline__ bool resident_wait(const int* flag, int want, int* fail, int code = 1)
 {
     // Polls are RELAXED agent-scope loads (an acquire poll invalidates the XCD's L2 for everybody, hundreds of waiting
     // wavefronts at a time: the working wavefronts slowed down 2.6 x).  There is NO fence behind the poll, only a compiler
@@ -1289,7 +1289,8 @@ __device__ __forceinline__ bool resident_wait(const int* flag, int want, int* fa
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
         ++spins;
         if (spins > (1 << 20) || ((spins & 255) == 0 && __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-            __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int expected = 0;   // (the FIRST failure's code stays: 1 = a bus of this GPU, 6 = the control wavefront's wait for the residual terms, 7 = its decision)
+            (void)__hip_atomic_compare_exchange_strong(fail, &expected, code, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return false;
         }
         __builtin_amdgcn_s_sleep(24);
@@ -1342,7 +1343,7 @@ __device__ __forceinline__ void resident_contribute(const ResidentSync& rs, int 
 __device__ __forceinline__ bool resident_go_on(const ResidentSync& rs, int passes_needed)
 {
     if (passes_needed <= 0) return true;
-    if (!resident_wait(rs.decided, passes_needed, rs.fail)) return false;
+    if (!resident_wait(rs.decided, passes_needed, rs.fail, 7)) return false;
     return __hip_atomic_load(rs.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
 }
 
@@ -1394,11 +1395,9 @@ struct ResidentHeavy {
 //     doubles) into our mailbox entry of that branch, and we do the same for it -- send first, then wait: no cycle;
 //   * the control wavefronts exchange their four partial residual sums the same way and add them IN RANK ORDER (the order of
 //     k_halo_unpack: the same bits and therefore the same decision in the same iteration on every rank).
-// Mailbox words are SELF-VALIDATING: 16 bytes = (value, sequence number), written and read as one 16-byte access that bypasses the
-// caches (sc0 sc1); a reader polls until the word carries the sequence number it waits for.  No flag, no fence, no ordering
-// assumption between stores -- only that an aligned 16-byte store arrives as a unit (what the LL protocols of the collective
-// libraries build on as well).  An entry is one 128-byte line: 4 words per iteration parity; a sender reuses a parity only after the
-// receiver has consumed it (its next send depends on our answer to this one).
+// Mailbox words are SELF-VALIDATING (p2p_put / p2p_get below): 8 bytes = (half a double, sequence number) in one 64-bit access at
+// system scope; a reader polls until the words carry the sequence number it waits for.  An entry is one 128-byte line: 8 words per
+// iteration parity; a sender reuses a parity only after the receiver has consumed it (its next send depends on our answer to this one).
 // Waits are capped like every wait of the loop; a failed wait ends the launch with rs.fail set, the host agrees on the outcome with
 // its peers (exaadmm_hip.hip) and every rank repeats the call with the two-launch loop.
 constexpr int P2P_MAX_RANKS = 16;
@@ -1407,29 +1406,36 @@ struct ResidentPeers {
     const int* cut_code;                        // [Lp] -1: both buses local; else (mailbox entry << 1) | (1: the TO end's bus is the peer's, 0: the FROM end's)
     const unsigned long long* twin;             // [ncut] address of the twin lane's entry in the PEER's mailbox
     double* box;                                // this rank's mailbox: ncut branch entries, then one entry per rank (residual sums)
-    unsigned long long sums_at[P2P_MAX_RANKS];  // address of OUR sums entry in rank q's mailbox
+    const unsigned long long* sums_at;          // [nranks] (device memory: lanes index it) address of OUR sums entry in rank q's mailbox
     int nranks, rank, ncut;
     int epoch;   // launches of this kind so far, the same on every rank: sequence numbers are (epoch << 12) | iteration -- unique across launches
 };
-typedef unsigned int p2p_word __attribute__((ext_vector_type(4)));
+// A mailbox WORD is 8 bytes: (32 bits of payload, 32-bit sequence number), written and read as ONE 64-bit access at system scope
+// (sc0 sc1: performed at the memory side, not in a cache of either GPU).  An aligned 64-bit store is single-copy atomic, so a
+// reader that sees the sequence number it waits for has the payload that was stored with it -- no flag, no fence, no ordering
+// assumption between stores (the LL protocol of the collective libraries).  A double travels as two words (low half, high half);
+// a message of 4 doubles = 8 words = 64 bytes = one half of a 128-byte entry (the other half: the other iteration parity).
+#ifndef EXA_P2P_SCOPE
+#define EXA_P2P_SCOPE __HIP_MEMORY_SCOPE_SYSTEM
+#endif
 __device__ __forceinline__ void p2p_put(unsigned long long addr, double v, int seq)
 {
-    p2p_word w;
-    w.x = (unsigned)__double2loint(v);
-    w.y = (unsigned)__double2hiint(v);
-    w.z = (unsigned)seq;
-    w.w = 0u;
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(addr), "v"(w) : "memory");
+    unsigned long long* const q = reinterpret_cast<unsigned long long*>(addr);
+    const unsigned long long s = (unsigned long long)(unsigned)seq << 32;
+    __hip_atomic_store(q, s | (unsigned)__double2loint(v), __ATOMIC_RELAXED, EXA_P2P_SCOPE);
+    __hip_atomic_store(q + 1, s | (unsigned)__double2hiint(v), __ATOMIC_RELAXED, EXA_P2P_SCOPE);
 }
 __device__ __forceinline__ bool p2p_get(const double* p, int seq, double& v)
 {
-    p2p_word w;
-    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(w) : "v"(p) : "memory");
-    v = __hiloint2double((int)w.y, (int)w.x);
-    return (int)w.z == seq;
+    const unsigned long long* const q = reinterpret_cast<const unsigned long long*>(p);
+    const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, EXA_P2P_SCOPE), b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, EXA_P2P_SCOPE);
+    v = __hiloint2double((int)(unsigned)b, (int)(unsigned)a);
+    return (unsigned)(a >> 32) == (unsigned)seq && (unsigned)(b >> 32) == (unsigned)seq;
 }
-// the 4 words of `entry` (parity seq & 1) carry `seq`: their values; false = the wait was capped / another wavefront has failed
-__device__ __forceinline__ bool p2p_wait4(const double* entry, int seq, int* fail, double (&out)[4])
+// (what a failed wait leaves in rs.fail -- the host reports it: 1 a bus / decision of this GPU, 2 a cut branch's twin, 3 a peer's residual
+//  sums, 4 a peer's end-of-launch status or a failure it reported, 5 a twin in the launch's last step)
+// the 4 doubles of `entry` (parity seq & 1) carry `seq`: their values; false = the wait was capped / another wavefront has failed
+__device__ __forceinline__ bool p2p_wait4(const double* entry, int seq, int* fail, double (&out)[4], int code = 2)
 {
     const double* q = entry + 8 * (seq & 1);
     int spins = 0;
@@ -1437,10 +1443,16 @@ __device__ __forceinline__ bool p2p_wait4(const double* entry, int seq, int* fai
         bool ok = true;
 #pragma unroll
         for (int k = 0; k < 4; k++) ok = p2p_get(q + 2 * k, seq, out[k]) && ok;
-        if (ok) return true;
+        if (ok) {
+            asm volatile("" ::: "memory");
+            return true;
+        }
         ++spins;
         if (spins > (1 << 20) || (fail != nullptr && (spins & 255) == 0 && __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-            if (fail != nullptr) __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (fail != nullptr) {   // (the FIRST failure's code stays)
+                int expected = 0;
+                (void)__hip_atomic_compare_exchange_strong(fail, &expected, code, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             return false;
         }
         __builtin_amdgcn_s_sleep(24);
@@ -1461,6 +1473,7 @@ __device__ __forceinline__ void p2p_send4(unsigned long long entry_addr, int seq
 __global__ void __launch_bounds__(64) k_p2p_agree(ResidentPeers rp, int* fail)
 {
     const int lane = threadIdx.x;
+    if (lane == 0) reinterpret_cast<unsigned long long*>(fail + 1)[1] = (unsigned long long)wall_clock64();   // diagnostics: the launch before us has ended
     const bool peer_lane = lane < rp.nranks && lane != rp.rank;
     const int seq = (rp.epoch << 12) | 0xfff;
     const int mine = __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1472,7 +1485,7 @@ __global__ void __launch_bounds__(64) k_p2p_agree(ResidentPeers rp, int* fail)
         // (no flag to watch: the launch's own must not cut this wait short)
         bad = !p2p_wait4(rp.box + (size_t)P2P_ENTRY * (rp.ncut + rp.nranks + lane), seq, nullptr, got) || got[0] != 0.0;
     }
-    if (__ballot(bad) != 0ull && lane == 0) __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__ballot(bad) != 0ull && lane == 0 && mine == 0) __hip_atomic_store(fail, 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <int TILES, bool HEAVY = false, bool PEERS = false>
@@ -1481,6 +1494,8 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
                                                              ResidentHeavy rh, ResidentPeers rp)
 {
     static_assert(!(PEERS && HEAVY), "heavy wavefronts are not offered to a partition with peers");
+    if (PEERS && blockIdx.x == 0 && threadIdx.x == 0)   // diagnostics: when this launch's first wavefront started (constant 100 MHz clock)
+        reinterpret_cast<unsigned long long*>(rs.fail + 1)[0] = (unsigned long long)wall_clock64();
     if (ctrl->done) return;
     const int base_iter = ctrl->base;
     const double zl_beta = ctrl->beta;
@@ -1496,7 +1511,7 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
         // ---------------- control wavefront: one decision per z / l pass
         const int npass = resident_passes(first_has_zl, iters - 1);
         for (int p = 1; p <= npass; p++) {
-            if (!resident_wait(rs.contrib, p * nwork, rs.fail)) return;
+            if (!resident_wait(rs.contrib, p * nwork, rs.fail, 6)) return;
             const int i = p - (first_has_zl ? 1 : 0);     // index whose prologue made pass p
             const double* part = rs.partials[i & 1];
             double tot[4] = {0.0, 0.0, 0.0, 0.0};
@@ -1522,7 +1537,7 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
                 const int seq = (rp.epoch << 12) | p;
                 if (peer_lane) p2p_send4(rp.sums_at[lane], seq, tot);
                 bool ok = true;
-                if (peer_lane) ok = p2p_wait4(rp.box + (size_t)P2P_ENTRY * (rp.ncut + lane), seq, rs.fail, got);
+                if (peer_lane) ok = p2p_wait4(rp.box + (size_t)P2P_ENTRY * (rp.ncut + lane), seq, rs.fail, got, 3);
                 if (__ballot(!ok) != 0ull) return;
                 double sum[4] = {0.0, 0.0, 0.0, 0.0};
                 for (int q = 0; q < rp.nranks; q++) {
@@ -1840,15 +1855,23 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
 #pragma unroll
                     for (int m = 0; m < 4; m++) rt4[m] = ld_agent(pt + m);
                 }
-                if (ccode >= 0) {   // our bus's update to the twin lane first, then the twin's to us
+                // Our bus's update to the twin lane FIRST -- every cut lane of the wavefront, in one region that only stores -- and only then
+                // the wait for the twin's.  (With the send and the wait of the two kinds of cut lanes in the two arms of one branch, a
+                // wavefront runs one arm to its end -- wait included -- before the other arm has sent: two wavefronts on two ranks that
+                // each hold both kinds then wait for each other's second arm.  Met on the first run.)
+                {
                     const int seq = (rp.epoch << 12) | i;
-                    const double* const mine = rp.box + (size_t)P2P_ENTRY * (ccode >> 1);
-                    if (rem_f) {
-                        p2p_send4(rp.twin[ccode >> 1], seq, rt4);
-                        if (!p2p_wait4(mine, seq, rs.fail, rf)) return;
-                    } else {
-                        p2p_send4(rp.twin[ccode >> 1], seq, rf);
-                        if (!p2p_wait4(mine, seq, rs.fail, rt4)) return;
+                    double out4[4], in4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int m = 0; m < 4; m++) out4[m] = rem_f ? rt4[m] : rf[m];
+                    if (ccode >= 0) p2p_send4(rp.twin[ccode >> 1], seq, out4);
+                    bool ok = true;
+                    if (ccode >= 0) ok = p2p_wait4(rp.box + (size_t)P2P_ENTRY * (ccode >> 1), seq, rs.fail, in4);
+                    if (!ok) return;
+#pragma unroll
+                    for (int m = 0; m < 4; m++) {
+                        rf[m] = rem_f ? in4[m] : rf[m];
+                        rt4[m] = rem_t ? in4[m] : rt4[m];
                     }
                 }
                 vv[0] = (ub[0] + zo[0]) + (lo[0] + rf[0]) / bd.rho_[0];
@@ -2014,15 +2037,19 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
 #pragma unroll
                 for (int m = 0; m < 4; m++) rt4[m] = ld_agent(pt + m);
             }
-            if (ccode >= 0) {
+            {   // (every cut lane sends before any of them waits: see the loop's prologue)
                 const int seq = (rp.epoch << 12) | iters;
-                const double* const mine = rp.box + (size_t)P2P_ENTRY * (ccode >> 1);
-                if (rem_f) {
-                    p2p_send4(rp.twin[ccode >> 1], seq, rt4);
-                    if (!p2p_wait4(mine, seq, rs.fail, rf)) return;
-                } else {
-                    p2p_send4(rp.twin[ccode >> 1], seq, rf);
-                    if (!p2p_wait4(mine, seq, rs.fail, rt4)) return;
+                double out4[4], in4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int m = 0; m < 4; m++) out4[m] = rem_f ? rt4[m] : rf[m];
+                if (ccode >= 0) p2p_send4(rp.twin[ccode >> 1], seq, out4);
+                bool ok = true;
+                if (ccode >= 0) ok = p2p_wait4(rp.box + (size_t)P2P_ENTRY * (ccode >> 1), seq, rs.fail, in4, 5);
+                if (!ok) return;
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    rf[m] = rem_f ? in4[m] : rf[m];
+                    rt4[m] = rem_t ? in4[m] : rt4[m];
                 }
             }
         } else {

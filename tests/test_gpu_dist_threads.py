@@ -345,7 +345,7 @@ def test_resident_loop_with_peers_is_the_single_handle_solve(world, case):
     anchor 20 / 1232) and the fixed-count run BITWISE the single handle, replicas of the cut branches bit-identical on both owners -- with
     every rank on the resident loop (loop kind 2 before and after, no downgrade) and NO exchange per iteration: the RCCL stand-in sees
     one sums-only group at the end of a loop."""
-    out = _run_worker(world, case, EXAADMM_DIST_P2P="1", EXAADMM_RESIDENT_COOP="0")
+    out = _run_worker(world, case, EXAADMM_DIST_P2P="1", EXAADMM_RESIDENT_COOP="0", GPU_MAX_HW_QUEUES="16")
     assert out["cut"] > 0
     assert all(st["p2p"] and st["loop_kind"] == 2 and st["downgrades"] == 0 for st in out["dist_stats"]), out["dist_stats"]
     assert all(c == out["single"][1] for c in out["cumul"]) and all(o == out["single"][0] for o in out["outer"]), out

@@ -163,6 +163,7 @@ struct exaadmm_handle {
 #if defined(EXA_TEST_HOOKS)
     int hook_fail_launch = 0;        // test build only: the n-th resident launch of the handle reports a failed wait
     int hook_flip_ulp = 0;           // test build only: the next resident launch's result gets one ulp added to one u entry
+    int hook_p2p_delay_ticks = 0;    // test build only: every mailbox send of the resident loop with peers leaves this many 100 MHz ticks late
 #endif
     int resident_cap2 = -1;      // the same for k_resident_t<2> (two tiles of 64 branches per wavefront)
     // resident loop of a partition WITH PEERS (kernels.h ResidentPeers; dist_native.h "mailboxes"): what crosses GPUs goes by direct
@@ -1634,7 +1635,8 @@ static int enqueue_resident(exaadmm_handle* h, int n, int loop_iter0)
         // which tiles share a wavefront in this launch: from the solver-trip counters of the last x-updates (both buffer sets)
         const ResidentTiles& t = h->rtiles;
         int* const keys = const_cast<int*>(t.tiles) + 2 * (size_t)t.wb;   // (behind the table)
-        hipLaunchKernelGGL(k_tile_keys, dim3((t.nb + 3) / 4), dim3(256), 0, h->stream, (const int*)h->sets[0].st[2], (const int*)h->sets[1].st[2], h->L, t.nb, keys);
+        hipLaunchKernelGGL(k_tile_keys, dim3((t.nb + 3) / 4), dim3(256), 0, h->stream, (const int*)h->sets[0].st[2], (const int*)h->sets[1].st[2], h->L, t.nb, keys,
+                           dist_has_peers(h) ? h->rpeers.cut_code : (const int*)nullptr);
         hipLaunchKernelGGL(k_tile_assign, dim3(1), dim3(1024), 2 * (size_t)t.nb * sizeof(int), h->stream, (const int*)keys, t.nb, t.wb, const_cast<int*>(t.tiles));
         grid = t.wb + t.wg + 1;
     }
@@ -1662,6 +1664,9 @@ static int enqueue_resident(exaadmm_handle* h, int n, int loop_iter0)
     if (peers) {
         h->p2p_epoch = (h->p2p_epoch + 1) & 0x7ffff;   // (the same count on every rank: they make the same calls)
         rp.epoch = h->p2p_epoch;
+#if defined(EXA_TEST_HOOKS)
+        rp.delay_ticks = h->hook_p2p_delay_ticks;
+#endif
     }
     const void* const kernel = peers ? (mode == 2 ? (const void*)k_resident_t<2, false, true> : (const void*)k_resident_t<1, false, true>)
                                      : (mode == 2 ? (const void*)k_resident_t<2> : (rh.n > 0 ? (const void*)k_resident_t<1, true> : (const void*)k_resident_t<1>));
@@ -2671,6 +2676,7 @@ extern "C" int exaadmm_test_hook(exaadmm_handle* h, const char* key, int64_t val
     REQUIRE(h && key, "null argument");
     if (strcmp(key, "fail_resident_launch") == 0) h->hook_fail_launch = (int)value;
     else if (strcmp(key, "flip_resident_ulp") == 0) h->hook_flip_ulp = (int)value;
+    else if (strcmp(key, "p2p_delay_us") == 0) h->hook_p2p_delay_ticks = (int)(100 * value);
     else {
         set_err("unknown test hook %s", key);
         return EXAADMM_ERR_INVALID;

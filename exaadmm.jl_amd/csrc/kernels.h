@@ -1409,6 +1409,7 @@ struct ResidentPeers {
     const unsigned long long* sums_at;          // [nranks] (device memory: lanes index it) address of OUR sums entry in rank q's mailbox
     int nranks, rank, ncut;
     int epoch;   // launches of this kind so far, the same on every rank: sequence numbers are (epoch << 12) | iteration -- unique across launches
+    int delay_ticks;   // test build only (-DEXA_TEST_HOOKS, exaadmm_test_hook "p2p_delay_us"): every send waits this many 100 MHz ticks first
 };
 // A mailbox WORD is 8 bytes: (32 bits of payload, 32-bit sequence number), written and read as ONE 64-bit access at system scope
 // (sc0 sc1: performed at the memory side, not in a cache of either GPU).  An aligned 64-bit store is single-copy atomic, so a
@@ -1458,8 +1459,16 @@ __device__ __forceinline__ bool p2p_wait4(const double* entry, int seq, int* fai
         __builtin_amdgcn_s_sleep(24);
     }
 }
-__device__ __forceinline__ void p2p_send4(unsigned long long entry_addr, int seq, const double (&v)[4])
+__device__ __forceinline__ void p2p_send4(unsigned long long entry_addr, int seq, const double (&v)[4], int delay_ticks = 0)
 {
+#if defined(EXA_TEST_HOOKS)
+    if (delay_ticks > 0) {   // a slow link: the message leaves `delay_ticks` late (tests/test_gpu_dist_threads.py: what does an iteration lose?)
+        const long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < (long long)delay_ticks) __builtin_amdgcn_s_sleep(8);
+    }
+#else
+    (void)delay_ticks;
+#endif
     const unsigned long long q = entry_addr + 64ull * (unsigned)(seq & 1);
 #pragma unroll
     for (int k = 0; k < 4; k++) p2p_put(q + 16ull * k, v[k], seq);
@@ -1535,7 +1544,7 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
                 double got[4] = {0.0, 0.0, 0.0, 0.0};
                 const bool peer_lane = lane < rp.nranks && lane != rp.rank;
                 const int seq = (rp.epoch << 12) | p;
-                if (peer_lane) p2p_send4(rp.sums_at[lane], seq, tot);
+                if (peer_lane) p2p_send4(rp.sums_at[lane], seq, tot, rp.delay_ticks);
                 bool ok = true;
                 if (peer_lane) ok = p2p_wait4(rp.box + (size_t)P2P_ENTRY * (rp.ncut + lane), seq, rs.fail, got, 3);
                 if (__ballot(!ok) != 0ull) return;
@@ -1864,7 +1873,7 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
                     double out4[4], in4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                     for (int m = 0; m < 4; m++) out4[m] = rem_f ? rt4[m] : rf[m];
-                    if (ccode >= 0) p2p_send4(rp.twin[ccode >> 1], seq, out4);
+                    if (ccode >= 0) p2p_send4(rp.twin[ccode >> 1], seq, out4, rp.delay_ticks);
                     bool ok = true;
                     if (ccode >= 0) ok = p2p_wait4(rp.box + (size_t)P2P_ENTRY * (ccode >> 1), seq, rs.fail, in4);
                     if (!ok) return;
@@ -2042,7 +2051,7 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
                 double out4[4], in4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int m = 0; m < 4; m++) out4[m] = rem_f ? rt4[m] : rf[m];
-                if (ccode >= 0) p2p_send4(rp.twin[ccode >> 1], seq, out4);
+                if (ccode >= 0) p2p_send4(rp.twin[ccode >> 1], seq, out4, rp.delay_ticks);
                 bool ok = true;
                 if (ccode >= 0) ok = p2p_wait4(rp.box + (size_t)P2P_ENTRY * (ccode >> 1), seq, rs.fail, in4, 5);
                 if (!ok) return;
@@ -2139,12 +2148,17 @@ __global__ void __launch_bounds__(1024) k_heavy_select(const int* __restrict__ t
 // k_tile_keys -- one wavefront per tile: key[tile] = largest solver-trip count of the tile's lanes in the last accepted x-updates
 // (both buffer sets; coalesced reads, wave maximum); k_tile_assign -- one block: tiles ranked by key (ties by index), the
 // S = 2 wb - nb heaviest get a wavefront each, the other 2 (nb - wb) are paired heaviest with lightest, the heavier of a pair first.
-__global__ void __launch_bounds__(256) k_tile_keys(const int* __restrict__ ticks0, const int* __restrict__ ticks1, int L, int nb, int* __restrict__ key)
+// cut_code (a partition with peers, else nullptr): a tile that holds a cut branch ranks in front of every tile that holds none -- it gets
+// a wavefront of its own or is the FIRST tile of its wavefront, so that its lanes' sends to the twin lanes never sit behind another
+// tile's wait for a peer (two wavefronts on two ranks, each waiting in its first tile for what the other sends in its second: a cycle)
+__global__ void __launch_bounds__(256) k_tile_keys(const int* __restrict__ ticks0, const int* __restrict__ ticks1, int L, int nb, int* __restrict__ key,
+                                                   const int* __restrict__ cut_code)
 {
     const int t = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (t >= nb) return;
     const int b = t * BR_BLOCK + lane;
     int k = (b < L) ? max(ticks0[b], ticks1[b]) : 0;
+    if (cut_code != nullptr && b < L && cut_code[b] >= 0) k |= 0x100000;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) k = max(k, __shfl_down(k, off, 64));
     if (lane == 0) key[t] = k;

@@ -73,6 +73,8 @@ def run(r):
     try:
         assert bes[r].attach_native(Stub(r))
         lib, h = pkg.library(), bes[r].mod.handle
+        if os.environ.get("P2P_DELAY_US"):   # (test build of the library: every mailbox send of the resident loop leaves this late)
+            bes[r].mod.test_hook("p2p_delay_us", int(os.environ["P2P_DELAY_US"]))
         bes[r].run_fixed_native(PREP, 1, 1e3)
         pkg._check(lib.exaadmm_state_save(h), "state_save")
         for rep in range(3):
@@ -85,7 +87,9 @@ def run(r):
         n, v, g_, d_, pr = C.c_int(), C.c_int(), C.c_int64(), C.c_int64(), C.c_int()
         us = C.c_double()
         pkg._check(lib.exaadmm_dist_stats(h, C.byref(n), C.byref(v), C.byref(us), C.byref(g_), C.byref(d_), C.byref(pr)), "dist_stats")
-        stats[r] = {"exchange_us": us.value, "graph_batches": g_.value, "direct_batches": d_.value, "probe": pr.value}
+        stats[r] = {"exchange_us": us.value, "graph_batches": g_.value, "direct_batches": d_.value, "probe": pr.value,
+                    "mailboxes": bool(bes[r].p2p), "loop_kind": bes[r].mod.loop_kind(), "downgrades": bes[r].mod.loop_downgrades(),
+                    "resident_form": bes[r].mod.resident_form()}
     except BaseException as ex:
         errs[r] = repr(ex)
         try:

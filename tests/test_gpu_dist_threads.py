@@ -314,7 +314,8 @@ def test_a_child_that_hangs_after_touching_the_gpu_costs_an_attempt_not_the_line
 
 
 def _probe(case, iters, **extra_env):
-    env = dict(os.environ, EXAADMM_RCCL_LIB=_shim(), RCCL_SHIM_ASYNC="1", GPU_MAX_HW_QUEUES="16", **extra_env)
+    # (the two-launch loop with its RCCL exchange is what these probes time: mailboxes off unless a probe asks for them)
+    env = dict(os.environ, EXAADMM_RCCL_LIB=_shim(), RCCL_SHIM_ASYNC="1", GPU_MAX_HW_QUEUES="16", **dict({"EXAADMM_DIST_P2P": "0"}, **extra_env))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "dist_overlap_probe.py"), "2", case, str(iters)], env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])

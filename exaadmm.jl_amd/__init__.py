@@ -170,6 +170,7 @@ def library():
     L.exaadmm_download_branch_counters.argtypes = [H, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                                    C.POINTER(C.c_int32), C.c_int64]
     L.exaadmm_branch_kernel_occupancy.argtypes = [H, C.POINTER(C.c_int)]
+    L.exaadmm_download_tile_trips.argtypes = [H, C.POINTER(C.c_int32), C.c_int64]
     L.exaadmm_loop_kind.argtypes = [H, C.POINTER(C.c_int)]
     L.exaadmm_loop_downgrades.argtypes = [H, C.POINTER(C.c_int)]
     L.exaadmm_resident_form.argtypes = [H, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -491,6 +492,13 @@ class ModelAcopf(_HandleOptions):
         _check(library().exaadmm_download_branch_counters(self._h, a.ctypes.data_as(ip), m.ctypes.data_as(ip),
                                                           t.ctypes.data_as(ip), self.nline), "branch counters")
         return a, m, t
+
+    def tile_trips(self):
+        """per tile of 64 branches in storage order (= per wavefront): largest solver-trip count of its lanes in the last x-update"""
+        n = (self.nline + 63) // 64
+        out = np.zeros(n, dtype=np.int32)
+        _check(library().exaadmm_download_tile_trips(self._h, out.ctypes.data_as(C.POINTER(C.c_int32)), n), "exaadmm_download_tile_trips")
+        return out
 
     def loop_kind(self):
         """0 = four launches per iteration, 1 = two (speculative loop), 2 = resident loop (one launch per batch of iterations)"""

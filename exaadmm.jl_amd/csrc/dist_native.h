@@ -69,6 +69,8 @@ struct exaadmm_dist {
     size_t box_entries = 0;
     int *d_cut_code = nullptr;
     unsigned long long* d_twin = nullptr;
+    unsigned xcount = 0;       // host-issued sums exchanges through the mailboxes so far (the same on every rank)
+    int* d_xfail = nullptr;    // a host-issued exchange that found no peer leaves 1 here
     std::vector<void*> ipc_opened;
     int64_t graph_batches = 0, direct_batches = 0;
     int probe_result = -1;   // -1 not run, 0 capture refused (direct enqueue), 1 captured exchange replayed correctly
@@ -226,7 +228,7 @@ extern "C" int exaadmm_dist_detach(exaadmm_handle* h)
     for (hipEvent_t e : d->xev)
         if (e) (void)hipEventDestroy(e);
     if (d->xstream) (void)hipStreamDestroy(d->xstream);
-    void* bufs[] = {d->send, d->recv, d->local, d->d_pos, d->d_off, d->d_rcode, d->d_rpos, d->box, d->d_cut_code, d->d_twin};
+    void* bufs[] = {d->send, d->recv, d->local, d->d_pos, d->d_off, d->d_rcode, d->d_rpos, d->box, d->d_cut_code, d->d_twin, d->d_xfail};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (void* q : d->ipc_opened) (void)hipIpcCloseMemHandle(q);
@@ -315,7 +317,7 @@ static int dist_prepare_impl(exaadmm_handle* h, int nranks, int rank, int64_t nv
         // the mailbox of the resident loop: one 128-byte entry per cut branch (in the order of the cut lists), then one per rank for the
         // residual sums and one per rank for the end-of-launch status.  Fine-grained device memory: stores from a peer GPU become
         // visible to a running kernel here.  cut_code[storage slot] = (entry << 1) | (1: the TO end's bus is the peer's)
-        d->box_entries = (size_t)total + 2 * (size_t)nranks;
+        d->box_entries = (size_t)total + 3 * (size_t)nranks;   // cut branches | residual sums | end-of-launch status | host-issued sums exchanges
         void* bx = nullptr;
         hipError_t e = hipExtMallocWithFlags(&bx, d->box_entries * P2P_ENTRY * sizeof(double), hipDeviceMallocFinegrained);
         if (e != hipSuccess) {   // (no fine-grained memory on this system: the partition keeps the two-launch loop)
@@ -335,6 +337,8 @@ static int dist_prepare_impl(exaadmm_handle* h, int nranks, int rank, int64_t nv
             HIPCHK(hipMalloc((void**)&d->d_cut_code, code.size() * sizeof(int)));
             HIPCHK(hipMemcpy(d->d_cut_code, code.data(), code.size() * sizeof(int), hipMemcpyHostToDevice));
             HIPCHK(hipMalloc((void**)&d->d_twin, (size_t)(total + nranks) * sizeof(unsigned long long)));
+            HIPCHK(hipMalloc((void**)&d->d_xfail, sizeof(int)));
+            HIPCHK(hipMemset(d->d_xfail, 0, sizeof(int)));
         }
     }
     Dev& dv = h->d;
@@ -575,6 +579,14 @@ extern "C" int64_t exaadmm_dist_exchange_count(void) { return g_exchanges; }
 static int dist_exchange(exaadmm_handle* h, const Dev& dv, bool with_v, Ctrl* c, double* out, int sums_mode, hipStream_t stream)
 {
     exaadmm_dist* d = h->dist;
+    if (!with_v && h->p2p_ready && h->opt.dist_p2p != 0 && h->resident_downgrades == 0) {
+        // sums only, and the peers' mailboxes are mapped: one wavefront instead of pack kernel + grouped send / receive + unpack kernel
+        // (k_halo_pack_sums has just filled halo_local with this rank's four sums -- read from there)
+        d->xcount += 1;
+        hipLaunchKernelGGL(k_p2p_exchange4, dim3(1), dim3(64), 0, stream, h->rpeers, d->xcount, (const double*)dv.halo_local, c, out, sums_mode, d->d_xfail);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     REQUIRE(d->comm != nullptr, "partition has peers but no communicator (exaadmm_dist_connect)");
     NCCLCHK(d, d->api.GroupStart());
     ncclResult_t bad = ncclSuccess;

@@ -1413,6 +1413,27 @@ extern "C" int exaadmm_download_branch_counters(exaadmm_handle* h, int32_t* a, i
     return EXAADMM_OK;
 }
 
+// per tile of 64 branches IN STORAGE ORDER (= per wavefront of the branch launch / the resident loop): the largest number of solver-loop
+// trips any of its lanes made in the last x-update -- what the wavefront executed.  bench.py / scripts/wave_trips.py: instructions per
+// wavefront trip = SQ_INSTS_VALU of the launch / the sum of these
+extern "C" int exaadmm_download_tile_trips(exaadmm_handle* h, int32_t* out, int64_t ntiles)
+{
+    REQUIRE(h && out && ntiles == (int64_t)(h->Lp / BR_BLOCK), "buffer must hold one entry per tile of 64 branches");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    std::vector<int> t(h->Lp);
+    HIPCHK(hipMemcpy(t.data(), h->d.st_ticks, (size_t)h->Lp * sizeof(int), hipMemcpyDeviceToHost));
+    for (int64_t q = 0; q < ntiles; q++) {
+        int m = 0;
+        for (int k = 0; k < BR_BLOCK; k++) {
+            const int b = (int)q * BR_BLOCK + k;
+            if (b < h->L) m = std::max(m, t[b]);
+        }
+        out[q] = m;
+    }
+    return EXAADMM_OK;
+}
+
 // Resident wavefronts per SIMD the branch kernel's register / LDS footprint allows (occupancy API, 64-thread
 // blocks: blocks per CU / 4 SIMDs).  Diagnostics for bench.py's roofline block.
 extern "C" int exaadmm_branch_kernel_occupancy(exaadmm_handle* h, int* waves_per_simd)

@@ -353,8 +353,12 @@ __global__ void __launch_bounds__(64) k_gen_ramp(Dev d, BranchOptions o, double 
 // has just completed for it -- intact.
 // A partition (multi-GPU) solves the cut branches it shares with a peer as well (bit-identical replicas on
 // both owners): branches at or past d.Lown run the same prologue and solve, but add nothing to the residual sums.
+// (EXA_BR_WAVES: experiment switch, profiles/r05_two_waves_budget.txt -- wavefronts per SIMD the register allocator must leave room for)
+#ifndef EXA_BR_WAVES
+#define EXA_BR_WAVES 1
+#endif
 template <bool MP, bool ZL = false>
-__global__ void __launch_bounds__(BR_BLOCK, 1) k_branch_t(const Dev* __restrict__ dp, BranchOptions o, double scale, int major_iter, Ctrl* ctrl,
+__global__ void __launch_bounds__(BR_BLOCK, EXA_BR_WAVES) k_branch_t(const Dev* __restrict__ dp, BranchOptions o, double scale, int major_iter, Ctrl* ctrl,
                                                            int gen_blocks, int spec_j, double baseMVA)   // (all inside the 16 preloaded SGPRs)
 {
 #if defined(EXA_PROFILE_PHASES)
@@ -1495,6 +1499,53 @@ __global__ void __launch_bounds__(64) k_p2p_agree(ResidentPeers rp, int* fail)
         bad = !p2p_wait4(rp.box + (size_t)P2P_ENTRY * (rp.ncut + rp.nranks + lane), seq, nullptr, got) || got[0] != 0.0;
     }
     if (__ballot(bad) != 0ull && lane == 0 && mine == 0) __hip_atomic_store(fail, 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The sums-only exchange of a partition whose peers' mailboxes are mapped (the z / l pass that completes a loop's last iteration; ||z|| of
+// the outer loop): what k_halo_pack_sums + the grouped ncclSend / ncclRecv + k_halo_unpack do on the two-launch loop, in one wavefront
+// through the mailboxes -- every rank's four sums to every rank, added IN RANK ORDER, then the loop control advanced or the totals
+// delivered.  Host-issued exchanges have entries of their own (behind the status entries) and sequence numbers 0x80000000 | count,
+// whose parity alternates the two halves of an entry.  sums_mode as k_halo_unpack: 0 add, 1 only if ctrl->pending says so.
+// A wait that runs into its cap leaves *xfail = 1 (the host fails the call: the peers are gone).
+__global__ void __launch_bounds__(64) k_p2p_exchange4(ResidentPeers rp, unsigned xcount, const double* __restrict__ mine4, Ctrl* ctrl, double* out, int sums_mode, int* xfail)
+{
+    if (ctrl != nullptr && ctrl->done) return;
+    if (sums_mode == 1 && ctrl != nullptr && !ctrl->pending) return;
+    const int lane = threadIdx.x;
+    const bool peer_lane = lane < rp.nranks && lane != rp.rank;
+    const int seq = (int)(0x80000000u | xcount);
+    double mine[4], got[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < 4; j++) mine[j] = mine4[j];
+    if (peer_lane) p2p_send4(rp.sums_at[lane] + 256ull * (unsigned)rp.nranks, seq, mine, rp.delay_ticks);
+    bool ok = true;
+    if (peer_lane) ok = p2p_wait4(rp.box + (size_t)P2P_ENTRY * (rp.ncut + 2 * rp.nranks + lane), seq, nullptr, got);
+    if (__ballot(!ok) != 0ull) {   // a peer is gone: the failure must be visible in what the caller reads -- the sums become NaN, the loop ends
+        if (lane == 0) {
+            *xfail = 1;
+            const double nan = __longlong_as_double(0x7ff8000000000000ll);
+            if (out != nullptr) out[0] = out[1] = out[2] = out[3] = nan;
+            if (ctrl != nullptr) {
+                ctrl->res[0] = ctrl->res[1] = ctrl->res[2] = ctrl->res[3] = nan;
+                ctrl->done = 1;
+            }
+        }
+        return;
+    }
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int q = 0; q < rp.nranks; q++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const double gq = __shfl(got[j], q, 64);
+            s[j] += (q == rp.rank) ? mine[j] : gq;
+        }
+    }
+    if (lane != 0) return;
+    if (out != nullptr) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) out[j] = s[j];
+    }
+    if (ctrl != nullptr) ctrl_advance(ctrl, s);
 }
 
 template <int TILES, bool HEAVY = false, bool PEERS = false>

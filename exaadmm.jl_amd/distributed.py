@@ -237,7 +237,7 @@ class HipBackend:
     # ---- distributed loop inside the library (csrc/dist_native.h): RCCL called from C++ on the handle's own stream
     native = False
 
-    def attach_native(self, dist):
+    def attach_native(self, dist, connect=True):
         """Collective over the ranks of `dist` (torch.distributed, used only to hand the 128-byte RCCL id around and
         to agree on failures): creates the library-side communicator and message buffers.  From here on run_inner /
         run_fixed / norm_z run inside the library.  Returns False -- on EVERY rank, with the handle back on torch's
@@ -276,7 +276,9 @@ class HipBackend:
         if not all_ok(err is None):
             return fail("exaadmm_dist_prepare", err)
         one_rank_comm = world == 1 and os.environ.get("EXAADMM_DIST_ONE_RANK_COMM")   # tests: a real one-rank communicator
-        if world > 1 or one_rank_comm:
+        # connect = False: no RCCL communicator at all -- the partition then lives on its peers' mailboxes alone (resident loop, sums
+        # through the mailboxes) and has no two-launch loop to fall back to (tests: two PROCESSES on one GPU, where RCCL refuses to connect)
+        if (world > 1 and connect) or one_rank_comm:
             # phase 2: the id (rank 0), agreed on before anybody enters ncclCommInitRank
             ident = [None]
             if rank == 0:

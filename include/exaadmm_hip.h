@@ -151,6 +151,9 @@ int exaadmm_branch_stats(exaadmm_handle *h, double *avg_auglag_it, double *avg_m
 /* per-branch work counters of the last x-update: augmented-Lagrangian iterations, TRON minor
  * iterations (summed), solver-loop trips of the lane (divergence diagnostics) */
 int exaadmm_download_branch_counters(exaadmm_handle *h, int32_t *auglag_it, int32_t *minor_it, int32_t *ticks, int64_t nline);
+/* per tile of 64 branches in the device's storage order (= per wavefront of the branch launch): the largest solver-trip count of its
+ * lanes in the last x-update; ntiles = ceil(nline / 64) */
+int exaadmm_download_tile_trips(exaadmm_handle *h, int32_t *out, int64_t ntiles);
 /* resident wavefronts per SIMD that the branch kernel's register / LDS footprint allows (occupancy API) */
 int exaadmm_branch_kernel_occupancy(exaadmm_handle *h, int *waves_per_simd);
 /* which form of the inner loop exaadmm_run_inner / _run_fixed / _solve_two_level use on this handle (diagnostic):

@@ -661,7 +661,7 @@ EXA_HD void branch_solve(D& d, const BranchOptions& o, const MuPowTable& pw, dou
         stats.cyc[4] += EXA_TICK() - t4;
 #if defined(EXA_PROFILE_PHASES) && defined(__HIP_DEVICE_COMPILE__)
         if (stats.tl && ticks <= 127) stats.tl[ticks] = EXA_TICK() & 0x00ffffffffffffffull;  // end mark, overwritten by the next tick
-        if (n_active != 1) {
+        if (n_active != 1 && !CLONES) {   // (a heavy wavefront -- 64 clones of ONE solve -- keeps every trip: that IS its latency)
             EXA_UNROLL
             for (int k = 0; k < 5; k++) stats.cyc[k] = keep_c[k];
             EXA_UNROLL

@@ -1747,6 +1747,9 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
                 d.st_auglag[b] = st.auglag_it;
                 d.st_minor[b] = st.minor_it;
                 d.st_ticks[b] = st.ticks;
+#if defined(EXA_PROFILE_PHASES)
+                for (int q = 0; q < 13; q++) d.st_cyc[q * d.Lp + b] = st.cyc[q] + (q == 12 ? 1000ull : 0ull);   // (phase clocks of the heavy wavefront's last solve; entry 12 = 1000 + trips marks it)
+#endif
                 double* const tm = rs.terms[(i + 1) & 1];
                 {
                     double* q = tm + 4 * (size_t)rec_from;

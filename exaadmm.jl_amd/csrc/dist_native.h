@@ -766,6 +766,7 @@ static int dist_probe(exaadmm_handle* h)
     d->graph_ok = (exec != nullptr);
     d->probe_result = d->graph_ok ? 1 : 0;
     if (exec) (void)hipGraphExecDestroy(exec);
+    g_err.clear();   // (a library that refused the capture has left its message: handled here, not an error of the attach)
     return EXAADMM_OK;
 }
 

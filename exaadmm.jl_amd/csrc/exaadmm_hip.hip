@@ -71,7 +71,8 @@ extern "C" int exaadmm_dist_detach(exaadmm_handle* h);
 // environment variable of its own: a host that wants its switches from the environment translates them.
 struct Options {
     int bus_kernel_lane = 0, graph = 1, spec = 1, mp_spec = 1, rec = 1;
-    int resident = 1, resident_tiles = 1, resident_coop = 1, heavy = 1, heavy_from = 64;
+    int resident = 1, resident_tiles = 1, resident_coop = 1, heavy = 1, heavy_from = 64, heavy_max = 512, heavy_select_small = 0;
+    int resident_cap_limit = 0;   // > 0: pretend the chip holds no more resident wavefronts than this (tests: the two-tile form on small grids)
     int dist_overlap = 1, dist_graph = 1, dist_p2p = 1;
     int trust_resident = 0, verbose = 0;
     int prof_resident = 0;   // diagnostic build (-DEXA_PROFILE_PHASES): phase clocks of the resident loop's lanes instead of k_branch_t's timelines
@@ -1500,8 +1501,14 @@ static int resident_capacity(exaadmm_handle* h)
             // (the forms a partition with peers runs must be resident as well: the smaller figure counts)
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, (k_resident_t<1, false, true>), BR_BLOCK, 0) == hipSuccess)
                 h->resident_cap = std::min(h->resident_cap, std::max(0, std::min(blocks, 4) * prop.multiProcessorCount - 8));
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, (k_resident_t<1, true, true>), BR_BLOCK, 0) == hipSuccess)
+                h->resident_cap = std::min(h->resident_cap, std::max(0, std::min(blocks, 4) * prop.multiProcessorCount - 8));
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, (k_resident_t<2, false, true>), BR_BLOCK, 0) == hipSuccess)
                 h->resident_cap2 = std::min(h->resident_cap2, std::max(0, std::min(blocks, 4) * prop.multiProcessorCount - 8));
+        }
+        if (h->opt.resident_cap_limit > 0) {
+            h->resident_cap = std::min(h->resident_cap, h->opt.resident_cap_limit);
+            h->resident_cap2 = std::min(h->resident_cap2, h->opt.resident_cap_limit);
         }
         (void)hipGetLastError();
         // a cooperative launch makes the runtime check co-residency against its own occupancy figure and refuse what does
@@ -1609,7 +1616,7 @@ static int resident_prepare(exaadmm_handle* h, const Ctrl* begin = nullptr)
             HIPCHK(hipMemsetAsync(r.terms[q], 0, 4 * h->nrec_slots * sizeof(double), h->stream));
         }
     }
-    if (resident_mode(h) == 1 && !h->rheavy.list && !dist_has_peers(h)) {
+    if (resident_mode(h) == 1 && !h->rheavy.list) {
         // wavefronts of their own for the branches with the most solver trips: as many as the launch leaves SIMDs idle (at most 512)
         const int spare = resident_capacity(h) - (branch_blocks(h) + gen_blocks(h) + 1);
         h->heavy_max = std::max(0, std::min(512, spare));
@@ -1669,11 +1676,12 @@ static int enqueue_resident(exaadmm_handle* h, int n, int loop_iter0)
     // without them (profiles/r04_heavy_wavefronts.txt: +8.6 % in the steady state, -2.7 % over a whole solve if always on).
     const bool heavy_rule = (h->force_heavy >= 0) ? (h->force_heavy != 0) : (loop_iter0 >= h->opt.heavy_from && h->opt.heavy != 0);
     const bool peers = dist_has_peers(h);
-    if (mode == 1 && heavy_rule && h->heavy_max > 0 && !peers) {
+    if (mode == 1 && heavy_rule && std::min(h->heavy_max, h->opt.heavy_max) > 0) {
         // which branches get a wavefront of their own in this launch: from the solver-trip counters of the last x-updates (both buffer sets)
-        rh.n = h->heavy_max;
-        hipLaunchKernelGGL(k_heavy_select, dim3(1), dim3(1024), 0, h->stream, (const int*)h->sets[0].st[2], (const int*)h->sets[1].st[2], h->L, h->Lp, rh.n,
-                           const_cast<int*>(rh.list), const_cast<int*>(rh.flag), (const double*)h->d.z, (const double*)h->d.l, 2 * h->Gp, const_cast<double*>(rh.init));
+        rh.n = std::min(h->heavy_max, h->opt.heavy_max);
+        hipLaunchKernelGGL(k_heavy_select, dim3(1), dim3(h->opt.heavy_select_small != 0 ? 64 : 1024), 0, h->stream, (const int*)h->sets[0].st[2], (const int*)h->sets[1].st[2], h->L, h->Lp, rh.n,
+                           const_cast<int*>(rh.list), const_cast<int*>(rh.flag), (const double*)h->d.z, (const double*)h->d.l, 2 * h->Gp, const_cast<double*>(rh.init),
+                           peers ? h->rpeers.cut_code : (const int*)nullptr);
         grid += rh.n;
     }
     h->form_tiles = mode;
@@ -1689,7 +1697,7 @@ static int enqueue_resident(exaadmm_handle* h, int n, int loop_iter0)
         rp.delay_ticks = h->hook_p2p_delay_ticks;
 #endif
     }
-    const void* const kernel = peers ? (mode == 2 ? (const void*)k_resident_t<2, false, true> : (const void*)k_resident_t<1, false, true>)
+    const void* const kernel = peers ? (mode == 2 ? (const void*)k_resident_t<2, false, true> : (rh.n > 0 ? (const void*)k_resident_t<1, true, true> : (const void*)k_resident_t<1, false, true>))
                                      : (mode == 2 ? (const void*)k_resident_t<2> : (rh.n > 0 ? (const void*)k_resident_t<1, true> : (const void*)k_resident_t<1>));
     const Dev *d0 = h->d_dspec[0][0], *d1 = h->d_dspec[1][0];
     double scale = h->par.scale, base = h->baseMVA;
@@ -2644,7 +2652,7 @@ const OptKey OPT_KEYS[] = {
     {"bus_kernel_lane", &Options::bus_kernel_lane, 0, 1}, {"graph", &Options::graph, 0, 1}, {"spec", &Options::spec, 0, 1},
     {"mp_spec", &Options::mp_spec, 0, 1}, {"rec", &Options::rec, 0, 1}, {"resident", &Options::resident, 0, 1},
     {"resident_tiles", &Options::resident_tiles, 0, 1}, {"resident_coop", &Options::resident_coop, 0, 1}, {"heavy", &Options::heavy, 0, 1},
-    {"heavy_from", &Options::heavy_from, 0, 1 << 30}, {"dist_overlap", &Options::dist_overlap, 0, 1}, {"dist_graph", &Options::dist_graph, 0, 1}, {"dist_p2p", &Options::dist_p2p, 0, 1},
+    {"heavy_from", &Options::heavy_from, 0, 1 << 30}, {"heavy_max", &Options::heavy_max, 0, 512}, {"heavy_select_small", &Options::heavy_select_small, 0, 1}, {"resident_cap_limit", &Options::resident_cap_limit, 0, 1 << 20}, {"dist_overlap", &Options::dist_overlap, 0, 1}, {"dist_graph", &Options::dist_graph, 0, 1}, {"dist_p2p", &Options::dist_p2p, 0, 1},
     {"trust_resident", &Options::trust_resident, 0, 1}, {"verbose", &Options::verbose, 0, 1}, {"prof_resident", &Options::prof_resident, 0, 1},
 };
 }  // namespace

@@ -1553,7 +1553,8 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
                                                              Ctrl* ctrl, int gen_blocks, double baseMVA, int iters, ResidentSync rs, ResidentTiles rt,
                                                              ResidentHeavy rh, ResidentPeers rp)
 {
-    static_assert(!(PEERS && HEAVY), "heavy wavefronts are not offered to a partition with peers");
+    // (PEERS && HEAVY: heavy wavefronts take INTERIOR branches only -- k_heavy_select passes the cut branches by --, so a heavy wavefront
+    //  never talks to a peer and its code is the same with and without peers)
     if (PEERS && blockIdx.x == 0 && threadIdx.x == 0)   // diagnostics: when this launch's first wavefront started (constant 100 MHz clock)
         reinterpret_cast<unsigned long long*>(rs.fail + 1)[0] = (unsigned long long)wall_clock64();
     if (ctrl->done) return;
@@ -1918,6 +1919,11 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
 #pragma unroll
                     for (int m = 0; m < 4; m++) rt4[m] = ld_agent(pt + m);
                 }
+                if (TILES == 1 && HEAVY && heavy_lane) {   // (as without peers: u of the last iteration from the branch's heavy wavefront)
+                    const double* const ho = rh.u + ((size_t)((i - 1) & 1) * nheavy + rec_to) * 16;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) ub[k] = ld_agent(ho + k);
+                }
                 // Our bus's update to the twin lane FIRST -- every cut lane of the wavefront, in one region that only stores -- and only then
                 // the wait for the twin's.  (With the send and the wait of the two kinds of cut lanes in the two arms of one branch, a
                 // wavefront runs one arm to its end -- wait included -- before the other arm has sent: two wavefronts on two ranks that
@@ -2060,8 +2066,9 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
             ts[5] = __builtin_amdgcn_s_memtime();   // results and terms stored
 #endif
             if (PEERS) {
-                if (lane_on && !rem_f) resident_arrive(d, rs, bus4.x, bus4.y, i + 1);
-                if (lane_on && !rem_t) resident_arrive(d, rs, bus4.z, bus4.w, i + 1);
+                const bool solved_here = lane_on && !(TILES == 1 && HEAVY && rec_from < 0 && ccode < 0);   // (a heavy wavefront's branch arrives from there)
+                if (solved_here && !rem_f) resident_arrive(d, rs, bus4.x, bus4.y, i + 1);
+                if (solved_here && !rem_t) resident_arrive(d, rs, bus4.z, bus4.w, i + 1);
             } else if (lane_on && !(TILES == 1 && HEAVY && rec_from < 0)) {
                 resident_arrive(d, rs, bus4.x, bus4.y, i + 1);
                 resident_arrive(d, rs, bus4.z, bus4.w, i + 1);
@@ -2158,18 +2165,21 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
 // Which wavefront gets which branch is left to the order of the atomics: every branch is solved the same way wherever it runs.
 // init[w][0..7] = z, [8..15] = l of that branch as the launch finds them: the branch's lane overwrites both in place with the z / l pass
 // of the launch's first index, possibly before the heavy wavefront has looked (seen: ulp-level differences in a handful of branches).
+// cut_code (a partition with peers, else nullptr): cut branches are passed by -- their lanes talk to the peers, a heavy wavefront never does.
 __global__ void __launch_bounds__(1024) k_heavy_select(const int* __restrict__ ticks0, const int* __restrict__ ticks1, int L, int Lp, int nmax,
                                                        int* __restrict__ list, int* __restrict__ flag, const double* __restrict__ z,
-                                                       const double* __restrict__ l, int elem0, double* __restrict__ init)
+                                                       const double* __restrict__ l, int elem0, double* __restrict__ init, const int* __restrict__ cut_code)
 {
     __shared__ int hist[64];
     __shared__ int thr, count;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, nthreads = blockDim.x;   // (1 024 threads; 64 on request: one wavefront finds a free SIMD on a GPU that other
+                                                           //  resident launches share, a block of 16 wavefronts needs a whole free CU -- tests with thread ranks)
     if (tid < 64) hist[tid] = 0;
     if (tid == 0) count = 0;
     __syncthreads();
-    for (int b = tid; b < L; b += 1024) atomicAdd(&hist[min(63, max(ticks0[b], ticks1[b]))], 1);
-    for (int w = tid; w < nmax; w += 1024) list[w] = -1;
+    for (int b = tid; b < L; b += nthreads)
+        if (cut_code == nullptr || cut_code[b] < 0) atomicAdd(&hist[min(63, max(ticks0[b], ticks1[b]))], 1);
+    for (int w = tid; w < nmax; w += nthreads) list[w] = -1;
     __syncthreads();
     if (tid == 0) {
         int t = 64, acc = 0;
@@ -2181,9 +2191,9 @@ __global__ void __launch_bounds__(1024) k_heavy_select(const int* __restrict__ t
     }
     __syncthreads();
     const int T = thr;
-    for (int b = tid; b < Lp; b += 1024) {
+    for (int b = tid; b < Lp; b += nthreads) {
         int f = 0;
-        if (b < L && min(63, max(ticks0[b], ticks1[b])) >= T) {
+        if (b < L && (cut_code == nullptr || cut_code[b] < 0) && min(63, max(ticks0[b], ticks1[b])) >= T) {
             const int pos = atomicAdd(&count, 1);
             list[pos] = b;
             f = pos + 1;
@@ -2192,7 +2202,7 @@ __global__ void __launch_bounds__(1024) k_heavy_select(const int* __restrict__ t
     }
     __syncthreads();
     const int n = count;
-    for (int q = tid; q < 16 * n; q += 1024) {
+    for (int q = tid; q < 16 * n; q += nthreads) {
         const int w = q >> 4, k = q & 7, e = elem0 + list[w] + k * Lp;
         init[q] = (q & 8) ? l[e] : z[e];
     }

@@ -8,7 +8,7 @@ import re
 import sys
 
 NAMES = [("k_resident_tILi1ELb0ELb0EE", "k_resident"), ("k_resident_tILi1ELb1ELb0EE", "k_resident_t<1,heavy>"), ("k_resident_tILi2ELb0ELb0EE", "k_resident_t<2>"),
-         ("k_resident_tILi1ELb0ELb1EE", "k_resident_t<1,peers>"), ("k_resident_tILi2ELb0ELb1EE", "k_resident_t<2,peers>"), ("k_p2p_agree", "k_p2p_agree"), ("k_tile_assign", "k_tile_assign"), ("k_tile_keys", "k_tile_keys"), ("k_branch_tILb0ELb1EE", "k_branch_t<false,true>"), ("k_branch_tILb0ELb0EE", "k_branch_t<false,false>"),
+         ("k_resident_tILi1ELb0ELb1EE", "k_resident_t<1,peers>"), ("k_resident_tILi1ELb1ELb1EE", "k_resident_t<1,heavy,peers>"), ("k_resident_tILi2ELb0ELb1EE", "k_resident_t<2,peers>"), ("k_p2p_agree", "k_p2p_agree"), ("k_tile_assign", "k_tile_assign"), ("k_tile_keys", "k_tile_keys"), ("k_branch_tILb0ELb1EE", "k_branch_t<false,true>"), ("k_branch_tILb0ELb0EE", "k_branch_t<false,false>"),
          ("k_branch_tILb1ELb0EE", "k_branch_t<true,false>"), ("k_branch_tILb1ELb1EE", "k_branch_t<true,true>"),
          ("k_bus_group_tILb1ELb0EE", "k_bus_group_t<true>"), ("k_bus_group_tILb0ELb0EE", "k_bus_group_t<false>"), ("k_bus_group_tILb1ELb1EE", "k_bus_group_t<true,true>"),
          ("k_gen_ramp", "k_gen_ramp"), ("k_fused_zl", "k_fused_zl"), ("k_halo_unpack", "k_halo_unpack"), ("k_busE", "k_bus")]

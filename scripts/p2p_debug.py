@@ -8,12 +8,14 @@ import exaadmm_loader
 world = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 case = sys.argv[2] if len(sys.argv) > 2 else "case1354pegase"
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+iters2 = int(sys.argv[4]) if len(sys.argv) > 4 else 0      # a second run from iteration 101 (heavy wavefronts)
+areas = int(os.environ.get("P2P_DEBUG_AREAS", "1"))
 pkg = exaadmm_loader.load_package(); pkg.library()
 syn = exaadmm_loader.load_submodule("synthetic")
 dm = exaadmm_loader.load_submodule("distributed")
 import bench as B
 params = B.CASE_PARAMS[case]
-g = syn.sized_like(case, seed=0)
+g = syn.sized_like(case, seed=0, areas=areas)
 st = dm.init_state(g, params["rho_pq"], params["rho_va"])
 parts = [dm.Partition(g, world, r) for r in range(world)]
 buf = C.create_string_buffer(128)
@@ -46,6 +48,10 @@ def run(r):
         Stub.barrier.wait()
         res, ms = bes[r].run_fixed_native(iters, 1, 1e3)
         sys.stderr.write("rank %d done %s form=%s downgrades=%d last_error=%s\n" % (r, res, bes[r].mod.resident_form(), bes[r].mod.loop_downgrades(), pkg.library().exaadmm_last_error().decode()))
+        if iters2:
+            Stub.barrier.wait()
+            res, ms = bes[r].run_fixed_native(iters2, 101, 1e3)
+            sys.stderr.write("rank %d second run %s form=%s downgrades=%d last_error=%s\n" % (r, res, bes[r].mod.resident_form(), bes[r].mod.loop_downgrades(), pkg.library().exaadmm_last_error().decode()[:200]))
     except BaseException as ex:
         errs[r] = repr(ex)
         try: Stub.barrier.abort()

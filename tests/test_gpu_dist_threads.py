@@ -32,7 +32,11 @@ world = %(world)d
 case = %(case)r
 fixed_only = False
 NFIX = 60
-if case == "activsg70k":                  # BASELINE config 4's size (88 207 branches), fixed-count mode only
+NFIX2 = int(os.environ.get("EXAADMM_TEST_NFIX2", "0"))
+if case == "areas13659":                  # what `bench.py --gpus 2` runs: two areas of case13659pegase's size, fixed-count mode only
+    g = syn.sized_like("case13659pegase", seed=0, areas=world)
+    rho, par_over, fixed_only = (5e1, 5e3), {}, True
+elif case == "activsg70k":                # BASELINE config 4's size (88 207 branches), fixed-count mode only
     g = syn.sized_like("case_ACTIVSg70k", seed=0)
     rho, par_over, fixed_only = (3e4, 3e5), {}, True
 elif case == "synthetic1M":               # BASELINE config 5's size (1M branches, 500 000 buses), fixed-count mode only
@@ -135,6 +139,9 @@ def run2(r):
         bes2[r].run_fixed_native(NFIX, 1, 1e3)
         exch[r] = pkg.library().exaadmm_dist_exchange_count() - e0
         kinds[r] += [bes2[r].mod.loop_kind(), bes2[r].mod.loop_downgrades(), bes2[r].mod.resident_form()]
+        if NFIX2:   # a second run that continues beyond the 64th iteration: heavy wavefronts where the loop is resident
+            bes2[r].run_fixed_native(NFIX2, 101, 1e3)
+            kinds[r] += [bes2[r].mod.resident_form(), bes2[r].mod.loop_downgrades(), pkg.library().exaadmm_last_error().decode()[:120]]
     except BaseException as ex:
         errs[r] = repr(ex)
 ths = [threading.Thread(target=run2, args=(r,)) for r in range(world)]
@@ -148,6 +155,8 @@ out["nfix"] = NFIX
 env3 = pkg.AdmmEnv("single", rho[0], rho[1], verbose=0, grid=g)
 m3 = pkg.ModelAcopf(env3)
 m3.run_fixed(NFIX, first_major_iter=1, beta=1e3)
+if NFIX2:
+    m3.run_fixed(NFIX2, first_major_iter=101, beta=1e3)
 out["fixed_nonzero_differences"] = {}
 out["replica_differences"] = {}
 for name in ("u_curr", "v_curr", "z_curr", "l_curr"):
@@ -359,3 +368,34 @@ def test_resident_loop_with_peers_is_the_single_handle_solve(world, case):
     assert out["n_replica_entries"] == 8 * out["cut"] and all(n == 0 for n in out["replica_differences"].values()), out
     assert all(k[0] == 2 and k[1] == 2 and k[2] == 0 and k[3]["tiles"] == 1 and k[3]["launches"] == 1 for k in out["fixed_loop"]), out["fixed_loop"]
     assert out["exchanges_in_60_iterations"] == [0] * world, out       # (nothing goes through the communication library: the last sums use the mailboxes too)
+
+
+def test_resident_loop_with_peers_and_heavy_wavefronts_two_areas_of_the_headline_size():
+    """Two areas of case13659pegase's size cut in two (the grid a plain `bench.py --gpus 2` runs), both ranks' resident kernels on the one
+    GPU at the same time (2 x ~390 wavefronts + the heavy wavefronts that still fit): 60 iterations from the start, then 30 that continue
+    beyond the 64th -- launches with heavy wavefronts (interior branches only: cut branches stay with their lanes, which talk to the
+    peers) -- bitwise the single handle, replicas bit-identical, no downgrade."""
+    out = _run_worker(2, "areas13659", EXAADMM_DIST_P2P="1", EXAADMM_RESIDENT_COOP="0", GPU_MAX_HW_QUEUES="16", EXAADMM_TEST_NFIX2="30",
+                      EXAADMM_HEAVY_MAX="100",      # (both ranks share the 1 024 SIMDs of this box: 2 x (387 + 100) wavefronts
+                      EXAADMM_OPT_HEAVY_SELECT_SMALL="1")   #  ... and no CU is free of the other rank's resident wavefronts: the selection kernel as one wavefront)
+    assert out["cut"] > 0
+    print(out["fixed_loop"])
+    assert all(n == 0 for n in out["fixed_nonzero_differences"].values()), out
+    assert all(n == 0 for n in out["replica_differences"].values()), out
+    for k in out["fixed_loop"]:
+        assert k[0] == 2 and k[1] == 2 and k[2] == 0 and k[3]["tiles"] == 1 and k[3]["heavy"] == 0, k
+        assert k[4]["tiles"] == 1 and k[4]["heavy"] == 100 and k[5] == 0, k
+
+
+def test_two_tile_form_of_the_resident_loop_with_peers__on_a_small_grid():
+    """The form a partition of ACTIVSg70k's size runs (more tiles of 64 branches than SIMDs: up to two tiles per resident wavefront, tiles
+    that hold cut branches first in their wavefront) cannot share this box's one GPU between two ranks at its real size; the chip is
+    declared small instead (option resident_cap_limit) so that the 1 354-bus partitions (17 + 18 tiles) need the two-tile form: solves
+    with the single handle's counts, fixed-count run bitwise, replicas bit-identical, no downgrade."""
+    out = _run_worker(2, "", EXAADMM_DIST_P2P="1", EXAADMM_RESIDENT_COOP="0", GPU_MAX_HW_QUEUES="16", EXAADMM_OPT_RESIDENT_CAP_LIMIT="14")
+    assert all(st["p2p"] and st["loop_kind"] == 2 and st["downgrades"] == 0 and st["form"]["tiles"] == 2 for st in out["dist_stats"]), out["dist_stats"]
+    assert all(c == out["single"][1] for c in out["cumul"]) and all(o == out["single"][0] for o in out["outer"]), out
+    assert all(e <= 1e-10 for e in out["err"].values()), out
+    assert all(n == 0 for n in out["fixed_nonzero_differences"].values()), out
+    assert all(n == 0 for n in out["replica_differences"].values()), out
+    assert all(k[0] == 2 and k[2] == 0 and k[3]["tiles"] == 2 for k in out["fixed_loop"]), out["fixed_loop"]

@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 for grp in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_IFETCH"; do
   tag=$(echo $grp | tr ' ' '+')
-  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $R/$OUT/$tag -- python3 $R/bench.py --case $CASE --steps $STEPS --warmup 20 --repeats 1 --no-cpu-baseline --no-full-solve > $R/$OUT/$tag.log 2>&1
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $R/$OUT/$tag -- python3 $R/bench.py --case $CASE --steps $STEPS --warmup 20 --repeats 1 --no-cpu-baseline --no-full-solve --no-north-star > $R/$OUT/$tag.log 2>&1
   echo "$tag rc=$?"
 done
 cd $R

@@ -3,12 +3,12 @@
 # scripts/refresh_profiles.py writes profiles/<round>_pmc_summary.json (with the version string of THIS build), then the bench lines --
 # which read `traffic` / `valu_busy` from that summary and refuse it for any other build.  usage: bash scripts/final_batch.sh OUTDIR [ROUND]
 O=${1:-gpurun_out/final}; mkdir -p $O
-RND=${2:-r04}
+RND=${2:-r05}
 T="timeout 500"
 R=$PWD; cd /tmp; export TMPDIR=/tmp
 for c in "" case1354pegase case_ACTIVSg70k synthetic1M; do
   tag=${c:+_$c}; K=200; [ "$c" = "case_ACTIVSg70k" ] && K=100; [ "$c" = "synthetic1M" ] && K=50
-  $T rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/stats$tag -- python3 $R/bench.py ${c:+--case $c} --steps $K --warmup 20 --repeats 1 --no-cpu-baseline --no-full-solve > $R/$O/stats_bench$tag.log 2>&1
+  $T rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/stats$tag -- python3 $R/bench.py ${c:+--case $c} --steps $K --warmup 20 --repeats 1 --no-cpu-baseline --no-full-solve --no-north-star > $R/$O/stats_bench$tag.log 2>&1
   f=$(find $R/$O/stats$tag -name "*kernel_trace.csv" | head -1)
   [ -n "$f" ] && python3 $R/scripts/kernel_trace_split.py $f $K 20 300 > $R/$O/split$tag.json && rm -f $f
 done
@@ -17,8 +17,12 @@ bash scripts/collect_pmc.sh case13659pegase $O/pmc_case13659pegase 200 > $O/pmc1
 bash scripts/collect_pmc.sh case1354pegase $O/pmc_case1354pegase 200 > $O/pmc2.log 2>&1
 bash scripts/collect_pmc.sh case_ACTIVSg70k $O/pmc_case_ACTIVSg70k 100 > $O/pmc3.log 2>&1
 bash scripts/collect_pmc.sh synthetic1M $O/pmc_synthetic1M 50 > $O/pmc4.log 2>&1
+# calibration of roofline.critical_path: VALU instructions per wavefront trip = SQ_INSTS_VALU per iteration of the resident launch WITHOUT heavy
+# wavefronts / the trips its wavefronts ran (scripts/wave_trips.py at the same state, same switch)
+mkdir -p $O/pmc_noheavy; ( cd /tmp; EXAADMM_NO_HEAVY=1 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES --output-format csv -d $R/$O/pmc_noheavy/SQ_INSTS_VALU -- python3 $R/bench.py --steps 200 --warmup 20 --repeats 1 --no-cpu-baseline --no-full-solve --no-north-star > $R/$O/pmc_noheavy.log 2>&1 )
+EXAADMM_NO_HEAVY=1 python scripts/wave_trips.py case13659pegase 320 > $O/wave_trips_noheavy.json 2> $O/wave_trips_noheavy.err
 find $O -name "*kernel_trace.csv" -delete
-python scripts/refresh_profiles.py $O $RND "${BUILD_NOTE:-round 4 final build}" > $O/refresh1.log 2>&1
+python scripts/refresh_profiles.py $O $RND "${BUILD_NOTE:-round 5 final build}" > $O/refresh1.log 2>&1
 cp profiles/${RND}_pmc_summary.json $O/${RND}_pmc_summary.json
 $T python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.log 2>&1
 $T python bench.py > $O/bench_default.log 2>&1
@@ -29,6 +33,10 @@ $T python bench.py --case case_ACTIVSg70k --steps 100 --warmup 20 --cpu-solve-bu
 $T python bench.py --case synthetic1M --steps 100 --warmup 20 --no-cpu-baseline > $O/bench_synthetic1M.log 2>&1
 $T python bench.py --force-dist --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_dist1.log 2>&1
 $T python bench.py --force-dist --case case_ACTIVSg70k --steps 100 --warmup 20 --no-cpu-baseline > $O/bench_dist1_70k.log 2>&1
+# two thread ranks on this one GPU, two areas of the headline size: the mailbox loop against the two-launch loop with the RCCL stand-in, with delays
+( export EXAADMM_RCCL_LIB=tests/rccl_shim/librccl_shim.so RCCL_SHIM_ASYNC=1 GPU_MAX_HW_QUEUES=16 EXAADMM_RESIDENT_COOP=0 EXAADMM_NO_HEAVY=1
+  for d in 0 40; do echo "two-launch loop + stand-in, exchange delayed by $d us"; EXAADMM_DIST_P2P=0 RCCL_SHIM_DELAY_US=$d $T python scripts/dist_overlap_probe.py 2 case13659pegase 200 2>&1 | grep RESULT; done
+  for d in 0 5 10 20 40; do echo "mailbox loop, every send $d us late"; EXAADMM_HIP_LIB=exaadmm.jl_amd/libexaadmm_hip_hooks.so P2P_DELAY_US=$d $T python scripts/dist_overlap_probe.py 2 case13659pegase 200 2>&1 | grep RESULT; done ) > $O/dist_probes.txt 2>&1
 $T python bench.py --periods 4 --steps 100 --warmup 20 > $O/bench_mp4.log 2>&1
 EXAADMM_RESIDENT_TILES=0 $T python bench.py --case case_ACTIVSg70k --steps 100 --warmup 20 --no-cpu-baseline > $O/bench_case_ACTIVSg70k_two_launch.log 2>&1
 EXAADMM_MP_NO_SPEC=1 $T python bench.py --periods 4 --steps 100 --warmup 20 --no-cpu-baseline > $O/bench_mp4_four_launch.log 2>&1

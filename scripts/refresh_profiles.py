@@ -68,5 +68,19 @@ for case, steps in (("case13659pegase", 200), ("case1354pegase", 200), ("case_AC
                                                          "and reads their slot indices (8 B / 4 B): design traffic, not algorithmic -- it replaces 256 B of gathers per branch in the bus launch")
     if "k_bus_group" in out[wl]:
         out[wl]["k_bus_group"]["algorithmic_bytes"] = None
+# roofline.critical_path: VALU instructions one wavefront issues per solver trip = SQ_INSTS_VALU per iteration of the resident launch WITHOUT heavy
+# wavefronts / the wavefront trips of an iteration at that state (scripts/wave_trips.py).  The figure belongs to the CODE (the solver loop's
+# instruction count on the paths the lanes of that grid take), so the headline workload's entry carries it for the forms with heavy wavefronts too.
+try:
+    wt = line(os.path.join(src, "wave_trips_noheavy.json"))
+    sub = json.loads(subprocess.check_output([sys.executable, os.path.join(ROOT, "scripts", "summarize_pmc.py"), os.path.join(src, "pmc_noheavy"), "x", "200"]))["x"]
+    insts = sub["k_resident"]["SQ_INSTS_VALU"]
+    wl = "synthetic-case13659pegase-sized"
+    cal = {"valu_insts_per_iteration_no_heavy": insts, "wave_trips_per_iteration_no_heavy": wt["wave_trips_per_iteration"],
+           "valu_insts_per_wave_trip": insts / wt["wave_trips_per_iteration"], "max_trips_at_that_state": wt["max_trips"],
+           "how": "SQ_INSTS_VALU of k_resident (EXAADMM_NO_HEAVY=1, per iteration) / sum over the tiles of their largest lane trip count (scripts/wave_trips.py)"}
+    out.setdefault(wl, {}).setdefault("k_resident", {}).update({"valu_insts_per_wave_trip": cal["valu_insts_per_wave_trip"], "critical_path_calibration": cal})
+except Exception as e:
+    out["critical_path_calibration_error"] = repr(e)
 json.dump(out, open(out_p, "w"), indent=1)
 print("profiles refreshed from", src)

@@ -98,6 +98,33 @@ function download!(dev::HipNative, mod::ModelAcopf)
                    dev.handle, mod.membuf, 31, size(mod.membuf, 2)), "exaadmm_download_membuf")
 end
 
+# ---- options and diagnostics of a handle (include/exaadmm_hip.h: the library reads no environment variable of its own)
+function set_option(dev::HipNative, key::AbstractString, value::Integer)
+    hipcheck(ccall((:exaadmm_set_option, libexaadmm_hip), Cint, (Ptr{Cvoid}, Cstring, Int64), dev.handle, key, value), "exaadmm_set_option($key)")
+    return
+end
+function get_option(dev::HipNative, key::AbstractString)
+    r = Ref{Int64}(0)
+    hipcheck(ccall((:exaadmm_get_option, libexaadmm_hip), Cint, (Ptr{Cvoid}, Cstring, Ref{Int64}), dev.handle, key, r), "exaadmm_get_option($key)")
+    return r[]
+end
+# which loop the fused entry points use (0 four launches per iteration, 1 two, 2 resident) and what the last call launched
+function loop_kind(dev::HipNative)
+    r = Ref{Cint}(0)
+    hipcheck(ccall((:exaadmm_loop_kind, libexaadmm_hip), Cint, (Ptr{Cvoid}, Ref{Cint}), dev.handle, r), "exaadmm_loop_kind")
+    return Int(r[])
+end
+function resident_form(dev::HipNative)
+    t, hv, n, w = Ref{Cint}(0), Ref{Cint}(0), Ref{Cint}(0), Ref{Cint}(0)
+    hipcheck(ccall((:exaadmm_resident_form, libexaadmm_hip), Cint, (Ptr{Cvoid}, Ref{Cint}, Ref{Cint}, Ref{Cint}, Ref{Cint}), dev.handle, t, hv, n, w), "exaadmm_resident_form")
+    return (tiles = Int(t[]), heavy = Int(hv[]), launches = Int(n[]), wavefronts = Int(w[]))
+end
+function resident_selfchecks(dev::HipNative)
+    a, b = Ref{Cint}(0), Ref{Cint}(0)
+    hipcheck(ccall((:exaadmm_resident_selfcheck_stats, libexaadmm_hip), Cint, (Ptr{Cvoid}, Ref{Cint}, Ref{Cint}), dev.handle, a, b), "exaadmm_resident_selfcheck_stats")
+    return (checks = Int(a[]), mismatches = Int(b[]))
+end
+
 # ---- the plugin steps (docs/src/dev.md:65-155); counters keep the generic untyped methods of
 # ---- acopf_admm_increment.jl, which only touch mod.info
 function admm_outer_prestep(env::AdmmEnv, mod::AbstractOPFModel, dev::HipNative)

@@ -147,6 +147,9 @@ def compatible(jl, c):
         "Int64": {"int64_t"},
         "Ptr{Float64}": {"double*"},
         "Ref{Float64}": {"double*"},
+        "Ref{Int64}": {"int64_t*"},
+        "Ref{Cint}": {"int*"},
+        "Ptr{Int64}": {"int64_t*"},
         "Ref{ExaadmmGrid}": {"exaadmm_grid*"},
         "Ref{ExaadmmParams}": {"exaadmm_params*"},
         "Ref{Ptr{Cvoid}}": {"exaadmm_handle**"},

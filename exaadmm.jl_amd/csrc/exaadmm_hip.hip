@@ -271,7 +271,7 @@ static double* vec_ptr(exaadmm_handle* h, int which)
 #ifndef EXA_SRC_HASH
 #define EXA_SRC_HASH "unknown"
 #endif
-extern "C" const char* exaadmm_version(void) { return "exaadmm-hip 0.3 (gfx950) [" EXA_BUILD_FLAGS "] src:" EXA_SRC_HASH; }
+extern "C" const char* exaadmm_version(void) { return "exaadmm-hip 0.5 (gfx950) [" EXA_BUILD_FLAGS "] src:" EXA_SRC_HASH; }
 extern "C" const char* exaadmm_last_error(void) { return g_err.c_str(); }
 
 // Number of visible HIP devices (0 when there is none or the runtime cannot start).  Also the library's way of

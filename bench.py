@@ -12,7 +12,7 @@ and ./data; when absent (no network in this environment) a seeded size-matched s
 Benchmark state: the synthetic input includes the ADMM state, defined as the state after PREP (default 300)
 untimed inner iterations of outer iteration 1 from the reference's cold start (init_solution!); the W warm-up
 steps and the K timed steps follow.  (The cost of an iteration decays from 0.26 ms over the first 20 iterations of a cold
-start to a flat 0.085 ms from iteration ~300 on -- profiles/r02_iteration_cost_vs_iteration_index_case13659.txt; without
+start to a flat 0.085 ms from iteration ~300 on -- profiles/archive_r01_r02/r02_iteration_cost_vs_iteration_index_case13659.txt; without
 a defined state on the flat part the figure would depend on W and K.)  --prep 0 times from the cold start.  The CPU
 baseline is timed from the same state.  What a whole solve sees -- mostly the heavy first iterations of every inner
 loop -- is the `full_solve` block.
@@ -303,7 +303,7 @@ def main():
         done += args.warmup
     # timed region: exactly K steps, nothing but the iteration's own kernels on the stream, bracketed by synchronisation on
     # both sides.  (Round 1 bracketed every branch launch of the timed region with a HIP event pair: the rocprofv3 trace
-    # shows 5.7 us of idle queue on either side of the kernel for them -- profiles/r02_a_kernel_gaps_bench_with_events.txt.)
+    # shows 5.7 us of idle queue on either side of the kernel for them -- profiles/archive_r01_r02/r02_a_kernel_gaps_bench_with_events.txt.)
     # The region is REPEATED -- every repeat from THE SAME ADMM state (a device-side snapshot taken after the preparation and
     # warm-up iterations is restored, untimed, before each one: the iteration keeps getting cheaper as the inner loop
     # converges, 13.1 k it/s at iteration 320 and 16.3 k at 13 000, so consecutive stretches would not measure one thing)

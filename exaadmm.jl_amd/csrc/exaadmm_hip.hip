@@ -1138,7 +1138,7 @@ static void launch_mp_elem(exaadmm_handle* h, double beta, const Ctrl* c)
                        h->par.MAX_MULTIPLIER, c);
 }
 // 64 branches per wavefront (full waves) is the measured optimum at every size: spreading a small grid over more, emptier
-// waves shortens no wave's serial chain by much and costs more than it saves (profiles/r02_lanes_per_wave.txt).
+// waves shortens no wave's serial chain by much and costs more than it saves (profiles/archive_r01_r02/r02_lanes_per_wave.txt).
 static int branch_blocks(const exaadmm_handle* h) { return (int)grid_for(h->L, BR_BLOCK).x; }
 static int gen_blocks(const exaadmm_handle* h) { return (h->G > 0) ? (int)grid_for(h->G, BR_BLOCK).x : 0; }
 

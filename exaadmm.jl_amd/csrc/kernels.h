@@ -335,7 +335,7 @@ __global__ void __launch_bounds__(64) k_gen_ramp(Dev d, BranchOptions o, double 
 // the solver -- lives in registers (256 VGPR + AGPR spill space, one wave per SIMD); LDS only parks the
 // constants while the model step runs.  (The reference keeps 1728 B of shared memory per BRANCH and one 32-thread block per branch.
 // Variants measured and rejected -- constants / matrices staged in LDS, two waves per SIMD, fewer branches
-// per wavefront, lane regrouping: profiles/r02_two_waves_per_simd_experiments.txt, r02_lanes_per_wave.txt,
+// per wavefront, lane regrouping: profiles/archive_r01_r02/r02_two_waves_per_simd_experiments.txt, r02_lanes_per_wave.txt,
 // r02_wave_order_experiment.txt.)
 //
 // The Dev block is read through a pointer (not by-value kernel arguments): its ~40 pointers would
@@ -465,7 +465,7 @@ __global__ void __launch_bounds__(BR_BLOCK, EXA_BR_WAVES) k_branch_t(const Dev* 
         // Every load of the prologue first, every store after them.  As far as the compiler knows the planes may alias,
         // so a store between two loads is a full memory round trip: with the z/l pass written element by element
         // (load, compute, store, eight times, then the multipliers) a wave needed 10.6 k clocks from kernel entry to
-        // "loads landed" against 4.0 k for the launch without the pass (profiles/r02_wave_timeline_*).
+        // "loads landed" against 4.0 k for the launch without the pass (profiles/archive_r01_r02/r02_wave_timeline_*).
         double vv[8], zo[8], lo[8], lzv[8];
         const double* const zsrc = (do_zl && d.z_in) ? d.z_in : d.z;   // (three-set rotation of a partition with peers: see Dev::z_in)
         const double* const lsrc = (do_zl && d.l_in) ? d.l_in : d.l;

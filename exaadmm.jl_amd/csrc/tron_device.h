@@ -11,7 +11,7 @@
 //    owns one branch and every loop has a compile-time trip count N, so after
 //    unrolling all vectors, both packed-symmetric matrices and the 32 read-only
 //    problem constants live in registers (512 per lane on gfx950); no LDS.  (LDS-staged
-//    matrices / constants were measured 3-15 % slower: profiles/r02_two_waves_per_simd_experiments.txt.)
+//    matrices / constants were measured 3-15 % slower: profiles/archive_r01_r02/r02_two_waves_per_simd_experiments.txt.)
 //  * The face loop of the subspace CG does not compact the free variables into
 //    a smaller system (that needs run-time indexing -> scratch memory).  It keeps
 //    a free-variable MASK and works on the N x N system whose bound rows/columns
@@ -313,7 +313,7 @@ EXA_BIG void cauchy(const double (&x)[N], const double (&xl)[N], const double (&
 #if defined(__HIP_DEVICE_COMPILE__)
 // ---- the Cauchy search of a branch whose solve runs on all 64 lanes of a wavefront as clones (kernels.h: the heavy wavefronts of k_resident)
 // The step lengths the search tries are known up front: alpha, then 0.1^k alpha (interpolation) or 10^k alpha (extrapolation); a
-// straggler makes 3.8 model evaluations per search one after the other (profiles/r02_solver_loop_trip_counts.txt).  Every lane holds
+// straggler makes 3.8 model evaluations per search one after the other (profiles/archive_r01_r02/r02_solver_loop_trip_counts.txt).  Every lane holds
 // the same x, bounds, g, A, delta, alpha; lane 0 evaluates alpha, lanes 1..C the interpolation chain, lanes C+1..2C the extrapolation
 // chain -- gpstep_d / norm_exceeds / quad_model as the serial search calls them, on the operands the serial trip would see, so
 // every candidate carries the serial trip's bits -- and wavefront ballots replay the serial loop's decisions (first sufficient

@@ -136,7 +136,7 @@ int main()
     (void)hipDeviceSynchronize();
     std::vector<unsigned long long> c(32);
     (void)hipMemcpy(c.data(), d_cyc, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-    // s_memtime counts at 100 MHz: convert with the shader clock (2.4 GHz measured on this part, profiles/r02_pmc_summary.json)
+    // s_memtime counts at 100 MHz: convert with the shader clock (2.4 GHz measured on this part, profiles/archive_r01_r02/r02_pmc_summary.json)
     const double f = 24.0;
     const char* name[] = {"v_fma_f64 dependent chain", "v_fma_f64 2 independent chains", "v_fma_f64 4 independent chains",
                           "v_mul_f64 + v_add_f64 dependent", "cmp + add + 2 cndmask (select) dependent", "v_max_f64 + v_min_f64 dependent",

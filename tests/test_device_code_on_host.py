@@ -239,7 +239,7 @@ def test_exact_arith_build_is_bitwise_the_oracle_on_branches(hc_exact, oracle, c
     (x, multipliers, penalty, iteration counts) on every problem -- this pins the flattened tick loop, the
     masked (uncompacted) face loop and every TRON routine of tron_device.h to the CPU restatement; what is left
     to the default build is arithmetic only (FMA, reciprocal pivots, Cholesky shortcut, re-derived f/g/H), whose
-    effect tests/tools/classify_mismatches.py counts (profiles/r02_branch_arith_mismatch_classes.txt)."""
+    effect tests/tools/classify_mismatches.py counts (profiles/archive_r01_r02/r02_branch_arith_mismatch_classes.txt)."""
     rng = np.random.default_rng(70 if cold else 110)
     OL = oracle.lib()
     for _ in range(400):

@@ -97,7 +97,7 @@ def test_exact_build_matches_oracle_and_bounds_the_fast_build():
     # counts agree the solutions agree to 1e-10
     assert mis_exact <= 1e-4 * n, report
     assert all(s["max_err_same"] <= 1e-10 for s in exact["states"]), report
-    # default build: measured at 0.007-0.01 % (4-6 of 61 401: profiles/r02_branch_arith_mismatch_classes.txt,
+    # default build: measured at 0.007-0.01 % (4-6 of 61 401: profiles/archive_r01_r02/r02_branch_arith_mismatch_classes.txt,
     # r02_exact_arith_report_gpu.json; rounds 3 and 4: 5 of 61 401 = 0.8e-4); the gate is 0.015 % (9 of 61 401)
     assert mis_fast <= 1.5e-4 * n, report
     assert all(s["max_err_same"] <= 1e-7 for s in fast["states"]), report

@@ -7,7 +7,7 @@ shortcut, re-derived f/g/H) and -DEXA_EXACT_ORACLE_ARITH -- and both are run bes
 problems of realistic ADMM states (the states of tests/test_gpu_parity.py::test_branch_kernel_vs_oracle_on_perturbed_states:
 13 659-bus-sized grids, a few oracle iterations, optional noise).  Prints, per state, the exact number of branches whose
 (augmented-Lagrangian, TRON minor) iteration counts differ from the oracle's, the class of every difference and the
-distance of the solutions.  Output committed as profiles/r02_branch_arith_mismatch_classes.txt."""
+distance of the solutions.  Output committed as profiles/archive_r01_r02/r02_branch_arith_mismatch_classes.txt."""
 import ctypes as C
 import os
 import subprocess

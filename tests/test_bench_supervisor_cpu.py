@@ -167,3 +167,22 @@ def test_result_line_is_the_last_json_object_with_a_metric(sup):
     txt = 'RCCL version 2.26\n{"x": 1}\n{"metric": "m", "value": 1}\ntrailing noise\n'
     assert sup.result_line(txt) == {"metric": "m", "value": 1}
     assert sup.result_line("nothing here\n") is None
+
+
+def test_the_real_launcher_path_on_a_box_without_gpus():
+    """`python bench.py --gpus 2` as the driver's launcher runs it (torch.distributed.run -> one supervising bench.py per rank -> the ranks'
+    supervisors meet in the launcher's own rendezvous store -> children) on THIS box, which has no GPU: every child dies at its first HIP call
+    in every mode, and what must still come back is ONE JSON line -- value null, the six attempts with their modes and the children's error --
+    and a non-zero exit code, within seconds (nobody waits for a budget: the failure flag travels through the store)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: the children would measure")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--attempt-budget", "120",
+                        "--no-north-star"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode != 0
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["value"] is None and line["n_gpus"] == 2 and "error" in line
+    assert [a["mode"] for a in line["attempts"]] == ["resident+xgmi", "graph+overlap", "overlap", "one-stream", "python-twin", "python-gloo"]
+    assert all(not a["ok"] and a["failed_ranks"] == 2 and "No HIP GPUs" in a["stderr_tail"] for a in line["attempts"]), line["attempts"]
+    assert time.time() - t0 < 300

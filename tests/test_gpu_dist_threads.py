@@ -231,6 +231,9 @@ def test_batches_with_their_exchanges_replayed_from_a_hipgraph(world):
     out = _run_worker(world, "", RCCL_SHIM_ASYNC="1", GPU_MAX_HW_QUEUES="16")
     assert out["shim_failures"] == 0, (hex(out["shim_failures"]), out.get("shim_mailboxes"), out["dist_stats"])
     assert all(st["probe"] == 1 and st["graph_batches"] > 0 for st in out["dist_stats"]), out["dist_stats"]
+    # exactly one exchange per iteration + the one that closes the loop, also when batches are replayed from a graph (a captured exchange counts
+    # with every replay, not with its capture: ADVICE r04)
+    assert out["exchanges_in_60_iterations"] == [61] * world, out["exchanges_in_60_iterations"]
     assert all(c == out["single"][1] for c in out["cumul"]) and all(o == out["single"][0] for o in out["outer"]), out
     assert all(abs(m - out["single"][2]) <= 1e-10 * out["single"][2] for m in out["mismatch"]), out
     assert all(e <= 1e-10 for e in out["err"].values()), out

@@ -455,3 +455,46 @@ def test_a_gpu_mostly_taken_by_another_process_downgrades_the_loop_not_the_call(
     print("beside the hog:", got, "alone:", ref)
     assert got["digest"] == ref["digest"]
     assert (got["downgrades"], got["kind_after"]) in ((1, 1), (0, 2)), got
+
+
+def test_options_replace_the_environment_switches(pkg):
+    """exaadmm_set_option / exaadmm_get_option (include/exaadmm_hip.h): the library reads no environment variable; unknown keys and values out
+    of range are errors; the loop a handle uses follows its options; the Python mirror's translation of EXAADMM_* variables happens when a model
+    is created."""
+    syn = exaadmm_loader.load_submodule("synthetic")
+    g = syn.sized_like("case1354pegase", seed=0)
+    env = pkg.AdmmEnv("case1354pegase", 1e1, 1e3, verbose=0, grid=g)
+    mod = pkg.ModelAcopf(env)
+    want = pkg.options_from_environment()
+    for key, value in want.items():
+        assert mod.get_option(key) == value, key
+    if not SWITCHED_OFF:
+        assert mod.loop_kind() == 2
+        mod.set_option("resident", 0)
+        assert mod.loop_kind() == 1 and mod.get_option("resident") == 0
+        mod.set_option("spec", 0)
+        assert mod.loop_kind() == 0
+        mod.set_option("spec", 1)
+        mod.set_option("resident", 1)
+        assert mod.loop_kind() == 2
+        mod.set_option("rec", 0)               # (no pushed records: the resident loop has nothing to read its terms from)
+        assert mod.loop_kind() == 1
+        mod.set_option("rec", 1)
+    with pytest.raises(pkg.ExaAdmmError, match="unknown option"):
+        mod.set_option("no_such_switch", 1)
+    with pytest.raises(pkg.ExaAdmmError, match="out of range"):
+        mod.set_option("heavy_max", 100000)
+    with pytest.raises(pkg.ExaAdmmError):
+        mod.get_option("no_such_switch")
+    old = os.environ.get("EXAADMM_NO_HEAVY")
+    os.environ["EXAADMM_NO_HEAVY"] = "1"
+    try:
+        m2 = pkg.ModelAcopf(env)
+        assert m2.get_option("heavy") == 0 and mod.get_option("heavy") == want["heavy"]
+        m2.close()
+    finally:
+        if old is None:
+            os.environ.pop("EXAADMM_NO_HEAVY", None)
+        else:
+            os.environ["EXAADMM_NO_HEAVY"] = old
+    mod.close()

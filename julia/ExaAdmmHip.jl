@@ -162,7 +162,8 @@ end
 "solve_acopf with the MI355X backend; same keyword surface as interface/solve_acopf.jl:1-7."
 function solve_acopf_hip(case::String; case_format="matpower", outer_iterlim=20, inner_iterlim=1000,
         rho_pq=400.0, rho_va=40000.0, obj_scale=1.0, scale=1e-4, tight_factor=1.0, outer_eps=2e-4,
-        gpu_no=0, verbose=1, fused=false)
+        gpu_no=0, verbose=1, fused=false, options=Dict{String,Int}())
+    # options: A/B switches of the device model, e.g. Dict("resident" => 0) (include/exaadmm_hip.h exaadmm_set_option; none is needed)
     T = Float64; TD = Array{Float64,1}; TI = Array{Int,1}; TM = Array{Float64,2}
     env = AdmmEnv{T,TD,TI,TM}(case, rho_pq, rho_va; case_format=case_format, use_gpu=false,
                               tight_factor=tight_factor, verbose=verbose)
@@ -170,6 +171,9 @@ function solve_acopf_hip(case::String; case_format="matpower", outer_iterlim=20,
     env.params.scale = scale; env.params.obj_scale = obj_scale; env.params.outer_eps = outer_eps
     env.params.outer_iterlim = outer_iterlim; env.params.inner_iterlim = inner_iterlim
     dev = HipNative(env, mod; gpu_no=gpu_no)
+    for (key, value) in options
+        set_option(dev, key, value)
+    end
     if fused   # whole driver inside the library, loop control on the device
         info = zeros(UInt8, 160)
         hipcheck(ccall((:exaadmm_solve_two_level, libexaadmm_hip), Cint, (Ptr{Cvoid}, Ptr{UInt8}), dev.handle, info),

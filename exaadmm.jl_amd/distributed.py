@@ -623,6 +623,10 @@ def bench_main(args, rank, world, local_rank):
         m._all_reduce(sums)
 
     prep = max(0, getattr(args, "prep", 0))     # untimed preparation iterations that define the benchmark state
+    # (the ranks enter their first launch together: a rank that waited a second for a peer still busy on its host would give the launch
+    #  up -- capped waits -- and every rank would fall back to two launches per iteration for the rest of the job)
+    torch.cuda.synchronize()
+    dist.barrier()
     run(prep, 1)
     run(args.warmup, prep + 1)
     # timed region: exactly K steps between barrier + synchronize on both sides, MAX over the ranks.  Like the one-GPU line

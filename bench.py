@@ -358,6 +358,7 @@ def main():
     # cannot collect counters), summarised per workload in profiles/r03_pmc_summary.json together with the version string
     # of the library they were taken from.  An entry taken from other code than the library loaded now is refused.
     traffic = valu_busy = insts_per_trip = None
+    insts_calibrated_on = None
     # which loop ran: 2 = the resident loop (ONE launch for the K steps of a region: branch solves, bus updates by the last lane
     # to arrive, residual sums and stop test inside; the figures below are per ITERATION of that launch), 1 = two launches per iteration
     resident = (T == 1 and form["tiles"] > 0)
@@ -374,6 +375,12 @@ def main():
         elif kb:
             traffic, valu_busy = kb.get("traffic_bytes"), kb.get("valu_busy")
             insts_per_trip = kb.get("valu_insts_per_wave_trip")
+        # (the instruction count of a solver trip belongs to the CODE: where this workload has no calibration pass of its own, the headline
+        #  workload's -- taken from the same library -- stands in, and the line says so)
+        insts_calibrated_on = workload
+        if insts_per_trip is None and pmc.get("library_version") == lib_version:
+            insts_per_trip = pmc.get("synthetic-case13659pegase-sized", {}).get("k_resident", {}).get("valu_insts_per_wave_trip")
+            insts_calibrated_on = "synthetic-case13659pegase-sized"
             traffic_source = "%s (library %s, repository commit %s)" % (pmc_file, pmc.get("library_version"), pmc.get("commit"))
     except Exception as e:
         traffic_source = "none: %s unreadable (%s)" % (pmc_file, e)
@@ -415,7 +422,7 @@ def main():
         if insts_per_trip:
             floor_ms = max_trips * insts_per_trip * 4.0 / (clk_khz * 1e3) * 1e3
             critical = {"bound": "fp64-issue chain of the slowest branch", "max_solver_trips": max_trips, "valu_insts_per_wave_trip": insts_per_trip,
-                        "clocks_per_instruction": 4, "shader_clock_mhz": clk_khz / 1e3, "floor_ms": floor_ms, "kernel_ms": ms_branch,
+                        "instructions_calibrated_on": insts_calibrated_on, "clocks_per_instruction": 4, "shader_clock_mhz": clk_khz / 1e3, "floor_ms": floor_ms, "kernel_ms": ms_branch,
                         "frac": floor_ms / ms_branch, "definition": "max_solver_trips x valu_insts_per_wave_trip x 4 clocks / shader clock, over kernel_ms (per iteration)"}
         else:
             critical = {"max_solver_trips": max_trips, "shader_clock_mhz": clk_khz / 1e3, "frac": None,

@@ -1303,23 +1303,53 @@ __device__ __forceinline__ bool resident_wait(const int* flag, int want, int* fa
     return true;
 }
 
-// after the lane's terms of iteration j (1-based) are pushed and fenced
-__device__ __forceinline__ void resident_arrive(const Dev& d, const ResidentSync& rs, int I, int cnt, int j)
+// Two flags with ONE round trip per poll (both loads in flight together): a branch lane's two buses.  Same cap, same failure code as two
+// waits one after the other (which cost a lone lane a second round trip of ~0.5 us although both flags were up long ago).
+__device__ __forceinline__ bool resident_wait2(const int* fa, const int* fb, int want, int* fail, int code = 1)
+{
+    int spins = 0;
+    for (;;) {
+        const int a = __hip_atomic_load(fa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b = __hip_atomic_load(fb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a >= want && b >= want) break;
+        ++spins;
+        if (spins > (1 << 20) || ((spins & 255) == 0 && __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            int expected = 0;
+            (void)__hip_atomic_compare_exchange_strong(fail, &expected, code, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(24);
+    }
+    asm volatile("" ::: "memory");
+    return true;
+}
+
+// after the lane's terms of iteration j (1-based) are pushed and fenced.  Returns true when this lane was the last to arrive and has
+// updated the bus: res = what it published (mu1, mu2, w, theta) -- a lane that needs the result itself need not read it back.
+__device__ __forceinline__ bool resident_arrive_keep(const Dev& d, const ResidentSync& rs, int I, int cnt, int j, double (&res)[4])
 {
     const int n = cnt & 0xffff;
     const int old = __hip_atomic_fetch_add(rs.arrive + I, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (old + 1 == n * j) {
-        asm volatile("" ::: "memory");
-        double mu1, mu2, wi, ti;
-        bus_from_rec4(d, rs.terms[j & 1], I, cnt, mu1, mu2, wi, ti);
-        double* q = rs.busres[j & 1] + 4 * (size_t)I;
-        st_agent(q, mu1);
-        st_agent(q + 1, mu2);
-        st_agent(q + 2, wi);
-        st_agent(q + 3, ti);
-        resident_order_stores();
-        __hip_atomic_store(rs.ready + I, j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (old + 1 != n * j) return false;
+    asm volatile("" ::: "memory");
+    double mu1, mu2, wi, ti;
+    bus_from_rec4(d, rs.terms[j & 1], I, cnt, mu1, mu2, wi, ti);
+    double* q = rs.busres[j & 1] + 4 * (size_t)I;
+    st_agent(q, mu1);
+    st_agent(q + 1, mu2);
+    st_agent(q + 2, wi);
+    st_agent(q + 3, ti);
+    resident_order_stores();
+    __hip_atomic_store(rs.ready + I, j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    res[0] = mu1;
+    res[1] = mu2;
+    res[2] = wi;
+    res[3] = ti;
+    return true;
+}
+__device__ __forceinline__ void resident_arrive(const Dev& d, const ResidentSync& rs, int I, int cnt, int j)
+{
+    double res[4];
+    (void)resident_arrive_keep(d, rs, I, cnt, j, res);
 }
 
 // Loop control of the resident launch.  Index i of the launch = iteration ctrl->base + i + 1.  The z / l pass of iteration m - 1
@@ -1343,12 +1373,51 @@ __device__ __forceinline__ void resident_contribute(const ResidentSync& rs, int 
     __hip_atomic_fetch_add(rs.contrib, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// The decision word: `decided` = number of decisions published so far, bit 30 set by the decision that said stop (ONE word: a reader
+// needs one round trip, the control wavefront no acknowledgement between two stores; rs.stop is no longer read inside the launch).
+constexpr int RESIDENT_STOP_BIT = 1 << 30;
 // returns false when the loop has stopped (or a wait failed)
 __device__ __forceinline__ bool resident_go_on(const ResidentSync& rs, int passes_needed)
 {
     if (passes_needed <= 0) return true;
-    if (!resident_wait(rs.decided, passes_needed, rs.fail, 7)) return false;
-    return __hip_atomic_load(rs.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+    int spins = 0, v;
+    while ((v = __hip_atomic_load(rs.decided, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < passes_needed) {   // (a word with the stop bit is >= every count)
+        ++spins;
+        if (spins > (1 << 20) || ((spins & 255) == 0 && __hip_atomic_load(rs.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            int expected = 0;
+            (void)__hip_atomic_compare_exchange_strong(rs.fail, &expected, 7, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(24);
+    }
+    asm volatile("" ::: "memory");
+    return (v & RESIDENT_STOP_BIT) == 0;
+}
+
+// Top of an index of a HEAVY wavefront: the decision and the ready flags of its two buses asked for in ONE round of loads (its lone
+// arriving lanes are the launch's critical path: every round trip there is ~0.5 us of every iteration).  fa / fb = nullptr: the
+// wavefront made that bus's update itself (resident_arrive_keep) and waits for nobody.  Same order of precedence as resident_go_on
+// followed by the two waits: a published stop ends the loop whatever the flags say.
+__device__ __forceinline__ bool resident_top_wait(const ResidentSync& rs, int passes_needed, const int* fa, const int* fb, int want)
+{
+    int spins = 0;
+    for (;;) {
+        const int v = (passes_needed > 0) ? __hip_atomic_load(rs.decided, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        const int a = fa ? __hip_atomic_load(fa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : want;
+        const int b = fb ? __hip_atomic_load(fb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : want;
+        const bool dec = (passes_needed <= 0) || (v >= passes_needed);
+        if (dec && (v & RESIDENT_STOP_BIT) != 0) return false;
+        if (dec && a >= want && b >= want) break;
+        ++spins;
+        if (spins > (1 << 20) || ((spins & 255) == 0 && __hip_atomic_load(rs.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            int expected = 0;
+            (void)__hip_atomic_compare_exchange_strong(rs.fail, &expected, dec ? 1 : 7, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(24);
+    }
+    asm volatile("" ::: "memory");
+    return true;
 }
 
 // TILES = 2: grids with more tiles of 64 branches than the chip has SIMDs (up to twice as many: ~120 000 branches).  A resident
@@ -1615,9 +1684,8 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
             if (lane == 0) {
                 ctrl_advance(ctrl, tot);
                 stop = ctrl->done;
-                __hip_atomic_store(rs.stop, stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                resident_order_stores();
-                __hip_atomic_store(rs.decided, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(rs.stop, stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (diagnostics; readers take the bit of the decision word)
+                __hip_atomic_store(rs.decided, stop ? (p | RESIDENT_STOP_BIT) : p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             stop = __shfl(stop, 0, 64);
             if (stop) return;
@@ -1662,18 +1730,34 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
         bd.mu = (d0.mu_in ? d0.mu_in : d0.mu)[b];
         bd.scale = scale;
         const double rate_0 = d0.rateA[b];
+        // The bus updates of the last iteration that THIS wavefront completed (its lanes 0 and 1 arrive at the two buses side by side;
+        // the launch's slowest branch is the last to arrive at both of its buses): kept in registers -- the same doubles it published --,
+        // no wait for a flag it raised itself, no read-back.  (wave-uniform)
+        double keep_f[4] = {0.0, 0.0, 0.0, 0.0}, keep_t[4] = {0.0, 0.0, 0.0, 0.0};
+        bool have_f = false, have_t = false;
         for (int i = 0; i < iters; i++) {
-            if (i > 0 && !resident_go_on(rs, resident_passes(first_has_zl, i - 1))) return;   // (wave-uniform)
+            if (i > 0 && !resident_top_wait(rs, resident_passes(first_has_zl, i - 1), have_f ? nullptr : rs.ready + bus4.x,
+                                            have_t ? nullptr : rs.ready + bus4.z, i)) return;   // (wave-uniform)
             const Dev& d = (i & 1) ? *dp1 : *dp0;
             const bool do_zl = (i > 0) || first_has_zl;
             double vv[8];
             if (i > 0) {
-                if (!resident_wait(rs.ready + bus4.x, i, rs.fail)) return;
-                if (!resident_wait(rs.ready + bus4.z, i, rs.fail)) return;
-                const double* pf = rs.busres[i & 1] + 4 * (size_t)bus4.x;
-                const double* pt = rs.busres[i & 1] + 4 * (size_t)bus4.z;
-                const double rf[4] = {ld_agent(pf), ld_agent(pf + 1), ld_agent(pf + 2), ld_agent(pf + 3)};
-                const double rt4[4] = {ld_agent(pt), ld_agent(pt + 1), ld_agent(pt + 2), ld_agent(pt + 3)};
+                double rf[4], rt4[4];
+                if (have_f && have_t) {
+#pragma unroll
+                    for (int m = 0; m < 4; m++) {
+                        rf[m] = keep_f[m];
+                        rt4[m] = keep_t[m];
+                    }
+                } else {   // (a result this wavefront published itself reads back as what it kept: its stores were acknowledged before its flag went up)
+                    const double* pf = rs.busres[i & 1] + 4 * (size_t)bus4.x;
+                    const double* pt = rs.busres[i & 1] + 4 * (size_t)bus4.z;
+#pragma unroll
+                    for (int m = 0; m < 4; m++) {
+                        rf[m] = ld_agent(pf + m);
+                        rt4[m] = ld_agent(pt + m);
+                    }
+                }
                 vv[0] = (uc[0] + zc[0]) + (lc[0] + rf[0]) / bd.rho_[0];
                 vv[1] = (uc[1] + zc[1]) + (lc[1] + rf[1]) / bd.rho_[1];
                 vv[4] = rf[2];
@@ -1768,9 +1852,24 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
                 }
             }
             resident_order_stores();
-            if (lane == 0) {
-                resident_arrive(d, rs, bus4.x, bus4.y, i + 1);
-                resident_arrive(d, rs, bus4.z, bus4.w, i + 1);
+            {
+                // lane 0 arrives at the from-bus, lane 1 at the to-bus -- side by side: one counter round trip, one round of term loads, one
+                // chain, one acknowledgement for both (one after the other on lane 0 they were 2 x 2.2 us of every iteration)
+                double res[4] = {0.0, 0.0, 0.0, 0.0};
+                bool last = false;
+                if (lane < 2) last = resident_arrive_keep(d, rs, lane == 0 ? bus4.x : bus4.z, lane == 0 ? bus4.y : bus4.w, i + 1, res);
+                const unsigned long long lm = __ballot(last);
+                have_f = (lm & 1ull) != 0ull;
+                have_t = (lm & 2ull) != 0ull;
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                    keep_f[m] = lane_value(res[m], 0);
+                    keep_t[m] = lane_value(res[m], 1);
+#else
+                    keep_f[m] = keep_t[m] = res[m];   // (host pass of the compiler: never run)
+#endif
+                }
             }
         }
         // (v of the last index is written by the tile's lane, which wrote that word before: two XCDs with the same bytes dirty in their
@@ -1955,8 +2054,7 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
                 for (int k = 0; k < 8; k++) vbuf[base + k * Lp] = vv[k];
             }
             if (!PEERS && v_from_bus && lane_on) {
-                if (!resident_wait(rs.ready + bus4.x, i, rs.fail)) return;
-                if (!resident_wait(rs.ready + bus4.z, i, rs.fail)) return;
+                if (!resident_wait2(rs.ready + bus4.x, rs.ready + bus4.z, i, rs.fail)) return;
 #if defined(EXA_PROFILE_PHASES)
                 ts[2] = __builtin_amdgcn_s_memtime();   // both buses ready
 #endif
@@ -2123,8 +2221,7 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
                 }
             }
         } else {
-            if (!resident_wait(rs.ready + bus4.x, iters, rs.fail)) return;
-            if (!resident_wait(rs.ready + bus4.z, iters, rs.fail)) return;
+            if (!resident_wait2(rs.ready + bus4.x, rs.ready + bus4.z, iters, rs.fail)) return;
             const double* pf = rs.busres[iters & 1] + 4 * (size_t)bus4.x;
             const double* pt = rs.busres[iters & 1] + 4 * (size_t)bus4.z;
 #pragma unroll

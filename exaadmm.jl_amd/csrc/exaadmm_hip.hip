@@ -71,7 +71,7 @@ extern "C" int exaadmm_dist_detach(exaadmm_handle* h);
 // environment variable of its own: a host that wants its switches from the environment translates them.
 struct Options {
     int bus_kernel_lane = 0, graph = 1, spec = 1, mp_spec = 1, rec = 1;
-    int resident = 1, resident_tiles = 1, resident_coop = 1, heavy = 1, heavy_from = 64, heavy_max = 512, heavy_select_small = 0;
+    int resident = 1, resident_tiles = 1, resident_coop = 1, heavy = 1, heavy_from = 64, heavy_max = 512, heavy_select_small = 0, heavy_window = 32;
     int resident_cap_limit = 0;   // > 0: pretend the chip holds no more resident wavefronts than this (tests: the two-tile form on small grids)
     int dist_overlap = 1, dist_graph = 1, dist_p2p = 1;
     int trust_resident = 0, verbose = 0;
@@ -176,6 +176,7 @@ struct exaadmm_handle {
     ResidentTiles rtiles = {nullptr, 0, 0, 0, 0};
     ResidentHeavy rheavy = {nullptr, nullptr, nullptr, nullptr, 0};   // heavy wavefronts of the resident launch (kernels.h); n = 0: none
     int heavy_max = 0;
+    int resident_iters = 0;   // iterations the resident launches of this handle were asked for so far (the clock of ResidentSync::last3)
     std::vector<void*> guard;
     size_t nrec_slots = 0;
     ResidentSync rsync = {};
@@ -1629,6 +1630,10 @@ static int resident_prepare(exaadmm_handle* h, const Ctrl* begin = nullptr)
         h->rheavy.u = hu;
         h->rheavy.init = hu + 2 * 16 * (size_t)std::max(1, h->heavy_max);
     }
+    if (!r.last3) {
+        if ((rc = dev_alloc(h, &r.last3, (size_t)h->Lp))) return rc;
+        HIPCHK(hipMemsetAsync(r.last3, 0, (size_t)h->Lp * sizeof(int), h->stream));
+    }
     if (resident_mode(h) == 2 && !h->rtiles.tiles) {
         const int nb = branch_blocks(h), ng = gen_blocks(h);
         int* t = nullptr;
@@ -1681,7 +1686,7 @@ static int enqueue_resident(exaadmm_handle* h, int n, int loop_iter0)
         rh.n = std::min(h->heavy_max, h->opt.heavy_max);
         hipLaunchKernelGGL(k_heavy_select, dim3(1), dim3(h->opt.heavy_select_small != 0 ? 64 : 1024), 0, h->stream, (const int*)h->sets[0].st[2], (const int*)h->sets[1].st[2], h->L, h->Lp, rh.n,
                            const_cast<int*>(rh.list), const_cast<int*>(rh.flag), (const double*)h->d.z, (const double*)h->d.l, 2 * h->Gp, const_cast<double*>(rh.init),
-                           peers ? h->rpeers.cut_code : (const int*)nullptr);
+                           peers ? h->rpeers.cut_code : (const int*)nullptr, (const int*)h->rsync.last3, h->resident_iters, h->opt.heavy_window);
         grid += rh.n;
     }
     h->form_tiles = mode;
@@ -1701,6 +1706,8 @@ static int enqueue_resident(exaadmm_handle* h, int n, int loop_iter0)
                                      : (mode == 2 ? (const void*)k_resident_t<2> : (rh.n > 0 ? (const void*)k_resident_t<1, true> : (const void*)k_resident_t<1>));
     const Dev *d0 = h->d_dspec[0][0], *d1 = h->d_dspec[1][0];
     double scale = h->par.scale, base = h->baseMVA;
+    h->rsync.stamp0 = h->resident_iters;
+    h->resident_iters = (h->resident_iters + n) & 0x03ffffff;   // (a wrap once in 67 million iterations costs one launch its history)
     void* args[] = {(void*)&d0, (void*)&d1, (void*)&h->bo, (void*)&scale, (void*)&h->d_ctrl, (void*)&ng, (void*)&base, (void*)&n, (void*)&h->rsync, (void*)&h->rtiles, (void*)&rh, (void*)&rp};
     bool launched = false;
     if (h->resident_coop) {
@@ -2652,7 +2659,7 @@ const OptKey OPT_KEYS[] = {
     {"bus_kernel_lane", &Options::bus_kernel_lane, 0, 1}, {"graph", &Options::graph, 0, 1}, {"spec", &Options::spec, 0, 1},
     {"mp_spec", &Options::mp_spec, 0, 1}, {"rec", &Options::rec, 0, 1}, {"resident", &Options::resident, 0, 1},
     {"resident_tiles", &Options::resident_tiles, 0, 1}, {"resident_coop", &Options::resident_coop, 0, 1}, {"heavy", &Options::heavy, 0, 1},
-    {"heavy_from", &Options::heavy_from, 0, 1 << 30}, {"heavy_max", &Options::heavy_max, 0, 512}, {"heavy_select_small", &Options::heavy_select_small, 0, 1}, {"resident_cap_limit", &Options::resident_cap_limit, 0, 1 << 20}, {"dist_overlap", &Options::dist_overlap, 0, 1}, {"dist_graph", &Options::dist_graph, 0, 1}, {"dist_p2p", &Options::dist_p2p, 0, 1},
+    {"heavy_from", &Options::heavy_from, 0, 1 << 30}, {"heavy_max", &Options::heavy_max, 0, 512}, {"heavy_select_small", &Options::heavy_select_small, 0, 1}, {"heavy_window", &Options::heavy_window, 0, 1 << 20}, {"resident_cap_limit", &Options::resident_cap_limit, 0, 1 << 20}, {"dist_overlap", &Options::dist_overlap, 0, 1}, {"dist_graph", &Options::dist_graph, 0, 1}, {"dist_p2p", &Options::dist_p2p, 0, 1},
     {"trust_resident", &Options::trust_resident, 0, 1}, {"verbose", &Options::verbose, 0, 1}, {"prof_resident", &Options::prof_resident, 0, 1},
 };
 }  // namespace

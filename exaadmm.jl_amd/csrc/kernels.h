@@ -1204,6 +1204,9 @@ struct ResidentSync {
     int* decided;      // decisions published so far
     int* stop;         // the last decision said stop
     int* fail;
+    int* last3;        // [Lp] (TILES = 1) (resident iteration in which the branch last needed >= 3 solver trips) << 4 | those trips; 0: never.  Advisory:
+                       //  k_heavy_select reads it in front of a later launch (a straggler that rests for two iterations is still a straggler)
+    int stamp0;        // resident iterations of this handle before this launch (its index i is iteration stamp0 + i + 1 of that count)
 };
 
 __device__ __forceinline__ void bus_from_rec4(const Dev& d, const double* __restrict__ rec4, int I, int cnt, double& mu1, double& mu2,
@@ -1325,20 +1328,30 @@ __device__ __forceinline__ bool resident_wait2(const int* fa, const int* fb, int
 
 // after the lane's terms of iteration j (1-based) are pushed and fenced.  Returns true when this lane was the last to arrive and has
 // updated the bus: res = what it published (mu1, mu2, w, theta) -- a lane that needs the result itself need not read it back.
-__device__ __forceinline__ bool resident_arrive_keep(const Dev& d, const ResidentSync& rs, int I, int cnt, int j, double (&res)[4])
+__device__ __forceinline__ bool resident_arrive_keep(const Dev& d, const ResidentSync& rs, int I, int cnt, int j, double (&res)[4],
+                                                     unsigned long long* stamps = nullptr)   // stamps: diagnostic build, 3 clocks (counter back, update computed, stores acknowledged)
 {
     const int n = cnt & 0xffff;
     const int old = __hip_atomic_fetch_add(rs.arrive + I, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (old + 1 != n * j) return false;
     asm volatile("" ::: "memory");
+#if defined(EXA_PROFILE_PHASES)
+    if (stamps) stamps[0] = __builtin_amdgcn_s_memtime();
+#endif
     double mu1, mu2, wi, ti;
     bus_from_rec4(d, rs.terms[j & 1], I, cnt, mu1, mu2, wi, ti);
+#if defined(EXA_PROFILE_PHASES)
+    if (stamps) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamps[1]) : "v"(mu1), "v"(wi), "v"(ti) : "memory");
+#endif
     double* q = rs.busres[j & 1] + 4 * (size_t)I;
     st_agent(q, mu1);
     st_agent(q + 1, mu2);
     st_agent(q + 2, wi);
     st_agent(q + 3, ti);
     resident_order_stores();
+#if defined(EXA_PROFILE_PHASES)
+    if (stamps) stamps[2] = __builtin_amdgcn_s_memtime();
+#endif
     __hip_atomic_store(rs.ready + I, j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     res[0] = mu1;
     res[1] = mu2;
@@ -1736,8 +1749,21 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
         double keep_f[4] = {0.0, 0.0, 0.0, 0.0}, keep_t[4] = {0.0, 0.0, 0.0, 0.0};
         bool have_f = false, have_t = false;
         for (int i = 0; i < iters; i++) {
-            if (i > 0 && !resident_top_wait(rs, resident_passes(first_has_zl, i - 1), have_f ? nullptr : rs.ready + bus4.x,
-                                            have_t ? nullptr : rs.ready + bus4.z, i)) return;   // (wave-uniform)
+#if defined(EXA_PROFILE_PHASES)
+            unsigned long long hts[8], hx[4] = {0ull, 0ull, 0ull, 0ull};   // diagnostic build: stamps of this iteration of the heavy wavefront (scripts/heavy_timeline.py)
+            hts[0] = __builtin_amdgcn_s_memtime();
+            hts[6] = (unsigned long long)((have_f ? 1 : 0) | (have_t ? 2 : 0));
+#endif
+            // The heavy wavefront does NOT wait for the stop decision here.  What the decision protects is the iterate that would be final:
+            // the ordinary lanes' z / l pass overwrites z, l in place, and an x-update overwrites the u of the buffer set two indices back.
+            // A heavy wavefront keeps z, l in registers and stores nothing before its solve is over: it reads its two bus results, solves
+            // on speculation and asks for the decision in front of its stores (below) -- by then it has been out for a whole solve, where
+            // at the top it cost the launch's critical path the full latency of arrival -> bus -> tile's z / l pass -> contribution ->
+            // control wavefront -> decision in every iteration (profiles/r05_heavy_wavefront_series.txt: 15 - 27 k of 115 k clocks).
+            if (i > 0 && !resident_top_wait(rs, 0, have_f ? nullptr : rs.ready + bus4.x, have_t ? nullptr : rs.ready + bus4.z, i)) return;   // (wave-uniform)
+#if defined(EXA_PROFILE_PHASES)
+            hts[1] = __builtin_amdgcn_s_memtime();   // decision + flags seen
+#endif
             const Dev& d = (i & 1) ? *dp1 : *dp0;
             const bool do_zl = (i > 0) || first_has_zl;
             double vv[8];
@@ -1800,10 +1826,19 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
                 branch_start(uc, bnd, rate_0, x, xl, xu);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if defined(EXA_PROFILE_PHASES)
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(hts[2]) : "v"(x[0]), "v"(bd.xt_[7]) : "memory");   // bus results in, v, z / l, start point formed
+#endif
             BranchStats st;
             st.tl = nullptr;
             branch_solve<true>(bd, o, pw_h, x, xl, xu, A, L, phi, st, park_h + lane, search_h);
             asm volatile("" ::: "memory");
+#if defined(EXA_PROFILE_PHASES)
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(hts[3]) : "v"(phi[0]) : "memory");   // solve over
+#endif
+            // the decision that the ordinary lanes read at the top of this index: if the loop has stopped, this index never ran -- nothing of it
+            // has left the wavefront yet (the u of buffer set i & 1, which these stores would overwrite, belongs to the final iterate)
+            if (i > 0 && !resident_go_on(rs, resident_passes(first_has_zl, i - 1))) return;   // (wave-uniform)
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 zc[k] = keep[16 + k];
@@ -1832,8 +1867,10 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
                 d.st_auglag[b] = st.auglag_it;
                 d.st_minor[b] = st.minor_it;
                 d.st_ticks[b] = st.ticks;
+                if (st.ticks >= 3) rs.last3[b] = ((rs.stamp0 + i + 1) << 4) | min(st.ticks, 15);
 #if defined(EXA_PROFILE_PHASES)
                 for (int q = 0; q < 13; q++) d.st_cyc[q * d.Lp + b] = st.cyc[q] + (q == 12 ? 1000ull : 0ull);   // (phase clocks of the heavy wavefront's last solve; entry 12 = 1000 + trips marks it)
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(hx[0]) : : "memory");   // hand-over, planes, diagnostics acknowledged (the shipped build does not wait here)
 #endif
                 double* const tm = rs.terms[(i + 1) & 1];
                 {
@@ -1852,12 +1889,19 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
                 }
             }
             resident_order_stores();
+#if defined(EXA_PROFILE_PHASES)
+            hts[4] = __builtin_amdgcn_s_memtime();   // results, hand-over and terms stored (acknowledged)
+#endif
             {
                 // lane 0 arrives at the from-bus, lane 1 at the to-bus -- side by side: one counter round trip, one round of term loads, one
                 // chain, one acknowledgement for both (one after the other on lane 0 they were 2 x 2.2 us of every iteration)
                 double res[4] = {0.0, 0.0, 0.0, 0.0};
                 bool last = false;
+#if defined(EXA_PROFILE_PHASES)
+                if (lane < 2) last = resident_arrive_keep(d, rs, lane == 0 ? bus4.x : bus4.z, lane == 0 ? bus4.y : bus4.w, i + 1, res, lane == 0 ? hx + 1 : nullptr);
+#else
                 if (lane < 2) last = resident_arrive_keep(d, rs, lane == 0 ? bus4.x : bus4.z, lane == 0 ? bus4.y : bus4.w, i + 1, res);
+#endif
                 const unsigned long long lm = __ballot(last);
                 have_f = (lm & 1ull) != 0ull;
                 have_t = (lm & 2ull) != 0ull;
@@ -1871,6 +1915,31 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
 #endif
                 }
             }
+#if defined(EXA_PROFILE_PHASES)
+            hts[5] = __builtin_amdgcn_s_memtime();   // arrivals (and the bus updates the wavefront completed) done
+#if defined(EXA_HEAVY_SERIES)
+            if (d.st_tl && lane == 0 && hw < nwaves - gen_blocks && i >= iters - 16) {   // series build: the last 16 iterations of the launch
+                unsigned long long* q = d.st_tl + (size_t)hw * 128 + 32 + 3 * (i - (iters - 16));
+                const unsigned long long m20 = (1ull << 20) - 1;
+                q[0] = hts[0];
+                q[1] = ((hts[3] - hts[2]) << 8) | (unsigned long long)st.ticks;
+                q[2] = ((hts[1] - hts[0]) & m20) | (((hts[4] - hts[3]) & m20) << 20) | (((hts[5] - hts[4]) & m20) << 40) | (hts[6] << 60);   // top wait | stores acked | arrivals | kept bits
+            }
+            if (false) {
+#else
+            if (d.st_tl && lane == 0 && nwaves - gen_blocks > 0) {   // the last two iterations survive, in the unused part of a tile's timeline block
+#endif
+                const int nbt = nwaves - gen_blocks;
+                unsigned long long* q = d.st_tl + (size_t)(hw % nbt) * 128 + 32 + 16 * ((hw / nbt) & 3) + 8 * (i & 1);
+                for (int k = 0; k < 6; k++) q[k] = hts[k];
+                q[6] = hts[6] | ((unsigned long long)st.ticks << 8);
+                q[7] = (unsigned long long)i + 1;
+                if (hw < nbt) {
+                    unsigned long long* q2 = d.st_tl + (size_t)hw * 128 + 96 + 8 * (i & 1);
+                    for (int k = 0; k < 4; k++) q2[k] = hx[k];
+                }
+            }
+#endif
         }
         // (v of the last index is written by the tile's lane, which wrote that word before: two XCDs with the same bytes dirty in their
         //  L2s would leave the order of the write-backs to chance -- seen)
@@ -1956,7 +2025,7 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
     const int my_tile1 = (TILES == 1) ? -1 : rt.tiles[2 * blockIdx.x + 1];
     for (int i = 0; i < iters; i++) {
 #if defined(EXA_PROFILE_PHASES)
-        unsigned long long ts[8];   // diagnostic build: stamps of this iteration (scripts/resident_timeline.py)
+        unsigned long long ts[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};   // diagnostic build: stamps of this iteration (scripts/resident_timeline.py)
         ts[0] = __builtin_amdgcn_s_memtime();
 #endif
         if (i > 0 && !resident_go_on(rs, resident_passes(first_has_zl, i - 1))) return;   // (wave-uniform: the loop has stopped)
@@ -2155,6 +2224,7 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
                 d.st_auglag[b] = st.auglag_it;
                 d.st_minor[b] = st.minor_it;
                 d.st_ticks[b] = st.ticks;
+                if (TILES == 1 && st.ticks >= 3) rs.last3[b] = ((rs.stamp0 + i + 1) << 4) | min(st.ticks, 15);
 #if defined(EXA_PROFILE_PHASES)
                 for (int q = 0; q < 13; q++) d.st_cyc[q * d.Lp + b] = st.cyc[q];   // (phase clocks of the lane's last solve)
 #endif
@@ -2173,6 +2243,22 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
             }
 #if defined(EXA_PROFILE_PHASES)
             ts[6] = __builtin_amdgcn_s_memtime();   // arrivals (and the bus updates this wavefront's lanes completed) done
+#if defined(EXA_HEAVY_SERIES)
+            if (TILES == 1 && d.st_tl && i >= iters - 16) {   // series build: the last 16 iterations of every tile (scripts/heavy_series.py)
+                const bool solved = lane_on && !(TILES == 1 && HEAVY && heavy_lane);
+                int mt = solved ? d.st_ticks[b] : 0;
+                for (int off = 32; off > 0; off >>= 1) mt = max(mt, __shfl_xor(mt, off, 64));
+                const unsigned long long sm = __ballot(solved);
+                const int wl = sm ? (int)__ffsll((long long)sm) - 1 : 0;
+                if (lane == wl) {
+                    const unsigned long long m20 = (1ull << 20) - 1;
+                    unsigned long long* q = d.st_tl + (size_t)blockIdx.x * 128 + 80 + 3 * (i - (iters - 16));
+                    q[0] = ts[0];
+                    q[1] = ((ts[2] - ts[0]) & m20) | (((ts[3] - ts[2]) & m20) << 20) | (((ts[4] - ts[3]) & m20) << 40);   // top -> buses ready | -> contributed | solve
+                    q[2] = ((ts[6] - ts[4]) & m20) | ((unsigned long long)mt << 20) | ((unsigned long long)__popcll(sm) << 32);   // stores + arrivals | max trips | lanes that solved
+                }
+            }
+#endif
             if (TILES == 1 && d.st_tl && lane == 0) {   // the last two iterations of the launch survive
                 unsigned long long* q = d.st_tl + (size_t)blockIdx.x * 128 + 8 * (i & 1);
                 for (int k = 0; k < 7; k++) q[k] = ts[k];
@@ -2257,15 +2343,26 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
 }
 
 // Which branches get a heavy wavefront in the next resident launch (one block in front of it): those with the most solver trips in
-// the last accepted x-updates (both buffer sets), at least 3, at most `nmax` of them -- all branches with >= T trips, T the smallest
-// threshold that fits.  list[w] = the branch of heavy wavefront w (-1: none), flag[b] = w + 1 (0: the branch stays with its lane).
-// Which wavefront gets which branch is left to the order of the atomics: every branch is solved the same way wherever it runs.
+// the last accepted x-updates (both buffer sets), at least 3, AND those that needed >= 3 trips in any of the last `window` resident
+// iterations (last3: a thermal-limit-binding branch needs 4 - 5 trips in most iterations, not in all of them; picked from the last two
+// iterations alone, a launch of 200 was paced by the stragglers that happened to rest when it started -- profiles/r05_heavy_wavefront_series.txt).
+// At most `nmax` of them: all branches with key >= T, T the smallest threshold that fits; key = trips of the last two iterations, 3 for a
+// branch that is only there by its history.  list[w] = the branch of heavy wavefront w (-1: none), flag[b] = w + 1 (0: the branch stays
+// with its lane).  Which wavefront gets which branch is left to the order of the atomics: every branch is solved the same way wherever it runs.
 // init[w][0..7] = z, [8..15] = l of that branch as the launch finds them: the branch's lane overwrites both in place with the z / l pass
 // of the launch's first index, possibly before the heavy wavefront has looked (seen: ulp-level differences in a handful of branches).
 // cut_code (a partition with peers, else nullptr): cut branches are passed by -- their lanes talk to the peers, a heavy wavefront never does.
+__device__ __forceinline__ int heavy_key(const int* __restrict__ ticks0, const int* __restrict__ ticks1, const int* __restrict__ last3, int now, int window, int b)
+{
+    const int k = min(63, max(ticks0[b], ticks1[b]));
+    const int h = last3[b];
+    const bool recent = window > 0 && h != 0 && now - (h >> 4) <= window;
+    return (k < 3 && recent) ? 3 : k;
+}
 __global__ void __launch_bounds__(1024) k_heavy_select(const int* __restrict__ ticks0, const int* __restrict__ ticks1, int L, int Lp, int nmax,
                                                        int* __restrict__ list, int* __restrict__ flag, const double* __restrict__ z,
-                                                       const double* __restrict__ l, int elem0, double* __restrict__ init, const int* __restrict__ cut_code)
+                                                       const double* __restrict__ l, int elem0, double* __restrict__ init, const int* __restrict__ cut_code,
+                                                       const int* __restrict__ last3, int now, int window)
 {
     __shared__ int hist[64];
     __shared__ int thr, count;
@@ -2275,7 +2372,7 @@ __global__ void __launch_bounds__(1024) k_heavy_select(const int* __restrict__ t
     if (tid == 0) count = 0;
     __syncthreads();
     for (int b = tid; b < L; b += nthreads)
-        if (cut_code == nullptr || cut_code[b] < 0) atomicAdd(&hist[min(63, max(ticks0[b], ticks1[b]))], 1);
+        if (cut_code == nullptr || cut_code[b] < 0) atomicAdd(&hist[heavy_key(ticks0, ticks1, last3, now, window, b)], 1);
     for (int w = tid; w < nmax; w += nthreads) list[w] = -1;
     __syncthreads();
     if (tid == 0) {
@@ -2290,7 +2387,7 @@ __global__ void __launch_bounds__(1024) k_heavy_select(const int* __restrict__ t
     const int T = thr;
     for (int b = tid; b < Lp; b += nthreads) {
         int f = 0;
-        if (b < L && (cut_code == nullptr || cut_code[b] < 0) && min(63, max(ticks0[b], ticks1[b])) >= T) {
+        if (b < L && (cut_code == nullptr || cut_code[b] < 0) && heavy_key(ticks0, ticks1, last3, now, window, b) >= T) {
             const int pos = atomicAdd(&count, 1);
             list[pos] = b;
             f = pos + 1;
@@ -2305,13 +2402,6 @@ __global__ void __launch_bounds__(1024) k_heavy_select(const int* __restrict__ t
     }
 }
 
-// Which tiles share a resident wavefront (k_resident_t<2>), in two small launches in front of every resident launch:
-// k_tile_keys -- one wavefront per tile: key[tile] = largest solver-trip count of the tile's lanes in the last accepted x-updates
-// (both buffer sets; coalesced reads, wave maximum); k_tile_assign -- one block: tiles ranked by key (ties by index), the
-// S = 2 wb - nb heaviest get a wavefront each, the other 2 (nb - wb) are paired heaviest with lightest, the heavier of a pair first.
-// cut_code (a partition with peers, else nullptr): a tile that holds a cut branch ranks in front of every tile that holds none -- it gets
-// a wavefront of its own or is the FIRST tile of its wavefront, so that its lanes' sends to the twin lanes never sit behind another
-// tile's wait for a peer (two wavefronts on two ranks, each waiting in its first tile for what the other sends in its second: a cycle)
 __global__ void __launch_bounds__(256) k_tile_keys(const int* __restrict__ ticks0, const int* __restrict__ ticks1, int L, int nb, int* __restrict__ key,
                                                    const int* __restrict__ cut_code)
 {

@@ -1,0 +1,6 @@
+O=gpurun_out/r05l; mkdir -p $O
+timeout 900 python -m pytest tests/test_gpu_resident.py -x -q > $O/resident.txt 2>&1; tail -3 $O/resident.txt
+bash scripts/gpu_ab.sh $O "base default" 3 2>&1 | tee $O/ab.txt
+for w in 0 8 64 128; do echo "heavy_window $w"; EXAADMM_HEAVY_WINDOW=$w bash scripts/gpu_ab.sh $O/w$w "default" 2 2>&1; done | tee $O/ab_window.txt
+bash scripts/gpu_ab.sh $O/c1354 "base default" 2 --case case1354pegase 2>&1 | tee $O/ab1354.txt
+EXAADMM_HIP_LIB=$PWD/exaadmm.jl_amd/libexaadmm_hip_series.so EXAADMM_PROF_RESIDENT=1 timeout 300 python scripts/heavy_series.py case13659pegase 300 2>&1 | grep -v amdgpu.ids > $O/heavy_series.txt; sed -n 1,12p $O/heavy_series.txt; tail -3 $O/heavy_series.txt

@@ -71,7 +71,7 @@ extern "C" int exaadmm_dist_detach(exaadmm_handle* h);
 // environment variable of its own: a host that wants its switches from the environment translates them.
 struct Options {
     int bus_kernel_lane = 0, graph = 1, spec = 1, mp_spec = 1, rec = 1;
-    int resident = 1, resident_tiles = 1, resident_coop = 1, heavy = 1, heavy_from = 64, heavy_max = 512, heavy_select_small = 0, heavy_window = 32;
+    int resident = 1, resident_tiles = 1, resident_coop = 1, heavy = 1, heavy_from = 64, heavy_max = 512, heavy_select_small = 0, heavy_window = 32, heavy_split = 32, heavy_split_prev = 96;
     int resident_cap_limit = 0;   // > 0: pretend the chip holds no more resident wavefronts than this (tests: the two-tile form on small grids)
     int dist_overlap = 1, dist_graph = 1, dist_p2p = 1;
     int trust_resident = 0, verbose = 0;
@@ -176,6 +176,7 @@ struct exaadmm_handle {
     ResidentTiles rtiles = {nullptr, 0, 0, 0, 0};
     ResidentHeavy rheavy = {nullptr, nullptr, nullptr, nullptr, 0};   // heavy wavefronts of the resident launch (kernels.h); n = 0: none
     int heavy_max = 0;
+    int last_inner_len = -1;  // iterations of the handle's previous convergence-tested inner loop (run_inner_spec); -1: there was none yet
     int resident_iters = 0;   // iterations the resident launches of this handle were asked for so far (the clock of ResidentSync::last3)
     std::vector<void*> guard;
     size_t nrec_slots = 0;
@@ -1679,7 +1680,8 @@ static int enqueue_resident(exaadmm_handle* h, int n, int loop_iter0)
     // are chosen from the trip counters of the iterations before the launch, and at the start of an inner loop (the penalties
     // restart, the slowest branch changes from iteration to iteration) those say nothing -- a launch from there runs the kernel
     // without them (profiles/r04_heavy_wavefronts.txt: +8.6 % in the steady state, -2.7 % over a whole solve if always on).
-    const bool heavy_rule = (h->force_heavy >= 0) ? (h->force_heavy != 0) : (loop_iter0 >= h->opt.heavy_from && h->opt.heavy != 0);
+    const int heavy_from = (h->opt.heavy_split > 0) ? std::min(h->opt.heavy_from, h->opt.heavy_split) : h->opt.heavy_from;
+    const bool heavy_rule = (h->force_heavy >= 0) ? (h->force_heavy != 0) : (loop_iter0 >= heavy_from && h->opt.heavy != 0);
     const bool peers = dist_has_peers(h);
     if (mode == 1 && heavy_rule && std::min(h->heavy_max, h->opt.heavy_max) > 0) {
         // which branches get a wavefront of their own in this launch: from the solver-trip counters of the last x-updates (both buffer sets)
@@ -2047,7 +2049,15 @@ static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
         // resident: ONE launch (and one host visit) per 1 024 iterations -- normally the whole inner loop; the launch ends inside the
         // kernel at the iteration the stop test names, so its length only bounds the host visits (a launch has a fixed cost of
         // 0.15 ms at 13 659 buses, 0.23 ms at 88 207 branches: profiles/r04_resident_launch_fixed_cost.txt)
-        const int nb = std::min(resident ? 1024 : batch, max_inner - enq);
+        // (option heavy_split = S > 0: the first launch of an inner loop ends after S iterations, so that the rest of the loop runs with heavy
+        //  wavefronts chosen from those S iterations' history -- one more launch per inner loop, 0.15 ms, taken only when the handle's
+        //  previous inner loop ran long enough to promise it back (heavy_split_prev iterations): 15.0 k -> 16.8 k it/s over the whole solve of
+        //  the 1 354-bus grid, whose loops run 250 iterations; nothing at 13 659 buses, whose loops run 100)
+        const bool split = resident && h->opt.heavy_split > 0 && h->opt.heavy != 0 && resident_mode(h) == 1 && enq < h->opt.heavy_split &&
+                           (h->last_inner_len < 0 || h->last_inner_len >= h->opt.heavy_split_prev) && h->heavy_max > 0;   // (a handle's first loop: one launch risked)
+        // (a batch that another one follows must be a multiple of the number of buffer sets long: every launch starts on set 0)
+        const int split_len = ((h->opt.heavy_split + h->nsets - 1) / h->nsets) * h->nsets;
+        const int nb = std::min(resident ? (split && enq < split_len ? split_len - enq : 1024) : batch, max_inner - enq);
         *h->h_base = enq;   // the stream is idle here (synchronised at the end of every batch)
         HIPCHK(hipMemcpyAsync(&h->d_ctrl->base, h->h_base, sizeof(int), hipMemcpyHostToDevice, h->stream));
         if (resident) {
@@ -2113,6 +2123,7 @@ static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
         }
         if (hc->done) break;   // (a partition: every rank sees the same sums, added in the same order -> the same decision)
     }
+    if (!downgrade) h->last_inner_len = hc->inner;
     if (!downgrade) {
         if (!completed) {
             if ((rc = spec_complete_last(h, enq))) return rc;
@@ -2659,7 +2670,7 @@ const OptKey OPT_KEYS[] = {
     {"bus_kernel_lane", &Options::bus_kernel_lane, 0, 1}, {"graph", &Options::graph, 0, 1}, {"spec", &Options::spec, 0, 1},
     {"mp_spec", &Options::mp_spec, 0, 1}, {"rec", &Options::rec, 0, 1}, {"resident", &Options::resident, 0, 1},
     {"resident_tiles", &Options::resident_tiles, 0, 1}, {"resident_coop", &Options::resident_coop, 0, 1}, {"heavy", &Options::heavy, 0, 1},
-    {"heavy_from", &Options::heavy_from, 0, 1 << 30}, {"heavy_max", &Options::heavy_max, 0, 512}, {"heavy_select_small", &Options::heavy_select_small, 0, 1}, {"heavy_window", &Options::heavy_window, 0, 1 << 20}, {"resident_cap_limit", &Options::resident_cap_limit, 0, 1 << 20}, {"dist_overlap", &Options::dist_overlap, 0, 1}, {"dist_graph", &Options::dist_graph, 0, 1}, {"dist_p2p", &Options::dist_p2p, 0, 1},
+    {"heavy_from", &Options::heavy_from, 0, 1 << 30}, {"heavy_max", &Options::heavy_max, 0, 512}, {"heavy_select_small", &Options::heavy_select_small, 0, 1}, {"heavy_window", &Options::heavy_window, 0, 1 << 20}, {"heavy_split", &Options::heavy_split, 0, 1 << 20}, {"heavy_split_prev", &Options::heavy_split_prev, 0, 1 << 20}, {"resident_cap_limit", &Options::resident_cap_limit, 0, 1 << 20}, {"dist_overlap", &Options::dist_overlap, 0, 1}, {"dist_graph", &Options::dist_graph, 0, 1}, {"dist_p2p", &Options::dist_p2p, 0, 1},
     {"trust_resident", &Options::trust_resident, 0, 1}, {"verbose", &Options::verbose, 0, 1}, {"prof_resident", &Options::prof_resident, 0, 1},
 };
 }  // namespace

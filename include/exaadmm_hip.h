@@ -198,6 +198,8 @@ int exaadmm_resident_selfcheck_stats(exaadmm_handle *h, int *checks, int *mismat
  *   "heavy_from" (64)      first iteration of an inner loop from which a resident launch may carry heavy wavefronts
  *   "heavy_max" (512)      at most this many of them (they take the SIMDs the launch leaves idle; fewer when the GPU is shared)
  *   "heavy_window" (32)    a branch that needed >= 3 solver trips in any of the last this-many resident iterations is a candidate too (0: only the last two count)
+ *   "heavy_split" (32)     > 0: the first launch of a convergence-tested inner loop ends after this many iterations and the rest of the loop runs with heavy
+ *                          wavefronts -- when the handle's previous inner loop ran at least "heavy_split_prev" (96) iterations; 0: one launch per 1 024 iterations
  *   "heavy_select_small" (0) 1: the kernel that picks them runs as ONE wavefront (slower; a block of 16 wavefronts cannot start on a GPU whose
  *                          CUs all hold a resident wavefront of ANOTHER launch that waits for this one -- ranks sharing a GPU in tests)
  *   "resident_cap_limit" (0) > 0: treat the chip as holding at most this many resident wavefronts (tests: the two-tile form on small grids)

@@ -145,6 +145,37 @@ def test_resident_whole_solves_reproduce_the_anchors_and_the_two_launch_runs(pkg
     assert res[0] == res[1] and res[0][:3] == ("Solved", 3, 250)
 
 
+@pytest.mark.skipif(SWITCHED_OFF or bool(os.environ.get("EXAADMM_NO_HEAVY")), reason="a switch of this run turns the resident loop / its heavy wavefronts off")
+def test_whole_solves_whose_inner_loops_continue_with_heavy_wavefronts(pkg):
+    """Option heavy_split = S: the first launch of every inner loop ends after S iterations and the rest of the loop runs with heavy
+    wavefronts -- in loops that END BY THEIR STOP TEST.  A heavy wavefront does not wait for the stop decision before its solve
+    (kernels.h): one that returns on a stop has not arrived at its buses, and one that waits for a bus must hear of the stop too
+    (met: a capped wait and a downgrade on the first whole solve that ran this way).  Same anchors, same bits as the default
+    launches, no downgrade, on grids of 1, 3, 32 and 320 tiles."""
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    syn = exaadmm_loader.load_submodule("synthetic")
+    cases = [(os.path.join(golden, "case9.m"), None, dict(outer_iterlim=25, rho_pq=4e2, rho_va=4e4, outer_eps=2e-5), ("Solved", 20, 705)),
+             (os.path.join(golden, "case118.m"), None, dict(outer_iterlim=25, rho_pq=4e2, rho_va=4e4, outer_eps=2e-5), ("Solved", 20, 1232)),
+             ("case1354pegase", syn.sized_like("case1354pegase", seed=0), dict(rho_pq=1e1, rho_va=1e3, outer_iterlim=20, inner_iterlim=1000), None),
+             ("case13659pegase", syn.sized_like("case13659pegase", seed=0), dict(rho_pq=5e1, rho_va=5e3, outer_iterlim=20, inner_iterlim=1000), ("Solved", 3, 250))]
+    for case, g, kw, anchor in cases:
+        res = []
+        for split in (0, 8, 21):
+            with _env(EXAADMM_HEAVY_SPLIT=split, EXAADMM_HEAVY_SPLIT_PREV=0):
+                env, mod = pkg.solve_acopf(case, verbose=0, **(dict(kw, grid=g) if g is not None else kw))
+                i = mod.info
+                assert mod.loop_kind() == 2 and mod.loop_downgrades() == 0, (case, split, pkg.library().exaadmm_last_error())
+                res.append((i.status, i.outer, i.cumul, i.objval, i.primres, i.dualres, mod.solution.u_curr.tobytes(), mod.solution.v_curr.tobytes(),
+                            mod.solution.l_curr.tobytes()))
+                if split and g is not None:
+                    assert mod.resident_form()["heavy"] > 0, (case, split)   # (the last launch of the solve carried heavy wavefronts; the two small
+                                                                             #  cases end on inner loops shorter than the split)
+                mod.close()
+        assert res[0] == res[1] == res[2], case
+        if anchor:
+            assert res[0][:3] == anchor
+
+
 def test_grids_with_more_than_twice_as_many_tiles_as_simds_keep_the_two_launch_loop(pkg):
     syn = exaadmm_loader.load_submodule("synthetic")
     g = syn.synthetic_grid(20000, 160000, 110000, seed=3)      # 2 500 tiles of 64 branches: not even two per wavefront fit
@@ -169,7 +200,7 @@ class _env:
     def __enter__(self):
         self.old = {k: os.environ.get(k) for k in self.kv}
         for k, v in self.kv.items():
-            os.environ[k] = v
+            os.environ[k] = str(v)
 
     def __exit__(self, *a):
         for k, v in self.old.items():

@@ -2053,7 +2053,8 @@ static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
         //  wavefronts chosen from those S iterations' history -- one more launch per inner loop, 0.15 ms, taken only when the handle's
         //  previous inner loop ran long enough to promise it back (heavy_split_prev iterations): 15.0 k -> 16.8 k it/s over the whole solve of
         //  the 1 354-bus grid, whose loops run 250 iterations; nothing at 13 659 buses, whose loops run 100)
-        const bool split = resident && h->opt.heavy_split > 0 && h->opt.heavy != 0 && resident_mode(h) == 1 && enq < h->opt.heavy_split &&
+        // (not on a partition with peers: every rank must give its launches the same lengths, and the spare SIMDs differ from rank to rank)
+        const bool split = resident && !peers && h->opt.heavy_split > 0 && h->opt.heavy != 0 && resident_mode(h) == 1 && enq < h->opt.heavy_split &&
                            (h->last_inner_len < 0 || h->last_inner_len >= h->opt.heavy_split_prev) && h->heavy_max > 0;   // (a handle's first loop: one launch risked)
         // (a batch that another one follows must be a multiple of the number of buffer sets long: every launch starts on set 0)
         const int split_len = ((h->opt.heavy_split + h->nsets - 1) / h->nsets) * h->nsets;

@@ -2369,15 +2369,32 @@ __global__ void __launch_bounds__(1024) k_heavy_select(const int* __restrict__ t
                                                        const double* __restrict__ l, int elem0, double* __restrict__ init, const int* __restrict__ cut_code,
                                                        const int* __restrict__ last3, int now, int window)
 {
+    // (one block: it sits between a call's opening launch and the resident launch, 30 us of every call when every thread walked its
+    //  branches one load round trip after the other; now eight branches' loads are in flight per thread and the keys of the first pass wait
+    //  in flag[] for the second)
     __shared__ int hist[64];
     __shared__ int thr, count;
     const int tid = threadIdx.x, nthreads = blockDim.x;   // (1 024 threads; 64 on request: one wavefront finds a free SIMD on a GPU that other
                                                            //  resident launches share, a block of 16 wavefronts needs a whole free CU -- tests with thread ranks)
+    constexpr int U = 8;
     if (tid < 64) hist[tid] = 0;
     if (tid == 0) count = 0;
     __syncthreads();
-    for (int b = tid; b < L; b += nthreads)
-        if (cut_code == nullptr || cut_code[b] < 0) atomicAdd(&hist[heavy_key(ticks0, ticks1, last3, now, window, b)], 1);
+    for (int b0 = tid; b0 < Lp; b0 += U * nthreads) {
+        int key[U];
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+            const int b = b0 + j * nthreads;
+            const bool on = b < L && (cut_code == nullptr || cut_code[b] < 0);
+            key[j] = on ? heavy_key(ticks0, ticks1, last3, now, window, b) : -1;
+        }
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+            const int b = b0 + j * nthreads;
+            if (key[j] >= 0) atomicAdd(&hist[key[j]], 1);
+            if (b < Lp) flag[b] = key[j];
+        }
+    }
     for (int w = tid; w < nmax; w += nthreads) list[w] = -1;
     __syncthreads();
     if (tid == 0) {
@@ -2390,14 +2407,24 @@ __global__ void __launch_bounds__(1024) k_heavy_select(const int* __restrict__ t
     }
     __syncthreads();
     const int T = thr;
-    for (int b = tid; b < Lp; b += nthreads) {
-        int f = 0;
-        if (b < L && (cut_code == nullptr || cut_code[b] < 0) && heavy_key(ticks0, ticks1, last3, now, window, b) >= T) {
-            const int pos = atomicAdd(&count, 1);
-            list[pos] = b;
-            f = pos + 1;
+    for (int b0 = tid; b0 < Lp; b0 += U * nthreads) {
+        int key[U];
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+            const int b = b0 + j * nthreads;
+            key[j] = (b < Lp) ? flag[b] : -1;   // (written by this thread above)
         }
-        flag[b] = f;
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+            const int b = b0 + j * nthreads;
+            int f = 0;
+            if (key[j] >= T) {
+                const int pos = atomicAdd(&count, 1);
+                list[pos] = b;
+                f = pos + 1;
+            }
+            if (b < Lp) flag[b] = f;
+        }
     }
     __syncthreads();
     const int n = count;

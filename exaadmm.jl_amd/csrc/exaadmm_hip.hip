@@ -71,7 +71,7 @@ extern "C" int exaadmm_dist_detach(exaadmm_handle* h);
 // environment variable of its own: a host that wants its switches from the environment translates them.
 struct Options {
     int bus_kernel_lane = 0, graph = 1, spec = 1, mp_spec = 1, rec = 1;
-    int resident = 1, resident_tiles = 1, resident_coop = 1, heavy = 1, heavy_from = 64, heavy_max = 512, heavy_select_small = 0, heavy_window = 32, heavy_split = 32, heavy_split_prev = 96;
+    int resident = 1, resident_tiles = 1, resident_coop = 1, heavy = 1, heavy_from = 64, heavy_max = 512, heavy_select_small = 0, heavy_window = 64, heavy_split = 32, heavy_split_prev = 96, resident_chunk = 50;
     int resident_cap_limit = 0;   // > 0: pretend the chip holds no more resident wavefronts than this (tests: the two-tile form on small grids)
     int dist_overlap = 1, dist_graph = 1, dist_p2p = 1;
     int trust_resident = 0, verbose = 0;
@@ -113,6 +113,12 @@ struct exaadmm_handle {
     // cut branches; the other end's bus update runs on a peer)
     std::vector<char> cut_side;
     std::vector<double*> snap;   // exaadmm_state_save: u, v, z, z_prev, l, lz (N each), ls1, ls2, mu (Lp each)
+    // ... and what the choice of the heavy wavefronts / the pairing of the tiles is made from (the solver-trip counters of every buffer set, the
+    // trip history, its clock): a restored state that kept the counters of whatever ran last would give a REPLAYED run a heavy set chosen with
+    // knowledge of its own future (seen: the repeats of bench.py's region 14 % faster than its first pass)
+    int* snap_hist[4] = {nullptr, nullptr, nullptr, nullptr};   // st_ticks of sets 0 .. 2, last3
+    bool snap_hist_valid[4] = {false, false, false, false};
+    int snap_resident_iters = 0, snap_last_inner_len = -1, snap_nsets = -1;
     double* d_busc = nullptr;   // rho-only constants of the bus update (k_bus_const); recomputed when rho changes
     bool busc_dirty = true;
     // hipGraph of one batch of fused inner iterations (exaadmm_run_inner); rebuilt when anything
@@ -2058,6 +2064,8 @@ static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
                            (h->last_inner_len < 0 || h->last_inner_len >= h->opt.heavy_split_prev) && h->heavy_max > 0;   // (a handle's first loop: one launch risked)
         // (a batch that another one follows must be a multiple of the number of buffer sets long: every launch starts on set 0)
         const int split_len = ((h->opt.heavy_split + h->nsets - 1) / h->nsets) * h->nsets;
+        // (launches of a convergence-tested loop are NOT cut into chunks of resident_chunk iterations the way exaadmm_run_fixed's are: measured, the
+        //  extra launches cost a whole solve 1.5 - 2.5 % -- its loops are short and their first half is not a steady state)
         const int nb = std::min(resident ? (split && enq < split_len ? split_len - enq : 1024) : batch, max_inner - enq);
         *h->h_base = enq;   // the stream is idle here (synchronised at the end of every batch)
         HIPCHK(hipMemcpyAsync(&h->d_ctrl->base, h->h_base, sizeof(int), hipMemcpyHostToDevice, h->stream));
@@ -2387,8 +2395,13 @@ static int run_fixed_impl(exaadmm_handle* h, int iters, int first_major_iter, do
             if (resident) {
                 // ONE launch for all `iters` iterations: every wavefront stays resident, a bus is updated by the last lane to arrive at it
                 if (time_branch) HIPCHK(hipEventRecord(h->ev[2], h->stream));
-                if ((rc = enqueue_resident(h, iters, first_major_iter - 1)) < 0) return rc;
-                refused = rc > 0;
+                // (option resident_chunk = C > 0: launches of at most C iterations -- every launch chooses its heavy wavefronts anew)
+                const int chunk = (h->opt.resident_chunk > 0 && resident_mode(h) == 1 && !dist_has_peers(h) && h->opt.heavy != 0 && h->heavy_max > 0) ? std::max(h->nsets, (h->opt.resident_chunk / h->nsets) * h->nsets) : iters;
+                for (int i0 = 0; i0 < iters && !refused; i0 += chunk) {
+                    if (i0 > 0) hipLaunchKernelGGL(k_ctrl_set_base, dim3(1), dim3(1), 0, h->stream, h->d_ctrl, first_major_iter - 1 + i0);
+                    if ((rc = enqueue_resident(h, std::min(chunk, iters - i0), first_major_iter - 1 + i0)) < 0) return rc;
+                    refused = rc > 0;
+                }
                 if (time_branch) HIPCHK(hipEventRecord(h->ev[3], h->stream));   // (one launch: its time / iters is reported)
             } else if (dist_has_peers(h)) {
                 // batches of 12 like the convergence-tested loop: the first one enqueued directly (its first launch has no z / l
@@ -2671,7 +2684,7 @@ const OptKey OPT_KEYS[] = {
     {"bus_kernel_lane", &Options::bus_kernel_lane, 0, 1}, {"graph", &Options::graph, 0, 1}, {"spec", &Options::spec, 0, 1},
     {"mp_spec", &Options::mp_spec, 0, 1}, {"rec", &Options::rec, 0, 1}, {"resident", &Options::resident, 0, 1},
     {"resident_tiles", &Options::resident_tiles, 0, 1}, {"resident_coop", &Options::resident_coop, 0, 1}, {"heavy", &Options::heavy, 0, 1},
-    {"heavy_from", &Options::heavy_from, 0, 1 << 30}, {"heavy_max", &Options::heavy_max, 0, 512}, {"heavy_select_small", &Options::heavy_select_small, 0, 1}, {"heavy_window", &Options::heavy_window, 0, 1 << 20}, {"heavy_split", &Options::heavy_split, 0, 1 << 20}, {"heavy_split_prev", &Options::heavy_split_prev, 0, 1 << 20}, {"resident_cap_limit", &Options::resident_cap_limit, 0, 1 << 20}, {"dist_overlap", &Options::dist_overlap, 0, 1}, {"dist_graph", &Options::dist_graph, 0, 1}, {"dist_p2p", &Options::dist_p2p, 0, 1},
+    {"heavy_from", &Options::heavy_from, 0, 1 << 30}, {"heavy_max", &Options::heavy_max, 0, 512}, {"heavy_select_small", &Options::heavy_select_small, 0, 1}, {"heavy_window", &Options::heavy_window, 0, 1 << 20}, {"heavy_split", &Options::heavy_split, 0, 1 << 20}, {"heavy_split_prev", &Options::heavy_split_prev, 0, 1 << 20}, {"resident_chunk", &Options::resident_chunk, 0, 1 << 20}, {"resident_cap_limit", &Options::resident_cap_limit, 0, 1 << 20}, {"dist_overlap", &Options::dist_overlap, 0, 1}, {"dist_graph", &Options::dist_graph, 0, 1}, {"dist_p2p", &Options::dist_p2p, 0, 1},
     {"trust_resident", &Options::trust_resident, 0, 1}, {"verbose", &Options::verbose, 0, 1}, {"prof_resident", &Options::prof_resident, 0, 1},
 };
 }  // namespace
@@ -2764,6 +2777,18 @@ extern "C" int exaadmm_state_save(exaadmm_handle* h)
                        h->d.r_u, h->d.r_s, h->d.r_z, h->d.r_zp, h->d.r_l, h->d.r_lz, h->d.r_mu, h->d.r_xi};
     for (size_t q = 0; q < h->snap.size(); q++)
         HIPCHK(hipMemcpyAsync(h->snap[q], src[q], (q < 6 ? (size_t)h->N : (q < 9 ? (size_t)h->Lp : nramp)) * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    {
+        const int* hist[4] = {h->nsets > 0 ? h->sets[0].st[2] : h->d.st_ticks, h->nsets > 1 ? h->sets[1].st[2] : nullptr, h->nsets > 2 ? h->sets[2].st[2] : nullptr, h->rsync.last3};
+        for (int q = 0; q < 4; q++) {
+            h->snap_hist_valid[q] = hist[q] != nullptr;
+            if (!hist[q]) continue;
+            if (!h->snap_hist[q] && (rc = dev_alloc(h, &h->snap_hist[q], (size_t)h->Lp))) return rc;
+            HIPCHK(hipMemcpyAsync(h->snap_hist[q], hist[q], (size_t)h->Lp * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+        }
+        h->snap_resident_iters = h->resident_iters;
+        h->snap_nsets = h->nsets;
+        h->snap_last_inner_len = h->last_inner_len;
+    }
     return sync_check(h, true);
 }
 
@@ -2776,6 +2801,18 @@ extern "C" int exaadmm_state_restore(exaadmm_handle* h)
                        h->d.r_u, h->d.r_s, h->d.r_z, h->d.r_zp, h->d.r_l, h->d.r_lz, h->d.r_mu, h->d.r_xi};
     for (size_t q = 0; q < h->snap.size(); q++)
         HIPCHK(hipMemcpyAsync(dst[q], h->snap[q], (q < 6 ? (size_t)h->N : (q < 9 ? (size_t)h->Lp : nramp)) * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    {
+        int* hist[4] = {h->nsets > 0 ? h->sets[0].st[2] : h->d.st_ticks, h->nsets > 1 ? h->sets[1].st[2] : nullptr, h->nsets > 2 ? h->sets[2].st[2] : nullptr, h->rsync.last3};
+        for (int q = 0; q < 4 && h->nsets == h->snap_nsets; q++) {   // (the buffer sets were set up differently when the state was saved: the history stays)
+            if (!hist[q]) continue;
+            if (h->snap_hist_valid[q])
+                HIPCHK(hipMemcpyAsync(hist[q], h->snap_hist[q], (size_t)h->Lp * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+            else   // (a buffer that did not exist when the state was saved held nothing then)
+                HIPCHK(hipMemsetAsync(hist[q], 0, (size_t)h->Lp * sizeof(int), h->stream));
+        }
+        h->resident_iters = h->snap_resident_iters;
+        h->last_inner_len = h->snap_last_inner_len;
+    }
     h->residual_vectors_valid = false;
     return sync_check(h, true);
 }

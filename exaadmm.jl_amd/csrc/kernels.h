@@ -2359,10 +2359,15 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
 // cut_code (a partition with peers, else nullptr): cut branches are passed by -- their lanes talk to the peers, a heavy wavefront never does.
 __device__ __forceinline__ int heavy_key(const int* __restrict__ ticks0, const int* __restrict__ ticks1, const int* __restrict__ last3, int now, int window, int b)
 {
+    // trips of the last two iterations if >= 3; else by how long ago the branch last needed >= 3: within `window` iterations 3, within 4 x window 2,
+    // within 16 x window 1 (the slots that the first tier leaves free go to the next one: the heavy set of a launch of 50 - 200 iterations is
+    // better the more of the stragglers of the last few hundred iterations it holds -- measured with HONEST replays, see exaadmm_state_restore)
     const int k = min(63, max(ticks0[b], ticks1[b]));
+    if (k >= 3) return k;
     const int h = last3[b];
-    const bool recent = window > 0 && h != 0 && now - (h >> 4) <= window;
-    return (k < 3 && recent) ? 3 : k;
+    if (window <= 0 || h == 0) return 0;
+    const int age = now - (h >> 4);
+    return age <= window ? 3 : (age <= 4 * window ? 2 : (age <= 16 * window ? 1 : 0));
 }
 __global__ void __launch_bounds__(1024) k_heavy_select(const int* __restrict__ ticks0, const int* __restrict__ ticks1, int L, int Lp, int nmax,
                                                        int* __restrict__ list, int* __restrict__ flag, const double* __restrict__ z,
@@ -2386,12 +2391,12 @@ __global__ void __launch_bounds__(1024) k_heavy_select(const int* __restrict__ t
         for (int j = 0; j < U; j++) {
             const int b = b0 + j * nthreads;
             const bool on = b < L && (cut_code == nullptr || cut_code[b] < 0);
-            key[j] = on ? heavy_key(ticks0, ticks1, last3, now, window, b) : -1;
+            key[j] = on ? heavy_key(ticks0, ticks1, last3, now, window, b) : 0;
         }
 #pragma unroll
         for (int j = 0; j < U; j++) {
             const int b = b0 + j * nthreads;
-            if (key[j] >= 0) atomicAdd(&hist[key[j]], 1);
+            if (key[j] > 0) atomicAdd(&hist[key[j]], 1);
             if (b < Lp) flag[b] = key[j];
         }
     }
@@ -2399,7 +2404,7 @@ __global__ void __launch_bounds__(1024) k_heavy_select(const int* __restrict__ t
     __syncthreads();
     if (tid == 0) {
         int t = 64, acc = 0;
-        while (t > 3 && acc + hist[t - 1] <= nmax) {
+        while (t > 1 && acc + hist[t - 1] <= nmax) {
             t--;
             acc += hist[t];
         }
@@ -2412,13 +2417,13 @@ __global__ void __launch_bounds__(1024) k_heavy_select(const int* __restrict__ t
 #pragma unroll
         for (int j = 0; j < U; j++) {
             const int b = b0 + j * nthreads;
-            key[j] = (b < Lp) ? flag[b] : -1;   // (written by this thread above)
+            key[j] = (b < Lp) ? flag[b] : 0;   // (written by this thread above)
         }
 #pragma unroll
         for (int j = 0; j < U; j++) {
             const int b = b0 + j * nthreads;
             int f = 0;
-            if (key[j] >= T) {
+            if (key[j] >= T && key[j] > 0) {
                 const int pos = atomicAdd(&count, 1);
                 list[pos] = b;
                 f = pos + 1;

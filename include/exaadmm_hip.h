@@ -197,7 +197,9 @@ int exaadmm_resident_selfcheck_stats(exaadmm_handle *h, int *checks, int *mismat
  *   "heavy" (1)            heavy wavefronts (the branches with the most solver trips on wavefronts of their own)
  *   "heavy_from" (64)      first iteration of an inner loop from which a resident launch may carry heavy wavefronts
  *   "heavy_max" (512)      at most this many of them (they take the SIMDs the launch leaves idle; fewer when the GPU is shared)
- *   "heavy_window" (32)    a branch that needed >= 3 solver trips in any of the last this-many resident iterations is a candidate too (0: only the last two count)
+ *   "heavy_window" (64)    W: a branch that needed >= 3 solver trips in the last W resident iterations is a candidate too, after those of the last two
+ *                          iterations; then those of the last 4 W, then 16 W iterations, as far as the heavy wavefronts reach (0: only the last two count)
+ *   "resident_chunk" (50)  exaadmm_run_fixed on a grid with heavy wavefronts: launches of at most this many iterations, each with a fresh choice (0: one launch)
  *   "heavy_split" (32)     > 0: the first launch of a convergence-tested inner loop ends after this many iterations and the rest of the loop runs with heavy
  *                          wavefronts -- when the handle's previous inner loop ran at least "heavy_split_prev" (96) iterations; 0: one launch per 1 024 iterations
  *   "heavy_select_small" (0) 1: the kernel that picks them runs as ONE wavefront (slower; a block of 16 wavefronts cannot start on a GPU whose

@@ -71,7 +71,7 @@ extern "C" int exaadmm_dist_detach(exaadmm_handle* h);
 // environment variable of its own: a host that wants its switches from the environment translates them.
 struct Options {
     int bus_kernel_lane = 0, graph = 1, spec = 1, mp_spec = 1, rec = 1;
-    int resident = 1, resident_tiles = 1, resident_coop = 1, heavy = 1, heavy_from = 64, heavy_max = 512, heavy_select_small = 0, heavy_window = 64, heavy_split = 32, heavy_split_prev = 96, resident_chunk = 50;
+    int resident = 1, resident_tiles = 1, resident_coop = 1, heavy = 1, heavy_from = 64, heavy_max = 512, heavy_select_small = 0, heavy_window = 64, heavy_split = 32, heavy_split_prev = 96, resident_chunk = 0, heavy_adopt = 4;
     int resident_cap_limit = 0;   // > 0: pretend the chip holds no more resident wavefronts than this (tests: the two-tile form on small grids)
     int dist_overlap = 1, dist_graph = 1, dist_p2p = 1;
     int trust_resident = 0, verbose = 0;
@@ -1633,9 +1633,15 @@ static int resident_prepare(exaadmm_handle* h, const Ctrl* begin = nullptr)
         h->rheavy.list = t;
         h->rheavy.flag = t + std::max(1, h->heavy_max);
         double* hu = nullptr;
-        if ((rc = dev_alloc(h, &hu, 3 * 16 * (size_t)std::max(1, h->heavy_max)))) return rc;
+        if ((rc = dev_alloc(h, &hu, (3 * 16 + 32) * (size_t)std::max(1, h->heavy_max)))) return rc;
         h->rheavy.u = hu;
         h->rheavy.init = hu + 2 * 16 * (size_t)std::max(1, h->heavy_max);
+        h->rheavy.adopt = hu + 3 * 16 * (size_t)std::max(1, h->heavy_max);
+        int* rq = nullptr;
+        if ((rc = dev_alloc(h, &rq, (size_t)std::max(1, h->heavy_max) + 2))) return rc;
+        HIPCHK(hipMemsetAsync(rq, 0, ((size_t)std::max(1, h->heavy_max) + 2) * sizeof(int), h->stream));
+        h->rheavy.req = rq;
+        h->rheavy.cnt = rq + std::max(1, h->heavy_max);
     }
     if (!r.last3) {
         if ((rc = dev_alloc(h, &r.last3, (size_t)h->Lp))) return rc;
@@ -1694,7 +1700,8 @@ static int enqueue_resident(exaadmm_handle* h, int n, int loop_iter0)
         rh.n = std::min(h->heavy_max, h->opt.heavy_max);
         hipLaunchKernelGGL(k_heavy_select, dim3(1), dim3(h->opt.heavy_select_small != 0 ? 64 : 1024), 0, h->stream, (const int*)h->sets[0].st[2], (const int*)h->sets[1].st[2], h->L, h->Lp, rh.n,
                            const_cast<int*>(rh.list), const_cast<int*>(rh.flag), (const double*)h->d.z, (const double*)h->d.l, 2 * h->Gp, const_cast<double*>(rh.init),
-                           peers ? h->rpeers.cut_code : (const int*)nullptr, (const int*)h->rsync.last3, h->resident_iters, h->opt.heavy_window);
+                           peers ? h->rpeers.cut_code : (const int*)nullptr, (const int*)h->rsync.last3, h->resident_iters, h->opt.heavy_window, rh.req, rh.cnt);
+        rh.adopt_thr = h->opt.heavy_adopt;
         grid += rh.n;
     }
     h->form_tiles = mode;
@@ -2684,7 +2691,7 @@ const OptKey OPT_KEYS[] = {
     {"bus_kernel_lane", &Options::bus_kernel_lane, 0, 1}, {"graph", &Options::graph, 0, 1}, {"spec", &Options::spec, 0, 1},
     {"mp_spec", &Options::mp_spec, 0, 1}, {"rec", &Options::rec, 0, 1}, {"resident", &Options::resident, 0, 1},
     {"resident_tiles", &Options::resident_tiles, 0, 1}, {"resident_coop", &Options::resident_coop, 0, 1}, {"heavy", &Options::heavy, 0, 1},
-    {"heavy_from", &Options::heavy_from, 0, 1 << 30}, {"heavy_max", &Options::heavy_max, 0, 512}, {"heavy_select_small", &Options::heavy_select_small, 0, 1}, {"heavy_window", &Options::heavy_window, 0, 1 << 20}, {"heavy_split", &Options::heavy_split, 0, 1 << 20}, {"heavy_split_prev", &Options::heavy_split_prev, 0, 1 << 20}, {"resident_chunk", &Options::resident_chunk, 0, 1 << 20}, {"resident_cap_limit", &Options::resident_cap_limit, 0, 1 << 20}, {"dist_overlap", &Options::dist_overlap, 0, 1}, {"dist_graph", &Options::dist_graph, 0, 1}, {"dist_p2p", &Options::dist_p2p, 0, 1},
+    {"heavy_from", &Options::heavy_from, 0, 1 << 30}, {"heavy_max", &Options::heavy_max, 0, 512}, {"heavy_select_small", &Options::heavy_select_small, 0, 1}, {"heavy_window", &Options::heavy_window, 0, 1 << 20}, {"heavy_split", &Options::heavy_split, 0, 1 << 20}, {"heavy_split_prev", &Options::heavy_split_prev, 0, 1 << 20}, {"resident_chunk", &Options::resident_chunk, 0, 1 << 20}, {"heavy_adopt", &Options::heavy_adopt, 0, 63}, {"resident_cap_limit", &Options::resident_cap_limit, 0, 1 << 20}, {"dist_overlap", &Options::dist_overlap, 0, 1}, {"dist_graph", &Options::dist_graph, 0, 1}, {"dist_p2p", &Options::dist_p2p, 0, 1},
     {"trust_resident", &Options::trust_resident, 0, 1}, {"verbose", &Options::verbose, 0, 1}, {"prof_resident", &Options::prof_resident, 0, 1},
 };
 }  // namespace

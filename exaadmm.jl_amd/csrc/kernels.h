@@ -1466,8 +1466,19 @@ struct ResidentTiles {
 // into that loop the side-by-side search cost every trip of every lane 8 - 21 % (profiles/r04_lone_search.txt).
 struct ResidentHeavy {
     const int* list;   // [n] storage slot of the branch of heavy wavefront w, -1: none
-    const int* flag;   // [Lp] w + 1: the branch is solved by heavy wavefront w in this launch, 0: by its lane
+    int* flag;         // [Lp] w + 1: the branch is solved by heavy wavefront w in this launch, 0: by its lane (bit 20: adopted at the end of the last index)
     const double* init;   // [n][16] z, l of the heavy branches in front of the launch (k_heavy_select)
+    // ADOPTION (adopt_thr > 0): a branch lane whose solve took >= adopt_thr trips hands its branch over to one of the launch's FREE heavy
+    // wavefronts (those behind the cnt[0] chosen in front of the launch), from the next index on: it takes a ticket (cnt[1]), writes the
+    // branch's state -- u, z, l, multipliers, penalty: 27 doubles -- into adopt[w] with agent-scope stores and, behind their acknowledgement,
+    // req[w] = (branch + 1) | (first index << 20); it marks flag[b] = (w + 1) | fresh (its own next index takes u from the planes it has just
+    // written, every later one from the heavy wavefront's hand-over).  A free heavy wavefront polls req[w] until a request, a stop, or the
+    // launch's last decision.  New stragglers emerge all the time (and a launch chose its heavy wavefronts before it began); a straggler that
+    // stays with its tile paces the whole launch until the next launch.
+    double* adopt;     // [n][32]
+    int* req;          // [n]
+    int* cnt;          // [0] heavy wavefronts chosen in front of the launch, [1] tickets taken so far
+    int adopt_thr;
     double* u;         // [2][n][16] hand-over of a heavy branch's u (8 of the 16) to its tile's lane, by iteration parity -- lines that
                        //  only agent-scope accesses ever touch.  (NOT through the u plane: the tile's wavefront holds that line in its
                        //  XCD's L2 for its plain accesses to the neighbouring branches, and an agent-scope load of such a line is
@@ -1635,6 +1646,23 @@ __global__ void __launch_bounds__(64) k_p2p_exchange4(ResidentPeers rp, unsigned
     if (ctrl != nullptr) ctrl_advance(ctrl, s);
 }
 
+// The results of an ADOPTED branch's last solve, from its heavy wavefront's hand-over into the planes of the buffer set that solve belongs to
+// (dp: that set), by the branch's own lane (ResidentHeavy: adoption; u has been read already).  stamp: the resident iteration of that solve.
+__device__ __forceinline__ void adopted_results_to_planes(const Dev& dp, const ResidentSync& rs, const double* ho, const double (&u)[8], int b, int base, int Lp, int stamp)
+{
+#pragma unroll
+    for (int k = 0; k < 8; k++) dp.u[base + k * Lp] = u[k];
+    dp.ls1[b] = ld_agent(ho + 8);
+    dp.ls2[b] = ld_agent(ho + 9);
+    dp.mu[b] = ld_agent(ho + 10);
+    const long long pk = __double_as_longlong(ld_agent(ho + 11));
+    const int ticks = (int)((pk >> 40) & 0xfffff);
+    dp.st_auglag[b] = (int)(pk & 0xfffff);
+    dp.st_minor[b] = (int)((pk >> 20) & 0xfffff);
+    dp.st_ticks[b] = ticks;
+    if (ticks >= 3) rs.last3[b] = (stamp << 4) | min(ticks, 15);
+}
+
 template <int TILES, bool HEAVY = false, bool PEERS = false>
 __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restrict__ dp0, const Dev* __restrict__ dp1, BranchOptions o, double scale,
                                                              Ctrl* ctrl, int gen_blocks, double baseMVA, int iters, ResidentSync rs, ResidentTiles rt,
@@ -1715,8 +1743,33 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
     if (TILES == 1 && HEAVY && (int)blockIdx.x >= nwaves) {
         // ---------------- heavy wavefront: one branch, 64 clones
         const int hw = (int)blockIdx.x - nwaves;
-        const int b = rh.list[hw];
-        if (b < 0) return;
+        int b = rh.list[hw], i_start = 0;
+        if (b < 0) {
+            // a FREE heavy wavefront: waits for a branch lane to hand it a straggler (ResidentHeavy: adoption), for the stop, or for the
+            // launch's last decision (every request is out before the pass that decision is made from)
+            const int npass_all = resident_passes(first_has_zl, iters - 1);
+            if (rh.adopt_thr <= 0 || npass_all <= 0) return;
+            int r = 0, spins = 0;
+            for (;;) {
+                r = __hip_atomic_load(rh.req + hw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (r != 0) break;
+                if ((spins & 15) == 15) {
+                    const int v = __hip_atomic_load(rs.decided, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((v & RESIDENT_STOP_BIT) != 0 || __hip_atomic_load(rs.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+                    if (v >= npass_all) {
+                        r = __hip_atomic_load(rh.req + hw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (r == 0) return;
+                        break;
+                    }
+                }
+                ++spins;
+                __builtin_amdgcn_s_sleep(64);
+            }
+            asm volatile("" ::: "memory");
+            b = (r & 0xfffff) - 1;
+            i_start = r >> 20;
+        }
+        const bool adopted = i_start > 0;
         if (lane < 24) reinterpret_cast<double*>(&pw_lds)[lane] = reinterpret_cast<const double*>(&c_mupow)[lane];
         double* const park_h = park_lds;
         double* const search_h = park_lds + 32 * BR_BLOCK;   // (entries 32 .. 39 hold z in the ordinary lanes' use of the area)
@@ -1738,14 +1791,28 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
                 keep[k] = d0.bnd[b + k * Lp];
                 keep[8 + k] = d0.lz[e];
             }
-            zc[k] = rh.init[16 * hw + k];
-            lc[k] = rh.init[16 * hw + 8 + k];
-            uc[k] = (d0.u_in ? d0.u_in : d0.u)[e];
+            if (!adopted) {
+                zc[k] = rh.init[16 * hw + k];
+                lc[k] = rh.init[16 * hw + 8 + k];
+                uc[k] = (d0.u_in ? d0.u_in : d0.u)[e];
+            } else {   // (what the branch's lane left in its request: the state behind index i_start - 1)
+                const double* const rec = rh.adopt + 32 * (size_t)hw;
+                uc[k] = ld_agent(rec + k);
+                zc[k] = ld_agent(rec + 8 + k);
+                lc[k] = ld_agent(rec + 16 + k);
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        bd.ls1 = (d0.ls1_in ? d0.ls1_in : d0.ls1)[b];
-        bd.ls2 = (d0.ls2_in ? d0.ls2_in : d0.ls2)[b];
-        bd.mu = (d0.mu_in ? d0.mu_in : d0.mu)[b];
+        if (!adopted) {
+            bd.ls1 = (d0.ls1_in ? d0.ls1_in : d0.ls1)[b];
+            bd.ls2 = (d0.ls2_in ? d0.ls2_in : d0.ls2)[b];
+            bd.mu = (d0.mu_in ? d0.mu_in : d0.mu)[b];
+        } else {
+            const double* const rec = rh.adopt + 32 * (size_t)hw;
+            bd.ls1 = ld_agent(rec + 24);
+            bd.ls2 = ld_agent(rec + 25);
+            bd.mu = ld_agent(rec + 26);
+        }
         bd.scale = scale;
         const double rate_0 = d0.rateA[b];
         // The bus updates of the last iteration that THIS wavefront completed (its lanes 0 and 1 arrive at the two buses side by side;
@@ -1753,7 +1820,7 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
         // no wait for a flag it raised itself, no read-back.  (wave-uniform)
         double keep_f[4] = {0.0, 0.0, 0.0, 0.0}, keep_t[4] = {0.0, 0.0, 0.0, 0.0};
         bool have_f = false, have_t = false;
-        for (int i = 0; i < iters; i++) {
+        for (int i = i_start; i < iters; i++) {
 #if defined(EXA_PROFILE_PHASES)
             unsigned long long hts[8], hx[4] = {0ull, 0ull, 0ull, 0ull};   // diagnostic build: stamps of this iteration of the heavy wavefront (scripts/heavy_timeline.py)
             hts[0] = __builtin_amdgcn_s_memtime();
@@ -1861,18 +1928,28 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
                 double* const ho = rh.u + ((size_t)(i & 1) * nheavy + hw) * 16;   // (read by the tile's lane with its next z / l pass)
 #pragma unroll
                 for (int k = 0; k < 8; k++) st_agent(ho + k, uc[k]);
-                // (the planes' words of this branch are written here only: the tile's lane leaves them alone.  They share cache lines
-                //  with the neighbouring branches' words, which the tile's wavefront writes from another XCD -- different bytes of a
-                //  line dirty in two L2s, merged by the byte masks of the write-backs like the output of any two workgroups)
+                if (adopted) {
+                    // an ADOPTED branch: its lane wrote these planes' words earlier in this launch, so the lane goes on writing them -- from
+                    // this hand-over, with its next z / l pass (one word dirty in two XCDs' L2s leaves the result to the order of the
+                    // write-backs: seen with the first form of the adoption, which let the heavy wavefront write them)
+                    st_agent(ho + 8, bd.ls1);
+                    st_agent(ho + 9, bd.ls2);
+                    st_agent(ho + 10, bd.mu);
+                    st_agent(ho + 11, __longlong_as_double((long long)(unsigned)st.auglag_it | ((long long)(unsigned)st.minor_it << 20) | ((long long)(unsigned)st.ticks << 40)));
+                } else {
+                    // (a branch chosen in front of the launch: the planes' words of this branch are written here only, the tile's lane leaves them
+                    //  alone.  They share cache lines with the neighbouring branches' words, which the tile's wavefront writes from another XCD --
+                    //  different bytes of a line dirty in two L2s, merged by the byte masks of the write-backs like the output of any two workgroups)
 #pragma unroll
-                for (int k = 0; k < 8; k++) d.u[base + k * Lp] = uc[k];
-                d.ls1[b] = bd.ls1;
-                d.ls2[b] = bd.ls2;
-                d.mu[b] = bd.mu;
-                d.st_auglag[b] = st.auglag_it;
-                d.st_minor[b] = st.minor_it;
-                d.st_ticks[b] = st.ticks;
-                if (st.ticks >= 3) rs.last3[b] = ((rs.stamp0 + i + 1) << 4) | min(st.ticks, 15);
+                    for (int k = 0; k < 8; k++) d.u[base + k * Lp] = uc[k];
+                    d.ls1[b] = bd.ls1;
+                    d.ls2[b] = bd.ls2;
+                    d.mu[b] = bd.mu;
+                    d.st_auglag[b] = st.auglag_it;
+                    d.st_minor[b] = st.minor_it;
+                    d.st_ticks[b] = st.ticks;
+                    if (st.ticks >= 3) rs.last3[b] = ((rs.stamp0 + i + 1) << 4) | min(st.ticks, 15);
+                }
 #if defined(EXA_PROFILE_PHASES)
                 for (int q = 0; q < 13; q++) d.st_cyc[q * d.Lp + b] = st.cyc[q] + (q == 12 ? 1000ull : 0ull);   // (phase clocks of the heavy wavefront's last solve; entry 12 = 1000 + trips marks it)
                 asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(hx[0]) : : "memory");   // hand-over, planes, diagnostics acknowledged (the shipped build does not wait here)
@@ -2045,8 +2122,13 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
             const int4 bus4 = reinterpret_cast<const int4*>(d.br_bus4)[b];
             // (TILES = 1) the lane's branch is solved by a heavy wavefront in this launch: z / l pass, residual terms and v here, nothing
             // else.  No value of its own across the solve: rec_from = -1 says so, rec_to holds the heavy wavefront's number.
-            const int hflag = (TILES == 1 && HEAVY && nheavy > 0) ? rh.flag[b] : 0;
+            const int hflag_raw = (TILES == 1 && HEAVY && nheavy > 0) ? rh.flag[b] : 0;
+            const int hflag = hflag_raw & 0xfffff;
             const bool heavy_lane = lane_on && hflag != 0;
+            // (adopted at the end of the last index: the u of that index is in the planes -- this lane wrote it --, not in the hand-over)
+            const bool heavy_fresh = heavy_lane && ((hflag_raw >> 20) & 1) != 0;
+            const bool heavy_mine = heavy_lane && ((hflag_raw >> 21) & 1) != 0;   // adopted in this launch: the planes' words of the branch stay this lane's
+            if (TILES == 1 && HEAVY && heavy_fresh) rh.flag[b] = hflag | (1 << 21);
             const int rec_from = heavy_lane ? -1 : d.rec_br[2 * b], rec_to = heavy_lane ? hflag - 1 : d.rec_br[2 * b + 1];
             const int major_iter = base_iter + i + 1;
             const bool do_zl = (i > 0) || first_has_zl;
@@ -2092,10 +2174,11 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
 #pragma unroll
                     for (int m = 0; m < 4; m++) rt4[m] = ld_agent(pt + m);
                 }
-                if (TILES == 1 && HEAVY && heavy_lane) {   // (as without peers: u of the last iteration from the branch's heavy wavefront)
+                if (TILES == 1 && HEAVY && heavy_lane && !heavy_fresh) {   // (as without peers: u of the last iteration from the branch's heavy wavefront)
                     const double* const ho = rh.u + ((size_t)((i - 1) & 1) * nheavy + rec_to) * 16;
 #pragma unroll
                     for (int k = 0; k < 8; k++) ub[k] = ld_agent(ho + k);
+                    if (heavy_mine) adopted_results_to_planes((i & 1) ? *dp0 : *dp1, rs, ho, ub, b, base, Lp, rs.stamp0 + i);
                 }
                 // Our bus's update to the twin lane FIRST -- every cut lane of the wavefront, in one region that only stores -- and only then
                 // the wait for the twin's.  (With the send and the wait of the two kinds of cut lanes in the two arms of one branch, a
@@ -2132,12 +2215,13 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
 #if defined(EXA_PROFILE_PHASES)
                 ts[2] = __builtin_amdgcn_s_memtime();   // both buses ready
 #endif
-                if (TILES == 1 && HEAVY && heavy_lane) {
+                if (TILES == 1 && HEAVY && heavy_lane && !heavy_fresh) {
                     // the results of the last iteration were handed over by the branch's heavy wavefront before it arrived: u for this
                     // z / l pass, and everything into the planes of the set that iteration wrote
                     const double* const ho = rh.u + ((size_t)((i - 1) & 1) * nheavy + rec_to) * 16;
 #pragma unroll
                     for (int k = 0; k < 8; k++) ub[k] = ld_agent(ho + k);
+                    if (heavy_mine) adopted_results_to_planes((i & 1) ? *dp0 : *dp1, rs, ho, ub, b, base, Lp, rs.stamp0 + i);
                 }
                 const double* pf = rs.busres[i & 1] + 4 * (size_t)bus4.x;
                 const double* pt = rs.busres[i & 1] + 4 * (size_t)bus4.z;
@@ -2184,6 +2268,7 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
 #if defined(EXA_PROFILE_PHASES)
             asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts[3]) : : "memory");   // v, z / l pass, contribution done
 #endif
+            int adopt_w = -1;   // (>= 0: this lane has just handed its branch to free heavy wavefront adopt_w: ResidentHeavy, adoption)
             if (lane_on && !(TILES == 1 && HEAVY && heavy_lane)) {
                 bd.mu = (major_iter == 1) ? 10.0 : mu_0;
                 bd.scale = scale;
@@ -2230,11 +2315,31 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
                 d.st_minor[b] = st.minor_it;
                 d.st_ticks[b] = st.ticks;
                 if (TILES == 1 && st.ticks >= 3) rs.last3[b] = ((rs.stamp0 + i + 1) << 4) | min(st.ticks, 15);
+                if (TILES == 1 && HEAVY && rh.adopt_thr > 0 && st.ticks >= rh.adopt_thr && i + 1 < iters && (!PEERS || ccode < 0)) {
+                    // a straggler: from the next index on one of the launch's free heavy wavefronts solves this branch (ResidentHeavy: adoption)
+                    const int w = rh.cnt[0] + __hip_atomic_fetch_add(rh.cnt + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (w < nheavy) {
+                        double* const rec = rh.adopt + 32 * (size_t)w;
+#pragma unroll
+                        for (int k = 0; k < 8; k++) {
+                            st_agent(rec + k, un[k]);
+                            st_agent(rec + 8 + k, zz[k]);
+                            st_agent(rec + 16 + k, bd.lam_[k]);
+                        }
+                        st_agent(rec + 24, bd.ls1);
+                        st_agent(rec + 25, bd.ls2);
+                        st_agent(rec + 26, bd.mu);
+                        rh.flag[b] = (w + 1) | (1 << 20) | (1 << 21);
+                        adopt_w = w;
+                    }
+                }
 #if defined(EXA_PROFILE_PHASES)
                 for (int q = 0; q < 13; q++) d.st_cyc[q * d.Lp + b] = st.cyc[q];   // (phase clocks of the lane's last solve)
 #endif
             }
             resident_order_stores();
+            if (TILES == 1 && HEAVY && adopt_w >= 0)   // (behind the acknowledgement of the record: the request itself)
+                __hip_atomic_store(rh.req + adopt_w, (b + 1) | ((i + 1) << 20), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #if defined(EXA_PROFILE_PHASES)
             ts[5] = __builtin_amdgcn_s_memtime();   // results and terms stored
 #endif
@@ -2330,11 +2435,13 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
             ll[k] = d.l[e];
             rr[k] = d.rho[e];
         }
-        const int hflag = (TILES == 1 && HEAVY && nheavy > 0) ? rh.flag[b] : 0;
+        const int hflag_raw = (TILES == 1 && HEAVY && nheavy > 0) ? rh.flag[b] : 0;   // (no adoption in the launch's last index: never fresh here)
+        const int hflag = hflag_raw & 0xfffff;
         if (hflag != 0) {   // (the results of the last iteration from the heavy wavefront's hand-over, as in the loop)
             const double* const ho = rh.u + ((size_t)((iters - 1) & 1) * nheavy + (hflag - 1)) * 16;
 #pragma unroll
             for (int k = 0; k < 8; k++) uu[k] = ld_agent(ho + k);
+            if (((hflag_raw >> 21) & 1) != 0) adopted_results_to_planes(d, rs, ho, uu, b, base, d.Lp, rs.stamp0 + iters);
         }
         d.v[base] = (uu[0] + zz[0]) + (ll[0] + rf[0]) / rr[0];
         d.v[base + Lp] = (uu[1] + zz[1]) + (ll[1] + rf[1]) / rr[1];
@@ -2372,7 +2479,7 @@ __device__ __forceinline__ int heavy_key(const int* __restrict__ ticks0, const i
 __global__ void __launch_bounds__(1024) k_heavy_select(const int* __restrict__ ticks0, const int* __restrict__ ticks1, int L, int Lp, int nmax,
                                                        int* __restrict__ list, int* __restrict__ flag, const double* __restrict__ z,
                                                        const double* __restrict__ l, int elem0, double* __restrict__ init, const int* __restrict__ cut_code,
-                                                       const int* __restrict__ last3, int now, int window)
+                                                       const int* __restrict__ last3, int now, int window, int* __restrict__ req, int* __restrict__ cnt)
 {
     // (one block: it sits between a call's opening launch and the resident launch, 30 us of every call when every thread walked its
     //  branches one load round trip after the other; now eight branches' loads are in flight per thread and the keys of the first pass wait
@@ -2436,6 +2543,14 @@ __global__ void __launch_bounds__(1024) k_heavy_select(const int* __restrict__ t
     for (int q = tid; q < 16 * n; q += nthreads) {
         const int w = q >> 4, k = q & 7, e = elem0 + list[w] + k * Lp;
         init[q] = (q & 8) ? l[e] : z[e];
+    }
+    // adoption (ResidentHeavy): no request yet, no ticket taken, the free heavy wavefronts start behind the n chosen here
+    if (req != nullptr) {
+        for (int w = tid; w < nmax; w += nthreads) req[w] = 0;
+        if (tid == 0) {
+            cnt[0] = n;
+            cnt[1] = 0;
+        }
     }
 }
 

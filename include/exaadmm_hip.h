@@ -199,7 +199,10 @@ int exaadmm_resident_selfcheck_stats(exaadmm_handle *h, int *checks, int *mismat
  *   "heavy_max" (512)      at most this many of them (they take the SIMDs the launch leaves idle; fewer when the GPU is shared)
  *   "heavy_window" (64)    W: a branch that needed >= 3 solver trips in the last W resident iterations is a candidate too, after those of the last two
  *                          iterations; then those of the last 4 W, then 16 W iterations, as far as the heavy wavefronts reach (0: only the last two count)
- *   "resident_chunk" (50)  exaadmm_run_fixed on a grid with heavy wavefronts: launches of at most this many iterations, each with a fresh choice (0: one launch)
+ *   "heavy_adopt" (4)      a branch lane whose solve took at least this many trips hands its branch to one of the launch's free heavy wavefronts, from the
+ *                          next iteration on (0: the heavy wavefronts of a launch are those chosen in front of it)
+ *   "resident_chunk" (0)   > 0: exaadmm_run_fixed on a grid with heavy wavefronts launches at most this many iterations at a time, each launch with a
+ *                          fresh choice (what the adoption made unnecessary: 0.1 ms per launch)
  *   "heavy_split" (32)     > 0: the first launch of a convergence-tested inner loop ends after this many iterations and the rest of the loop runs with heavy
  *                          wavefronts -- when the handle's previous inner loop ran at least "heavy_split_prev" (96) iterations; 0: one launch per 1 024 iterations
  *   "heavy_select_small" (0) 1: the kernel that picks them runs as ONE wavefront (slower; a block of 16 wavefronts cannot start on a GPU whose

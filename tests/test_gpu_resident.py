@@ -146,6 +146,35 @@ def test_resident_whole_solves_reproduce_the_anchors_and_the_two_launch_runs(pkg
 
 
 @pytest.mark.skipif(SWITCHED_OFF or bool(os.environ.get("EXAADMM_NO_HEAVY")), reason="a switch of this run turns the resident loop / its heavy wavefronts off")
+@pytest.mark.parametrize("case,rho", [("case1354pegase", (1e1, 1e3)), ("case13659pegase", (5e1, 5e3))])
+def test_stragglers_adopted_by_free_heavy_wavefronts_inside_a_launch(pkg, case, rho):
+    """Option heavy_adopt = t: a branch lane whose solve took >= t trips hands its branch to a free heavy wavefront from the next
+    iteration on (kernels.h ResidentHeavy: adoption) -- the state travels through an agent-scope record, the planes' words of the
+    branch stay the lane's (it writes them from the heavy wavefront's hand-over).  Off, at the default and at 3 trips (many more
+    adoptions), launches of odd and even lengths and chunks of 14: every bit the same."""
+    syn = exaadmm_loader.load_submodule("synthetic")
+    g = syn.sized_like(case, seed=0)
+    runs = []
+    for adopt, chunk in ((0, 0), (4, 0), (3, 0), (3, 14)):
+        with _env(EXAADMM_HEAVY_ADOPT=adopt, EXAADMM_RESIDENT_CHUNK=chunk):
+            env = pkg.AdmmEnv(case, rho[0], rho[1], verbose=0, grid=g)
+            mod = pkg.ModelAcopf(env)
+            assert mod.loop_kind() == 2
+            out, it = [], 1
+            for K in (70, 3, 40, 1, 64, 33):
+                norms, _, _ = mod.run_fixed(K, first_major_iter=it, beta=1e3)
+                it += K
+                out.append(_state(mod) + [norms.copy()])
+            assert mod.loop_downgrades() == 0, pkg.library().exaadmm_last_error()
+            runs.append(out)
+            mod.close()
+    for other in runs[1:]:
+        for a, b in zip(runs[0], other):
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y)
+
+
+@pytest.mark.skipif(SWITCHED_OFF or bool(os.environ.get("EXAADMM_NO_HEAVY")), reason="a switch of this run turns the resident loop / its heavy wavefronts off")
 def test_whole_solves_whose_inner_loops_continue_with_heavy_wavefronts(pkg):
     """Option heavy_split = S: the first launch of every inner loop ends after S iterations and the rest of the loop runs with heavy
     wavefronts -- in loops that END BY THEIR STOP TEST.  A heavy wavefront does not wait for the stop decision before its solve

@@ -2,7 +2,7 @@
 """Split the rocprofv3 kernel trace of `bench.py --steps K --warmup W [--prep P]` by the phases of the run, so that the
 trace's average kernel durations can be compared with the HIP-event figure of the bench line (which covers the timed
 region only; the plain --stats average also covers the cold preparation iterations and the two whole solves).
-usage: kernel_trace_split.py <kernel_trace.csv> [K=200] [W=20] [P=300] [chunk=50]  ->  JSON on stdout"""
+usage: kernel_trace_split.py <kernel_trace.csv> [K=200] [W=20] [P=300] [chunk=0]  ->  JSON on stdout"""
 import csv
 import json
 import sys
@@ -13,7 +13,7 @@ f = sys.argv[1]
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 W = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 P = int(sys.argv[4]) if len(sys.argv) > 4 else 300
-CHUNK = int(sys.argv[5]) if len(sys.argv) > 5 else 50   # option resident_chunk of the run (0: one launch per region)
+CHUNK = int(sys.argv[5]) if len(sys.argv) > 5 else int(__import__('os').environ.get('EXAADMM_RESIDENT_CHUNK', '0') or 0)   # option resident_chunk of the run (0, the default: one launch per region)
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 out = {"trace": f, "phases": "preparation %d | warm-up %d | timed region %d | event-bracketed pass %d | whole solves (rest)" % (P, W, K, K)}
 for key, tag in (("k_branch", "k_branch"), ("k_bus", "k_bus_group")):

@@ -309,6 +309,10 @@ def main():
     # converges, 13.1 k it/s at iteration 320 and 16.3 k at 13 000, so consecutive stretches would not measure one thing)
     # -- until the GPU has been busy for about a second, and the MEDIAN region is reported: K = 20 steps last 1.6 ms, too
     # short for the driver's smi sampling to see and at the mercy of one scheduling hiccup.
+    # The saved state includes the per-branch solver-trip counters and the trip history from which a resident launch chooses its
+    # heavy wavefronts / pairs its tiles (exaadmm_state_save, round 5): without them a repeat chose them from what the PREVIOUS
+    # repeat had left behind -- the stragglers of its own future -- and ran 6.6 - 14 % faster than the first pass (DESIGN.md section 4,
+    # profiles/r05_honest_replays.txt).  Every repeat is now the first pass.
     can_snapshot = True   # (multi-period handles snapshot their ramp blocks as well)
     if can_snapshot:
         mod.state_save()

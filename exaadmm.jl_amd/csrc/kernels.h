@@ -2554,6 +2554,8 @@ __global__ void __launch_bounds__(1024) k_heavy_select(const int* __restrict__ t
     }
 }
 
+// (a history like k_heavy_select's was tried for these keys -- a tile whose straggler rests when the launch starts keeps its rank --: 8.08 k against
+//  8.35 k it/s at 88 207 branches, whole solve + 0.7 %: not kept)
 __global__ void __launch_bounds__(256) k_tile_keys(const int* __restrict__ ticks0, const int* __restrict__ ticks1, int L, int nb, int* __restrict__ key,
                                                    const int* __restrict__ cut_code)
 {

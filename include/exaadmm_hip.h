@@ -231,7 +231,9 @@ int exaadmm_run_fixed(exaadmm_handle *h, int iters, int first_major_iter, double
                       double *ms_total, double *ms_branch);
 
 /* device-side snapshot / restore of the iterate (u, v, z, z_prev, l, lz, line-limit multipliers and penalty; on a multi-period
- * handle the ramp blocks as well): benchmark drivers time repeated stretches of iterations from one defined ADMM state */
+ * handle the ramp blocks as well) AND of what the resident launches choose their heavy wavefronts / tile pairs from (the per-branch
+ * solver-trip counters of every buffer set, the trip history and its clock): benchmark drivers time repeated stretches of iterations
+ * from one defined state -- a repeat must not start with knowledge of what the previous repeat saw */
 int exaadmm_state_save(exaadmm_handle *h);
 int exaadmm_state_restore(exaadmm_handle *h);
 

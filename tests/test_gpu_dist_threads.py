@@ -373,6 +373,7 @@ def test_resident_loop_with_peers_is_the_single_handle_solve(world, case):
     assert out["exchanges_in_60_iterations"] == [0] * world, out       # (nothing goes through the communication library: the last sums use the mailboxes too)
 
 
+@pytest.mark.skipif(bool(os.environ.get("EXAADMM_NO_HEAVY")) or os.environ.get("EXAADMM_DIST_P2P") == "0", reason="a switch of this run turns the heavy wavefronts / the mailbox loop off")
 def test_resident_loop_with_peers_and_heavy_wavefronts_two_areas_of_the_headline_size():
     """Two areas of case13659pegase's size cut in two (the grid a plain `bench.py --gpus 2` runs), both ranks' resident kernels on the one
     GPU at the same time (2 x ~390 wavefronts + the heavy wavefronts that still fit): 60 iterations from the start, then 30 that continue

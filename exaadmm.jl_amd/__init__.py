@@ -242,7 +242,7 @@ _ENV_OPTIONS = (("EXAADMM_BUS_KERNEL", "bus_kernel_lane", lambda v: 1 if v == "l
                 ("EXAADMM_DIST_OVERLAP", "dist_overlap", None), ("EXAADMM_DIST_GRAPH", "dist_graph", None), ("EXAADMM_DIST_P2P", "dist_p2p", None),
                 ("EXAADMM_TRUST_RESIDENT", "trust_resident", None), ("EXAADMM_VERBOSE", "verbose", 1), ("EXAADMM_PROF_RESIDENT", "prof_resident", 1))
 _OPTION_DEFAULTS = {"bus_kernel_lane": 0, "graph": 1, "spec": 1, "mp_spec": 1, "rec": 1, "resident": 1, "resident_tiles": 1, "resident_coop": 1,
-                    "heavy": 1, "heavy_from": 64, "heavy_max": 512, "heavy_select_small": 0, "heavy_window": 64, "heavy_split": 32, "heavy_split_prev": 96, "resident_chunk": 0, "heavy_adopt": 4, "resident_cap_limit": 0, "dist_overlap": 1, "dist_graph": 1, "dist_p2p": 1, "trust_resident": 0, "verbose": 0, "prof_resident": 0}
+                    "heavy": 1, "heavy_from": 64, "heavy_max": 512, "heavy_select_small": 0, "heavy_window": 64, "heavy_split": 48, "heavy_split_prev": 96, "resident_chunk": 0, "heavy_adopt": 4, "resident_cap_limit": 0, "dist_overlap": 1, "dist_graph": 1, "dist_p2p": 1, "trust_resident": 0, "verbose": 0, "prof_resident": 0}
 
 
 def options_from_environment(environ=None):

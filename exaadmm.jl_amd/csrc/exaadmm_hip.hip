@@ -71,7 +71,7 @@ extern "C" int exaadmm_dist_detach(exaadmm_handle* h);
 // environment variable of its own: a host that wants its switches from the environment translates them.
 struct Options {
     int bus_kernel_lane = 0, graph = 1, spec = 1, mp_spec = 1, rec = 1;
-    int resident = 1, resident_tiles = 1, resident_coop = 1, heavy = 1, heavy_from = 64, heavy_max = 512, heavy_select_small = 0, heavy_window = 64, heavy_split = 32, heavy_split_prev = 96, resident_chunk = 0, heavy_adopt = 4;
+    int resident = 1, resident_tiles = 1, resident_coop = 1, heavy = 1, heavy_from = 64, heavy_max = 512, heavy_select_small = 0, heavy_window = 64, heavy_split = 48, heavy_split_prev = 96, resident_chunk = 0, heavy_adopt = 4;
     int resident_cap_limit = 0;   // > 0: pretend the chip holds no more resident wavefronts than this (tests: the two-tile form on small grids)
     int dist_overlap = 1, dist_graph = 1, dist_p2p = 1;
     int trust_resident = 0, verbose = 0;
@@ -2064,8 +2064,9 @@ static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
         // 0.15 ms at 13 659 buses, 0.23 ms at 88 207 branches: profiles/r04_resident_launch_fixed_cost.txt)
         // (option heavy_split = S > 0: the first launch of an inner loop ends after S iterations, so that the rest of the loop runs with heavy
         //  wavefronts chosen from those S iterations' history -- one more launch per inner loop, 0.15 ms, taken only when the handle's
-        //  previous inner loop ran long enough to promise it back (heavy_split_prev iterations): 15.0 k -> 16.8 k it/s over the whole solve of
-        //  the 1 354-bus grid, whose loops run 250 iterations; nothing at 13 659 buses, whose loops run 100)
+        //  previous inner loop ran long enough to promise it back (heavy_split_prev iterations): 15.0 k -> 18.2 k it/s over the whole solve of
+        //  the 1 354-bus grid, whose loops run 250 iterations; nothing at 13 659 buses, whose loops run 100.  S = 48: with 24 or 32 the adoption spends
+        //  the free heavy wavefronts on the passing stragglers of a loop's first iterations -- 17.1 k)
         // (not on a partition with peers: every rank must give its launches the same lengths, and the spare SIMDs differ from rank to rank)
         const bool split = resident && !peers && h->opt.heavy_split > 0 && h->opt.heavy != 0 && resident_mode(h) == 1 && enq < h->opt.heavy_split &&
                            (h->last_inner_len < 0 || h->last_inner_len >= h->opt.heavy_split_prev) && h->heavy_max > 0;   // (a handle's first loop: one launch risked)

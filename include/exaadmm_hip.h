@@ -203,7 +203,7 @@ int exaadmm_resident_selfcheck_stats(exaadmm_handle *h, int *checks, int *mismat
  *                          next iteration on (0: the heavy wavefronts of a launch are those chosen in front of it)
  *   "resident_chunk" (0)   > 0: exaadmm_run_fixed on a grid with heavy wavefronts launches at most this many iterations at a time, each launch with a
  *                          fresh choice (what the adoption made unnecessary: 0.1 ms per launch)
- *   "heavy_split" (32)     > 0: the first launch of a convergence-tested inner loop ends after this many iterations and the rest of the loop runs with heavy
+ *   "heavy_split" (48)     > 0: the first launch of a convergence-tested inner loop ends after this many iterations and the rest of the loop runs with heavy
  *                          wavefronts -- when the handle's previous inner loop ran at least "heavy_split_prev" (96) iterations; 0: one launch per 1 024 iterations
  *   "heavy_select_small" (0) 1: the kernel that picks them runs as ONE wavefront (slower; a block of 16 wavefronts cannot start on a GPU whose
  *                          CUs all hold a resident wavefront of ANOTHER launch that waits for this one -- ranks sharing a GPU in tests)

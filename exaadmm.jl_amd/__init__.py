@@ -238,11 +238,11 @@ def _check_rc(L, rc, what):
 _ENV_OPTIONS = (("EXAADMM_BUS_KERNEL", "bus_kernel_lane", lambda v: 1 if v == "lane" else 0), ("EXAADMM_NO_GRAPH", "graph", 0),
                 ("EXAADMM_NO_SPEC", "spec", 0), ("EXAADMM_MP_NO_SPEC", "mp_spec", 0), ("EXAADMM_NO_REC", "rec", 0),
                 ("EXAADMM_NO_RESIDENT", "resident", 0), ("EXAADMM_RESIDENT", "resident", None), ("EXAADMM_RESIDENT_TILES", "resident_tiles", None),
-                ("EXAADMM_RESIDENT_COOP", "resident_coop", None), ("EXAADMM_NO_HEAVY", "heavy", 0), ("EXAADMM_HEAVY_FROM", "heavy_from", None), ("EXAADMM_HEAVY_MAX", "heavy_max", None), ("EXAADMM_HEAVY_WINDOW", "heavy_window", None), ("EXAADMM_HEAVY_SPLIT", "heavy_split", None), ("EXAADMM_HEAVY_SPLIT_PREV", "heavy_split_prev", None), ("EXAADMM_RESIDENT_CHUNK", "resident_chunk", None), ("EXAADMM_HEAVY_ADOPT", "heavy_adopt", None),
+                ("EXAADMM_RESIDENT_COOP", "resident_coop", None), ("EXAADMM_NO_HEAVY", "heavy", 0), ("EXAADMM_HEAVY_FROM", "heavy_from", None), ("EXAADMM_HEAVY_MAX", "heavy_max", None), ("EXAADMM_HEAVY_WINDOW", "heavy_window", None), ("EXAADMM_HEAVY_SPLIT", "heavy_split", None), ("EXAADMM_HEAVY_SPLIT_PREV", "heavy_split_prev", None), ("EXAADMM_RESIDENT_CHUNK", "resident_chunk", None), ("EXAADMM_HEAVY_ADOPT", "heavy_adopt", None), ("EXAADMM_BLOCK_ORDER", "block_order", None),
                 ("EXAADMM_DIST_OVERLAP", "dist_overlap", None), ("EXAADMM_DIST_GRAPH", "dist_graph", None), ("EXAADMM_DIST_P2P", "dist_p2p", None),
                 ("EXAADMM_TRUST_RESIDENT", "trust_resident", None), ("EXAADMM_VERBOSE", "verbose", 1), ("EXAADMM_PROF_RESIDENT", "prof_resident", 1))
 _OPTION_DEFAULTS = {"bus_kernel_lane": 0, "graph": 1, "spec": 1, "mp_spec": 1, "rec": 1, "resident": 1, "resident_tiles": 1, "resident_coop": 1,
-                    "heavy": 1, "heavy_from": 64, "heavy_max": 512, "heavy_select_small": 0, "heavy_window": 64, "heavy_split": 48, "heavy_split_prev": 96, "resident_chunk": 0, "heavy_adopt": 4, "resident_cap_limit": 0, "dist_overlap": 1, "dist_graph": 1, "dist_p2p": 1, "trust_resident": 0, "verbose": 0, "prof_resident": 0}
+                    "heavy": 1, "heavy_from": 64, "heavy_max": 512, "heavy_select_small": 0, "heavy_window": 64, "heavy_split": 48, "heavy_split_prev": 96, "resident_chunk": 0, "heavy_adopt": 4, "block_order": 1, "resident_cap_limit": 0, "dist_overlap": 1, "dist_graph": 1, "dist_p2p": 1, "trust_resident": 0, "verbose": 0, "prof_resident": 0}
 
 
 def options_from_environment(environ=None):

@@ -71,7 +71,7 @@ extern "C" int exaadmm_dist_detach(exaadmm_handle* h);
 // environment variable of its own: a host that wants its switches from the environment translates them.
 struct Options {
     int bus_kernel_lane = 0, graph = 1, spec = 1, mp_spec = 1, rec = 1;
-    int resident = 1, resident_tiles = 1, resident_coop = 1, heavy = 1, heavy_from = 64, heavy_max = 512, heavy_select_small = 0, heavy_window = 64, heavy_split = 48, heavy_split_prev = 96, resident_chunk = 0, heavy_adopt = 4;
+    int resident = 1, resident_tiles = 1, resident_coop = 1, heavy = 1, heavy_from = 64, heavy_max = 512, heavy_select_small = 0, heavy_window = 64, heavy_split = 48, heavy_split_prev = 96, resident_chunk = 0, heavy_adopt = 4, block_order = 1;
     int resident_cap_limit = 0;   // > 0: pretend the chip holds no more resident wavefronts than this (tests: the two-tile form on small grids)
     int dist_overlap = 1, dist_graph = 1, dist_p2p = 1;
     int trust_resident = 0, verbose = 0;
@@ -182,6 +182,8 @@ struct exaadmm_handle {
     ResidentTiles rtiles = {nullptr, 0, 0, 0, 0};
     ResidentHeavy rheavy = {nullptr, nullptr, nullptr, nullptr, 0};   // heavy wavefronts of the resident launch (kernels.h); n = 0: none
     int heavy_max = 0;
+    bool blk_order_off = false;
+    int *blk_order = nullptr, *blk_keys = nullptr;   // Dev::blk_order of the whole-grid launches of the fused loops (grids with more blocks than SIMDs)
     int last_inner_len = -1;  // iterations of the handle's previous convergence-tested inner loop (run_inner_spec); -1: there was none yet
     int resident_iters = 0;   // iterations the resident launches of this handle were asked for so far (the clock of ResidentSync::last3)
     std::vector<void*> guard;
@@ -1841,6 +1843,22 @@ static int spec_prepare(exaadmm_handle* h)
         }
         if ((rc = dev_alloc(h, &h->zp_scratch, (size_t)h->N))) return rc;
     }
+    // more branch blocks than the chip has SIMDs, no peers: the blocks take the tiles heaviest first (Dev::blk_order, refreshed per batch)
+    {
+        hipDeviceProp_t prop;
+        const bool want_order = h->opt.block_order != 0 && !dist_has_peers(h) && hipGetDeviceProperties(&prop, h->device) == hipSuccess &&
+                                branch_blocks(h) + gen_blocks(h) > 4 * prop.multiProcessorCount;
+        if (want_order && !h->blk_order) {
+            const int nbb = branch_blocks(h);
+            if ((rc = dev_alloc(h, &h->blk_order, (size_t)nbb))) return rc;
+            if ((rc = dev_alloc(h, &h->blk_keys, (size_t)nbb))) return rc;
+            std::vector<int> ident(nbb);
+            for (int q = 0; q < nbb; q++) ident[q] = q;
+            HIPCHK(hipMemcpyAsync(h->blk_order, ident.data(), (size_t)nbb * sizeof(int), hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+        }
+        h->blk_order_off = !want_order;
+    }
     // multi-period model: a block's partial sums have one slot per period its 64 lanes can belong to
     const int part_k = (h->T > 1) ? std::min(h->T, (BR_BLOCK - 1) / std::max(1, std::min(h->l1, std::max(h->g1, 1))) + 2) : 1;
     if (!h->partials_br) {
@@ -1891,11 +1909,13 @@ static int spec_prepare(exaadmm_handle* h)
             a.r_xi_in = rd.r_xi;  a.r_xi = w.r_xi;
         }
         a.part_k = part_k;
+        a.blk_order = h->blk_order_off ? nullptr : h->blk_order;   // (the whole-grid launch; the split launches of a partition keep block i = tile blk0 + i)
         a.partials_br = h->partials_br;
         a.npartials_br = nb + ng;
         a.blk0 = 0;
         a.gen_part0 = nb;
         var[r][0] = var[r][1] = var[r][2] = a;
+        var[r][1].blk_order = var[r][2].blk_order = nullptr;
         var[r][2].blk0 = nbi;
         // the pass that completes a loop's LAST launch (index i, r = (i + 1) mod n: what launch i + 1's prologue would have done):
         // u, v of launch i are its inputs; in place on two sets
@@ -1924,6 +1944,16 @@ static int spec_prepare(exaadmm_handle* h)
 }
 
 // iteration base + j + 1 of the loop on ONE GPU (j = position inside the batch; base is a multiple of the number of sets)
+// Dev::blk_order for the launches that follow: the tiles by the largest solver-trip count of their lanes in the last two iterations, heaviest first
+static void enqueue_block_order(exaadmm_handle* h)
+{
+    if (h->blk_order_off || !h->blk_order || h->nsets < 2) return;
+    const int nbb = branch_blocks(h);
+    hipLaunchKernelGGL(k_tile_keys, dim3((nbb + 3) / 4), dim3(256), 0, h->stream, (const int*)h->sets[0].st[2], (const int*)h->sets[1].st[2], h->L, nbb, h->blk_keys,
+                       (const int*)nullptr);
+    hipLaunchKernelGGL(k_block_order, dim3(1), dim3(1024), 0, h->stream, (const int*)h->blk_keys, nbb, h->blk_order);
+}
+
 static int enqueue_iteration_spec(exaadmm_handle* h, Ctrl* c, int j, bool sample = false, hipEvent_t* bev = nullptr)
 {
     const int r = j % h->nsets;
@@ -2103,6 +2133,7 @@ static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
             HIPCHK(hipGraphLaunch(h->spec_graph, h->stream));
             dist_count_batch(h, true, batch);
         } else if (!peers && !first && graph_ok && nb == batch) {
+            enqueue_block_order(h);
             if (!h->spec_graph) {
                 hipGraph_t g = nullptr;
                 HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
@@ -2121,6 +2152,7 @@ static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
             if ((rc = enqueue_dist_iterations(h, h->d_ctrl, 0, nb, first, nullptr))) return rc;
             dist_count_batch(h, false, 0);
         } else {
+            enqueue_block_order(h);
             for (int j = 0; j < nb; j++)
                 if ((rc = enqueue_iteration_spec(h, h->d_ctrl, j, first && j == 0))) return rc;
         }
@@ -2427,8 +2459,10 @@ static int run_fixed_impl(exaadmm_handle* h, int iters, int first_major_iter, do
                     dist_count_batch(h, false, 0);
                 }
             } else
-                for (int i = 0; i < iters; i++)
+                for (int i = 0; i < iters; i++) {
+                    if ((i & 15) == 0) enqueue_block_order(h);
                     if ((rc = enqueue_iteration_spec(h, h->d_ctrl, i, false, time_branch ? &h->ev[2 + 2 * i] : nullptr))) return rc;
+                }
             if (resident && refused) {   // the runtime says the grid is not co-resident
                 if (h->in_selfcheck) return 1;
                 if ((rc = resident_downgrade(h))) return rc;
@@ -2692,7 +2726,7 @@ const OptKey OPT_KEYS[] = {
     {"bus_kernel_lane", &Options::bus_kernel_lane, 0, 1}, {"graph", &Options::graph, 0, 1}, {"spec", &Options::spec, 0, 1},
     {"mp_spec", &Options::mp_spec, 0, 1}, {"rec", &Options::rec, 0, 1}, {"resident", &Options::resident, 0, 1},
     {"resident_tiles", &Options::resident_tiles, 0, 1}, {"resident_coop", &Options::resident_coop, 0, 1}, {"heavy", &Options::heavy, 0, 1},
-    {"heavy_from", &Options::heavy_from, 0, 1 << 30}, {"heavy_max", &Options::heavy_max, 0, 512}, {"heavy_select_small", &Options::heavy_select_small, 0, 1}, {"heavy_window", &Options::heavy_window, 0, 1 << 20}, {"heavy_split", &Options::heavy_split, 0, 1 << 20}, {"heavy_split_prev", &Options::heavy_split_prev, 0, 1 << 20}, {"resident_chunk", &Options::resident_chunk, 0, 1 << 20}, {"heavy_adopt", &Options::heavy_adopt, 0, 63}, {"resident_cap_limit", &Options::resident_cap_limit, 0, 1 << 20}, {"dist_overlap", &Options::dist_overlap, 0, 1}, {"dist_graph", &Options::dist_graph, 0, 1}, {"dist_p2p", &Options::dist_p2p, 0, 1},
+    {"heavy_from", &Options::heavy_from, 0, 1 << 30}, {"heavy_max", &Options::heavy_max, 0, 512}, {"heavy_select_small", &Options::heavy_select_small, 0, 1}, {"heavy_window", &Options::heavy_window, 0, 1 << 20}, {"heavy_split", &Options::heavy_split, 0, 1 << 20}, {"heavy_split_prev", &Options::heavy_split_prev, 0, 1 << 20}, {"resident_chunk", &Options::resident_chunk, 0, 1 << 20}, {"heavy_adopt", &Options::heavy_adopt, 0, 63}, {"block_order", &Options::block_order, 0, 1}, {"resident_cap_limit", &Options::resident_cap_limit, 0, 1 << 20}, {"dist_overlap", &Options::dist_overlap, 0, 1}, {"dist_graph", &Options::dist_graph, 0, 1}, {"dist_p2p", &Options::dist_p2p, 0, 1},
     {"trust_resident", &Options::trust_resident, 0, 1}, {"verbose", &Options::verbose, 0, 1}, {"prof_resident", &Options::prof_resident, 0, 1},
 };
 }  // namespace

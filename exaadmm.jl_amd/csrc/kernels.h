@@ -90,6 +90,10 @@ struct Dev {
     // peers' halo.  blk0 = first branch block this launch covers, gen_part0 = partial-sum slot of the first generator block
     // (= number of branch blocks of the whole grid; a one-piece launch: blk0 = 0, gen_part0 = its own branch blocks).
     int blk0, gen_part0;
+    // launches with more blocks than the chip has SIMDs (the multi-period model, grids beyond the resident loop): the tile of 64 branches that
+    // branch block i solves -- heaviest tiles first (k_block_order).  Blocks start in index order; a tile whose straggler needs 9 trips and starts
+    // in the launch's second round of wavefronts ends the launch a round late.  nullptr: block i solves tile i.
+    const int* blk_order;
     // ... and runs TWO launches ahead of the stop test (the interior launch of iteration j+1 starts before the halo of iteration
     // j -- which carries the residual sums that decide about iteration j-1 -- has arrived): the iterate rotates through three
     // buffer sets, z and l included.  z_in / l_in = z, l of the iteration BEFORE the one whose z / l pass rides in this launch's
@@ -380,12 +384,16 @@ __global__ void __launch_bounds__(BR_BLOCK, EXA_BR_WAVES) k_branch_t(const Dev* 
     // blocks past the branch range do the generator update (independent of the branches; one
     // launch and one inter-kernel gap less per iteration).  gen_blocks = 0: branches only.
     const int nbr_blocks = gridDim.x - gen_blocks;
+    // (with Dev::blk_order -- more blocks than SIMDs -- the generator / ramp blocks are the launch's FIRST blocks: behind 1 280 branch blocks they
+    //  started in its second round of wavefronts.  bid: the block's number in the layout "branch blocks, then generator blocks")
+    const bool gen_first = ZL && d.blk_order != nullptr;
+    const int bid = gen_first ? (((int)blockIdx.x < gen_blocks) ? nbr_blocks + (int)blockIdx.x : (int)blockIdx.x - gen_blocks) : (int)blockIdx.x;
     double zs[4] = {0.0, 0.0, 0.0, 0.0};   // ZL: this lane's residual terms
-    if ((int)blockIdx.x >= nbr_blocks) {
-        const int gi = ((int)blockIdx.x - nbr_blocks) * BR_BLOCK + threadIdx.x;
+    if (bid >= nbr_blocks) {
+        const int gi = (bid - nbr_blocks) * BR_BLOCK + threadIdx.x;
         if (MP && ZL) {   // multi-period model on the fused loop: z / l pass (incl. the ramp element) + ramp subproblem, per-period partial sums
             gen_ramp_lane_zl(d, o, baseMVA, major_iter, gi, do_zl, zl_beta, zs);
-            if (do_zl) mp_block_partials(d, d.gen_part0 + ((int)blockIdx.x - nbr_blocks), ((int)blockIdx.x - nbr_blocks) * BR_BLOCK, d.g1, d.G, gi < d.G ? gi / d.g1 : -1, zs);
+            if (do_zl) mp_block_partials(d, d.gen_part0 + (bid - nbr_blocks), (bid - nbr_blocks) * BR_BLOCK, d.g1, d.G, gi < d.G ? gi / d.g1 : -1, zs);
         } else if (MP)   // multi-period model: ramp subproblems run beside the branch solves, same launch
             gen_ramp_lane(d, o, baseMVA, major_iter, gi);
         else if (ZL) {
@@ -428,7 +436,7 @@ __global__ void __launch_bounds__(BR_BLOCK, EXA_BR_WAVES) k_branch_t(const Dev* 
                     for (int off = 32; off > 0; off >>= 1) zs[j] += __shfl_down(zs[j], off, 64);
                 }
                 if (threadIdx.x == 0) {
-                    const int part = d.gen_part0 + ((int)blockIdx.x - nbr_blocks);
+                    const int part = d.gen_part0 + (bid - nbr_blocks);
 #pragma unroll
                     for (int j = 0; j < 4; j++) d.partials_br[part * 4 + j] = zs[j];
                 }
@@ -441,7 +449,7 @@ __global__ void __launch_bounds__(BR_BLOCK, EXA_BR_WAVES) k_branch_t(const Dev* 
     // of the step-wise launch has fewer than 64 lanes).
     __shared__ MuPowTable pw_lds;
     if (threadIdx.x < 24) reinterpret_cast<double*>(&pw_lds)[threadIdx.x] = reinterpret_cast<const double*>(&c_mupow)[threadIdx.x];
-    const int blk = (ZL ? d.blk0 : 0) + (int)blockIdx.x;   // (split launches of a partition start at block blk0)
+    const int blk = (ZL ? d.blk0 : 0) + ((ZL && d.blk_order != nullptr) ? d.blk_order[bid] : bid);   // (split launches of a partition start at block blk0)
     const int slot = blk * BR_BLOCK + threadIdx.x;
     const bool lane_on = slot < d.L;
     if (!ZL && !lane_on) return;
@@ -546,7 +554,7 @@ __global__ void __launch_bounds__(BR_BLOCK, EXA_BR_WAVES) k_branch_t(const Dev* 
     branch_start(ub, bnd, rate_0, x, xl, xu);
     BranchStats st;
 #if defined(EXA_PROFILE_PHASES)
-    st.tl = d.st_tl ? d.st_tl + (size_t)blockIdx.x * 128 : nullptr;
+    st.tl = d.st_tl ? d.st_tl + (size_t)bid * 128 : nullptr;
     // force the loads to land before the stamp: consume one loaded value in the asm dependency
     unsigned long long t_loaded;
     asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_loaded) : "v"(x[0]) : "memory");
@@ -2567,6 +2575,27 @@ __global__ void __launch_bounds__(256) k_tile_keys(const int* __restrict__ ticks
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) k = max(k, __shfl_down(k, off, 64));
     if (lane == 0) key[t] = k;
+}
+
+// order[0 .. nb) = the tiles by falling key (k_tile_keys: the largest trip count of a tile's lanes in the last two iterations); which of two tiles
+// with the same key comes first is left to the atomics -- a tile is solved the same way whichever block solves it (Dev::blk_order)
+__global__ void __launch_bounds__(1024) k_block_order(const int* __restrict__ key, int nb, int* __restrict__ order)
+{
+    __shared__ int hist[64], start[64];
+    const int tid = threadIdx.x;
+    if (tid < 64) hist[tid] = 0;
+    __syncthreads();
+    for (int t = tid; t < nb; t += blockDim.x) atomicAdd(&hist[min(63, key[t] & 0xfffff)], 1);
+    __syncthreads();
+    if (tid == 0) {
+        int pos = 0;
+        for (int k = 63; k >= 0; k--) {
+            start[k] = pos;
+            pos += hist[k];
+        }
+    }
+    __syncthreads();
+    for (int t = tid; t < nb; t += blockDim.x) order[atomicAdd(&start[min(63, key[t] & 0xfffff)], 1)] = t;
 }
 
 __global__ void __launch_bounds__(1024) k_tile_assign(const int* __restrict__ key_g, int nb, int wb, int* __restrict__ tiles)

@@ -205,6 +205,8 @@ int exaadmm_resident_selfcheck_stats(exaadmm_handle *h, int *checks, int *mismat
  *                          fresh choice (what the adoption made unnecessary: 0.1 ms per launch)
  *   "heavy_split" (48)     > 0: the first launch of a convergence-tested inner loop ends after this many iterations and the rest of the loop runs with heavy
  *                          wavefronts -- when the handle's previous inner loop ran at least "heavy_split_prev" (96) iterations; 0: one launch per 1 024 iterations
+ *   "block_order" (1)      launches with more blocks than the chip has SIMDs (the multi-period model, grids beyond the resident loop): the generator / ramp
+ *                          blocks first, then the tiles of 64 branches by falling solver-trip count (0: in storage order)
  *   "heavy_select_small" (0) 1: the kernel that picks them runs as ONE wavefront (slower; a block of 16 wavefronts cannot start on a GPU whose
  *                          CUs all hold a resident wavefront of ANOTHER launch that waits for this one -- ranks sharing a GPU in tests)
  *   "resident_cap_limit" (0) > 0: treat the chip as holding at most this many resident wavefronts (tests: the two-tile form on small grids)

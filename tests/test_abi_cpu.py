@@ -236,3 +236,22 @@ def test_synthetic_instances_have_a_strictly_feasible_operating_point(case, kw):
     assert (qg >= 0.8 * g["qgmin"]).all() and (qg <= 0.8 * g["qgmax"]).all()
     lim = np.asarray(g["rateA"])
     assert ((pij ** 2 + qij ** 2) <= 0.5 * lim).all() and ((pji ** 2 + qji ** 2) <= 0.5 * lim).all()   # flows <= 1/1.5 of the rating
+
+
+def test_option_defaults_of_the_python_mirror_are_the_librarys(pkg):
+    """The Python mirror sets EVERY option when a model is created (environment switches translated into options): its table of
+    defaults must be the library's own (csrc/exaadmm_hip.hip struct Options), and every key of it must be a key the library knows
+    (the table behind exaadmm_set_option) and one that include/exaadmm_hip.h documents."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "exaadmm.jl_amd", "csrc", "exaadmm_hip.hip")).read()
+    body = src[src.index("struct Options {"):]
+    body = body[:body.index("};")]
+    lib = {k: int(v) for k, v in re.findall(r"(\w+)\s*=\s*(-?\d+)\s*[,;]", body)}
+    assert lib, "struct Options not parsed"
+    assert pkg._OPTION_DEFAULTS == lib, {k: (pkg._OPTION_DEFAULTS.get(k), lib.get(k)) for k in set(lib) | set(pkg._OPTION_DEFAULTS) if pkg._OPTION_DEFAULTS.get(k) != lib.get(k)}
+    table = set(re.findall(r'\{"(\w+)",\s*&Options::', src))
+    assert table == set(lib), table ^ set(lib)
+    header = open(os.path.join(root, "include", "exaadmm_hip.h")).read()
+    missing = [k for k in lib if '"%s"' % k not in header and k != "prof_resident"]   # (prof_resident: a switch of the diagnostic build only)
+    assert not missing, missing

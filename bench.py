@@ -132,15 +132,38 @@ def cpu_full_solve(grid, params, budget_s=30.0, nthreads=1, outer_lim=20, outer_
             "sample": ("the whole solve" if finished else "the first %d inner iterations of the same solve (%.0f s budget)" % (cumul, budget_s))}
 
 
-def north_star_single(pkg, syn, args, gpu_seconds=2.0):
-    """The N = 1 point of north_star's weak-scaling configuration: ONE area of ACTIVSg70k's size (88 207 branches) on one GPU, same state
-    definition and timing as the headline line (fixed-count regions from the state after --prep iterations, median), bounded to a few
-    seconds of GPU time.  `bench.py --gpus N` carries the N-area value of the same workload in the same field."""
+PMC_FILES = (os.path.join("profiles", "r06_pmc_summary.json"), os.path.join("profiles", "r05_pmc_summary.json"))
+
+
+def pmc_entry(workload, kernel_key, lib_version):
+    """HBM traffic / VALU utilisation of a workload's dominant kernel from the committed rocprofv3 --pmc summary (scripts/collect_pmc.sh +
+    scripts/summarize_pmc.py; bench.py itself cannot collect counters).  An entry taken from other code than the library loaded now is refused.
+    Returns (entry or {}, traffic_source, the whole summary or {})."""
+    pmc_file = next((f for f in PMC_FILES if os.path.exists(os.path.join(ROOT, f))), PMC_FILES[0])
+    try:
+        pmc = json.load(open(os.path.join(ROOT, pmc_file)))
+    except Exception as e:
+        return {}, "none: %s unreadable (%s)" % (pmc_file, e), {}
+    kb = pmc.get(workload, {}).get(kernel_key, {})
+    if kb and pmc.get("library_version") != lib_version:
+        return {}, "refused: %s was collected with %r, the loaded library is %r" % (pmc_file, pmc.get("library_version"), lib_version), pmc
+    if kb:
+        return kb, "%s (library %s, repository commit %s)" % (pmc_file, pmc.get("library_version"), pmc.get("commit")), pmc
+    return {}, "none: %s has no entry for this workload" % pmc_file, pmc
+
+
+def single_gpu_leg(pkg, syn, args, case, steps, gpu_seconds=2.0):
+    """One more workload on the same GPU, bounded to a few seconds of GPU time, with the headline line's state definition and timing
+    (fixed-count regions of `steps` iterations from the state after --prep + --warmup iterations, every region from that same state,
+    median) and its own roofline block (dominant kernel timed by HIP events on the launch stream over one more region):
+      case_ACTIVSg70k -- the N = 1 point of north_star's weak-scaling configuration: ONE area of ACTIVSg70k's size (88 207 branches);
+                         `bench.py --gpus N` carries the N-area value of the same workload in the same field;
+      synthetic1M     -- BASELINE.json configs[4], the throughput / roofline stress (1M branches, 1.3 GB of state: HBM-resident)."""
     import torch
-    case = "case_ACTIVSg70k"
     params = CASE_PARAMS[case]
     t_all = time.perf_counter()
     grid = syn.sized_like(case, seed=0)
+    t_grid = time.perf_counter() - t_all
     env = pkg.AdmmEnv(case, params["rho_pq"], params["rho_va"], tight_factor=0.99, gpu_no=0, verbose=0, grid=grid)
     mod = pkg.ModelAcopf(env)
     env.params.scale = params["scale"]
@@ -150,28 +173,43 @@ def north_star_single(pkg, syn, args, gpu_seconds=2.0):
     mod.state_save()
     first = args.prep + args.warmup + 1
 
-    def region():
+    def region(time_branch=False):
         mod.state_restore()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        mod.run_fixed(args.steps, first_major_iter=first, beta=beta)
+        _, _, ms_b = mod.run_fixed(steps, first_major_iter=first, beta=beta, time_branch=time_branch)
         torch.cuda.synchronize()
-        return time.perf_counter() - t0
+        return time.perf_counter() - t0, ms_b
 
-    regions = [region()]
+    regions = [region()[0]]
     for _ in range(max(0, min(2000, int(round(gpu_seconds / max(regions[0], 1e-6)))) - 1)):
-        regions.append(region())
+        regions.append(region()[0])
     dt = sorted(regions)[len(regions) // 2]
+    _, ms_branch = region(time_branch=True)
     form = mod.resident_form()
+    resident = form["tiles"] > 0
     G, L, B = int(grid["ngen"]), int(grid["nline"]), int(grid["nbus"])
-    its = args.steps / dt
-    out = {"metric": "ADMM inner iterations/sec", "value": its, "unit": "iterations/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": 1e3 * dt / args.steps, "scaling": "weak", "repeats": len(regions),
-           "config": {"workload": "synthetic-%s-sized" % case, "ngen": G, "nline": L, "nbus": B, "rho_pq": params["rho_pq"], "rho_va": params["rho_va"],
-                      "scale": params["scale"], "parallelism": "1 GPU", "resident_form": form, "loop_kind": mod.loop_kind()},
-           "roofline": {"bound": "hbm", "iteration_bytes": BYTES_PER_ITER(G, L, B), "iteration_frac": BYTES_PER_ITER(G, L, B) * its / 1e9 / HBM_PEAK_GBS},
+    its = steps / dt
+    workload = "synthetic-%s-sized" % case
+    lib_version = pkg.library().exaadmm_version().decode()
+    kb, traffic_source, _ = pmc_entry(workload, "k_resident" if resident else "k_branch", lib_version)
+    launch_bytes = float(BYTES_PER_ITER(G, L, B)) if resident else 824.0 * L + 192.0 * G
+    achieved = launch_bytes / (ms_branch * 1e-3) / 1e9
+    out = {"metric": "ADMM inner iterations/sec", "value": its, "unit": "iterations/s", "n_gpus": 1, "steps": steps, "warmup": args.warmup,
+           "ms_per_step": 1e3 * dt / steps, "scaling": "weak", "repeats": len(regions),
+           "config": {"workload": workload, "ngen": G, "nline": L, "nbus": B, "rho_pq": params["rho_pq"], "rho_va": params["rho_va"],
+                      "scale": params["scale"], "parallelism": "1 GPU", "resident_form": form, "loop_kind": mod.loop_kind(),
+                      "state": "ADMM state after %d untimed iterations from init_solution! (outer 1)" % (args.prep + args.warmup)},
+           "roofline": {"bound": "hbm",
+                        "kernel": ("k_resident_t<%d%s> (one launch = the %d iterations of a region; figures per iteration)" % (form["tiles"], ", heavy" if form["heavy"] else "", steps))
+                                  if resident else "k_branch_t<false,true> (branch solves + generator blocks + the z / l / residual pass of the previous iteration)",
+                        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "traffic": kb.get("traffic_bytes"), "traffic_source": traffic_source, "valu_busy": kb.get("valu_busy"),
+                        "algorithmic_bytes_per_launch": launch_bytes, "kernel_ms": ms_branch,
+                        "loop": "resident (one launch per region)" if resident else "two launches per iteration",
+                        "iteration_bytes": BYTES_PER_ITER(G, L, B), "iteration_frac": BYTES_PER_ITER(G, L, B) * its / 1e9 / HBM_PEAK_GBS},
            "selfchecks": mod.resident_selfchecks(), "loop_downgrades": mod.loop_downgrades(),
-           "seconds_for_this_leg": None}
+           "seconds_for_this_leg": None, "seconds_generating_the_grid_on_the_host": t_grid, "gpu_seconds": sum(regions)}
     mod.close()
     out["seconds_for_this_leg"] = time.perf_counter() - t_all
     return out
@@ -207,6 +245,9 @@ def main():
     ap.add_argument("--no-north-star", action="store_true",
                     help="skip the `north_star_scaling` block of the line (areas of ACTIVSg70k's size, north_star's weak-scaling configuration: "
                          "one area on one GPU at N = 1, N areas over N GPUs otherwise; bounded to about a minute)")
+    ap.add_argument("--no-throughput-leg", action="store_true",
+                    help="skip the `throughput_1M` block of the line (BASELINE.json configs[4]: synthetic 1M branches / 500k buses on ONE GPU, "
+                         "bounded to about 2 s of GPU time; generating the grid on the host takes the better part of a minute)")
     ap.add_argument("--attempt-budget", type=float, default=240.0,
                     help="N > 1: seconds a measuring child process may take before its supervisor ends it and starts the next, more "
                          "conservative mode of the distributed loop (exaadmm.jl_amd/bench_supervisor.py)")
@@ -361,33 +402,20 @@ def main():
     # HBM traffic of the dominant kernel: rocprofv3 --pmc passes of THIS command (scripts/collect_pmc.sh; bench.py itself
     # cannot collect counters), summarised per workload in profiles/r03_pmc_summary.json together with the version string
     # of the library they were taken from.  An entry taken from other code than the library loaded now is refused.
-    traffic = valu_busy = insts_per_trip = None
-    insts_calibrated_on = None
     # which loop ran: 2 = the resident loop (ONE launch for the K steps of a region: branch solves, bus updates by the last lane
     # to arrive, residual sums and stop test inside; the figures below are per ITERATION of that launch), 1 = two launches per iteration
     resident = (T == 1 and form["tiles"] > 0)
     lib_version = pkg.library().exaadmm_version().decode()
-    pmc_file = os.path.join("profiles", "r05_pmc_summary.json")
-    if not os.path.exists(os.path.join(ROOT, pmc_file)):
-        pmc_file = os.path.join("profiles", "r04_pmc_summary.json")
-    traffic_source = "none: %s has no entry for this workload" % pmc_file
-    try:
-        pmc = json.load(open(os.path.join(ROOT, pmc_file)))
-        kb = pmc.get(workload, {}).get("k_resident" if resident else "k_branch", {})
-        if kb and pmc.get("library_version") != lib_version:
-            traffic_source = "refused: %s was collected with %r, the loaded library is %r" % (pmc_file, pmc.get("library_version"), lib_version)
-        elif kb:
-            traffic, valu_busy = kb.get("traffic_bytes"), kb.get("valu_busy")
-            insts_per_trip = kb.get("valu_insts_per_wave_trip")
-        # (the instruction count of a solver trip belongs to the CODE: where this workload has no calibration pass of its own, the headline
-        #  workload's -- taken from the same library -- stands in, and the line says so)
-        insts_calibrated_on = workload
-        if insts_per_trip is None and pmc.get("library_version") == lib_version:
-            insts_per_trip = pmc.get("synthetic-case13659pegase-sized", {}).get("k_resident", {}).get("valu_insts_per_wave_trip")
-            insts_calibrated_on = "synthetic-case13659pegase-sized"
-            traffic_source = "%s (library %s, repository commit %s)" % (pmc_file, pmc.get("library_version"), pmc.get("commit"))
-    except Exception as e:
-        traffic_source = "none: %s unreadable (%s)" % (pmc_file, e)
+    kb, traffic_source, pmc = pmc_entry(workload, "k_resident" if resident else "k_branch", lib_version)
+    traffic, valu_busy, insts_per_trip = kb.get("traffic_bytes"), kb.get("valu_busy"), kb.get("valu_insts_per_wave_trip")
+    pmc_file = traffic_source.split(" ")[0] if not traffic_source.startswith(("none", "refused")) else PMC_FILES[0]
+    # (the instruction count of a solver trip belongs to the CODE: where this workload has no calibration pass of its own, the headline
+    #  workload's -- taken from the same library -- stands in, and `instructions_calibrated_on` says so; `traffic_source` only ever names
+    #  where `traffic` came from)
+    insts_calibrated_on = workload
+    if insts_per_trip is None and pmc.get("library_version") == lib_version:
+        insts_per_trip = pmc.get("synthetic-case13659pegase-sized", {}).get("k_resident", {}).get("valu_insts_per_wave_trip")
+        insts_calibrated_on = "synthetic-case13659pegase-sized"
     occ = mod.branch_kernel_occupancy() if hasattr(mod, "branch_kernel_occupancy") else None
     # registers / spills / LDS of the dominant kernel, from the remarks of the library's own compile (csrc/Makefile ->
     # exaadmm.jl_amd/kernel_resources.json, which carries the digest of the sources it belongs to)
@@ -468,11 +496,19 @@ def main():
     }
     out["solver"]["resident_selfchecks"] = list(mod.resident_selfchecks()) if T == 1 else None
     out["solver"]["loop_downgrades"] = mod.loop_downgrades() if T == 1 else None
+    mod.close()   # (the legs below create their own handles: give the headline handle's HBM back first)
     if T == 1 and not args.no_north_star and args.case != "case_ACTIVSg70k":
         try:
-            out["north_star_scaling"] = north_star_single(pkg, syn, args)
+            out["north_star_scaling"] = single_gpu_leg(pkg, syn, args, "case_ACTIVSg70k", args.steps)
         except Exception as e:   # never lose the line over an extra
             out["north_star_scaling"] = {"error": repr(e)}
+    if T == 1 and not args.no_throughput_leg and args.case != "synthetic1M":
+        # BASELINE.json configs[4]: the 1M-branch throughput / roofline stress, the only configuration whose state (1.3 GB) is HBM-resident --
+        # the regime in which the hbm roofline above is the roof that binds
+        try:
+            out["throughput_1M"] = single_gpu_leg(pkg, syn, args, "synthetic1M", min(args.steps, 20), gpu_seconds=2.0)
+        except Exception as e:
+            out["throughput_1M"] = {"error": repr(e)}
     if not args.no_full_solve and T == 1:
         # the reference's own definition of the metric (print_statistics.jl:12): cumul / time_overall of a whole
         # solve_acopf with the README settings (outer 20, inner 1000, early breaks active; timer scope

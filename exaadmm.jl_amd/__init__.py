@@ -236,13 +236,19 @@ def _check_rc(L, rc, what):
 # for A/B runs of the tests, the benchmark and the scripts (`EXAADMM_NO_RESIDENT=1 python bench.py`); the library itself reads none of
 # them.  (variable, option, value when the variable is set -- None: int(the variable's value)).  EXAADMM_OPT_<KEY>=<int> sets any option.
 _ENV_OPTIONS = (("EXAADMM_BUS_KERNEL", "bus_kernel_lane", lambda v: 1 if v == "lane" else 0), ("EXAADMM_NO_GRAPH", "graph", 0),
-                ("EXAADMM_NO_SPEC", "spec", 0), ("EXAADMM_MP_NO_SPEC", "mp_spec", 0), ("EXAADMM_NO_REC", "rec", 0),
+                ("EXAADMM_NO_SPEC", "spec", 0), ("EXAADMM_MP_NO_SPEC", "spec", 0), ("EXAADMM_NO_REC", "rec", 0),
                 ("EXAADMM_NO_RESIDENT", "resident", 0), ("EXAADMM_RESIDENT", "resident", None), ("EXAADMM_RESIDENT_TILES", "resident_tiles", None),
-                ("EXAADMM_RESIDENT_COOP", "resident_coop", None), ("EXAADMM_NO_HEAVY", "heavy", 0), ("EXAADMM_HEAVY_FROM", "heavy_from", None), ("EXAADMM_HEAVY_MAX", "heavy_max", None), ("EXAADMM_HEAVY_WINDOW", "heavy_window", None), ("EXAADMM_HEAVY_SPLIT", "heavy_split", None), ("EXAADMM_HEAVY_SPLIT_PREV", "heavy_split_prev", None), ("EXAADMM_RESIDENT_CHUNK", "resident_chunk", None), ("EXAADMM_HEAVY_ADOPT", "heavy_adopt", None), ("EXAADMM_BLOCK_ORDER", "block_order", None),
-                ("EXAADMM_DIST_OVERLAP", "dist_overlap", None), ("EXAADMM_DIST_GRAPH", "dist_graph", None), ("EXAADMM_DIST_P2P", "dist_p2p", None),
-                ("EXAADMM_TRUST_RESIDENT", "trust_resident", None), ("EXAADMM_VERBOSE", "verbose", 1), ("EXAADMM_PROF_RESIDENT", "prof_resident", 1))
-_OPTION_DEFAULTS = {"bus_kernel_lane": 0, "graph": 1, "spec": 1, "mp_spec": 1, "rec": 1, "resident": 1, "resident_tiles": 1, "resident_coop": 1,
-                    "heavy": 1, "heavy_from": 64, "heavy_max": 512, "heavy_select_small": 0, "heavy_window": 64, "heavy_split": 48, "heavy_split_prev": 96, "resident_chunk": 0, "heavy_adopt": 4, "block_order": 1, "resident_cap_limit": 0, "dist_overlap": 1, "dist_graph": 1, "dist_p2p": 1, "trust_resident": 0, "verbose": 0, "prof_resident": 0}
+                ("EXAADMM_NO_HEAVY", "heavy", 0), ("EXAADMM_HEAVY_MAX", "heavy_max", None), ("EXAADMM_HEAVY_SPLIT", "heavy_split", None), ("EXAADMM_HEAVY_SPLIT_PREV", "heavy_split_prev", None),
+                ("EXAADMM_HEAVY_ADOPT", "heavy_adopt", None), ("EXAADMM_BLOCK_ORDER", "block_order", None),
+                ("EXAADMM_DIST_OVERLAP", "dist_overlap", None), ("EXAADMM_DIST_P2P", "dist_p2p", None),
+                ("EXAADMM_TRUST_RESIDENT", "trust_resident", None))
+_OPTION_DEFAULTS = {"bus_kernel_lane": 0, "graph": 1, "spec": 1, "rec": 1, "resident": 1, "resident_tiles": 1, "heavy": 1, "heavy_max": 512,
+                    "heavy_split": 48, "heavy_split_prev": 96, "heavy_adopt": 4, "block_order": 1, "dist_overlap": 1, "dist_p2p": 1, "trust_resident": 0}
+# switches of the TEST build only (libexaadmm_hip_hooks.so, exaadmm_test_hook): a model created while one of these variables is set needs that build
+_ENV_TEST_HOOKS = (("EXAADMM_RESIDENT_TEST_FAIL", "fail_resident_launch"), ("EXAADMM_RESIDENT_COOP", "resident_coop"),
+                   ("EXAADMM_RESIDENT_CAP_LIMIT", "resident_cap_limit"), ("EXAADMM_HEAVY_SELECT_SMALL", "heavy_select_small"))
+# diagnostic build only (libexaadmm_hip_prof.so): phase clocks of the resident loop's lanes
+_ENV_PROF_OPTIONS = (("EXAADMM_PROF_RESIDENT", "prof_resident", 1),)
 
 
 def options_from_environment(environ=None):
@@ -275,17 +281,25 @@ class _HandleOptions:
 
     def apply_env_options(self):
         want = options_from_environment()
-        hook = os.environ.get("EXAADMM_RESIDENT_TEST_FAIL", "")
-        sig = (tuple(sorted(want.items())), hook)
+        hooks = tuple((key, int(os.environ[var])) for var, key in _ENV_TEST_HOOKS if os.environ.get(var, "") != "")
+        prof = tuple((key, val) for var, key, val in _ENV_PROF_OPTIONS if os.environ.get(var, "") != "")
+        sig = (tuple(sorted(want.items())), hooks, prof)
         if sig == self._opt_applied:
             return
         for k, v in want.items():
             self.set_option(k, v)
-        if hook != "" or (self._opt_applied is not None and self._opt_applied[1] != ""):
+        for k, v in prof:
+            self.set_option(k, v)
+        was = dict(self._opt_applied[1]) if self._opt_applied is not None else {}
+        if hooks or was:
             L = library()
             if not hasattr(L, "exaadmm_test_hook"):
-                raise ExaAdmmError("EXAADMM_RESIDENT_TEST_FAIL needs the test build of the library (libexaadmm_hip_hooks.so, EXAADMM_HIP_LIB)")
-            _check(L.exaadmm_test_hook(self._h, b"fail_resident_launch", int(hook or 0)), "exaadmm_test_hook")
+                raise ExaAdmmError("%s need(s) the test build of the library (libexaadmm_hip_hooks.so, EXAADMM_HIP_LIB)"
+                                   % ", ".join(var for var, _ in _ENV_TEST_HOOKS if os.environ.get(var, "") != ""))
+            now = dict(hooks)
+            for key in set(now) | set(was):   # (a variable that is no longer set: back to the default)
+                default = {"fail_resident_launch": 0, "resident_coop": 1, "resident_cap_limit": 0, "heavy_select_small": 0}[key]
+                _check(L.exaadmm_test_hook(self._h, key.encode(), now.get(key, default)), "exaadmm_test_hook(%s)" % key)
         self._opt_applied = sig
 
     def test_hook(self, key, value):

@@ -13,11 +13,11 @@ through the launcher's rendezvous store (TCP, CPU only) on what happened:
   * the first attempt that completes on every rank delivers the line; rank 0 prints it -- ONE JSON line, last on stdout -- with
     `attempts: [{mode, rc, seconds, stderr_tail}]` added, so that a run that needed a fallback says which one and why.
 
-The modes (exaadmm_hip.h: exaadmm_set_option keys, passed to the child as EXAADMM_OPT_* which bench's child applies to its handle):
+The modes (exaadmm_hip.h: exaadmm_set_option keys, passed to the child as the environment variables the Python mirror translates into options of its handle):
     resident+xgmi   the default path: the resident loop on every rank, what crosses GPUs goes by direct stores into the peer's mailbox
                     (a rank that cannot map a peer's memory makes all ranks take the next mode's loop by itself, inside the child)
     graph+overlap   two launches per iteration; RCCL exchange beside the interior solves, batches incl. exchanges replayed from a hipGraph
-    overlap         batches enqueued directly (dist_graph=0)
+    overlap         batches enqueued directly (graph=0)
     one-stream      ... and everything on one stream (dist_overlap=0)
     python-twin     the step-wise twin: Python issues every step, torch.distributed (RCCL) collectives
     python-gloo     the same twin over gloo, staged through the host (no RCCL at all)
@@ -38,8 +38,8 @@ import time
 MODES = [
     ("resident+xgmi", {}),
     ("graph+overlap", {"EXAADMM_DIST_P2P": "0"}),
-    ("overlap", {"EXAADMM_DIST_P2P": "0", "EXAADMM_OPT_DIST_GRAPH": "0"}),
-    ("one-stream", {"EXAADMM_DIST_P2P": "0", "EXAADMM_OPT_DIST_GRAPH": "0", "EXAADMM_OPT_DIST_OVERLAP": "0"}),
+    ("overlap", {"EXAADMM_DIST_P2P": "0", "EXAADMM_NO_GRAPH": "1"}),
+    ("one-stream", {"EXAADMM_DIST_P2P": "0", "EXAADMM_NO_GRAPH": "1", "EXAADMM_DIST_OVERLAP": "0"}),
     ("python-twin", {"EXAADMM_DIST_PYTHON_LOOP": "1"}),
     ("python-gloo", {"EXAADMM_DIST_PYTHON_LOOP": "1", "EXAADMM_BENCH_BACKEND": "gloo"}),
 ]
@@ -189,6 +189,8 @@ def run_attempt(store, key, rank, world, child_cmd, child_env, budget_s, grace_s
 
 def child_environment(base_env, mode_env, local_rank):
     env = {k: v for k, v in base_env.items() if not k.startswith("TORCHELASTIC_") and not k.startswith("EXAADMM_OPT_DIST_")}
+    env.pop("EXAADMM_NO_GRAPH", None)
+    env.pop("EXAADMM_DIST_OVERLAP", None)
     env.pop("EXAADMM_DIST_PYTHON_LOOP", None)
     env.pop("EXAADMM_BENCH_BACKEND", None)
     env.pop("EXAADMM_DIST_P2P", None)

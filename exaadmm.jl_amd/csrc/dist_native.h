@@ -446,6 +446,11 @@ struct P2PBlob {
     unsigned long long address;
     hipIpcMemHandle_t ipc;
     int ncut[P2P_MAX_RANKS];
+    // which resident form this rank's partition would run with its peers' mailboxes mapped (resident_mode_if: 0 none, 1 one tile, 2 two tiles per
+    // wavefront): EVERY rank must run a resident form or none may -- a rank on the two-launch loop would leave its peers' launches in their capped
+    // waits -- and only when all of them run the one-tile form may the first launch of an inner loop be split for the heavy wavefronts (launch
+    // lengths must agree across ranks).  Every rank reads the same blobs, so every rank reaches the same verdict without another exchange.
+    int resident_form;
 };
 static_assert(sizeof(P2PBlob) <= 256, "blob size is part of the ABI (EXAADMM_P2P_BLOB_BYTES)");
 constexpr unsigned long long P2P_MAGIC = 0x6578616164326d70ull;
@@ -471,6 +476,7 @@ extern "C" int exaadmm_dist_p2p_export(exaadmm_handle* h, void* blob, int64_t nb
         }
         for (int p = 0; p < d->nranks; p++) b.ncut[p] = (int)d->ncut[p];
     }
+    b.resident_form = b.has_box ? resident_mode_if(h, true) : 0;
     memset(blob, 0, 256);
     memcpy(blob, &b, sizeof(b));
     return EXAADMM_OK;
@@ -490,6 +496,13 @@ extern "C" int exaadmm_dist_p2p_import(exaadmm_handle* h, const void* blobs, int
         REQUIRE(bl[p].magic == P2P_MAGIC && bl[p].rank == p && bl[p].nranks == d->nranks, "blob of the wrong rank / job");
         REQUIRE(bl[p].has_box == 1, "a peer has no mailbox");
     }
+    bool all_one_tile = true;
+    for (int p = 0; p < d->nranks; p++) {
+        // (same blobs on every rank -> the same refusal on every rank: nobody is left with a resident loop its peers do not run)
+        REQUIRE(bl[p].resident_form != 0, "a rank's partition does not fit the resident loop (size, options or stream): all ranks keep two launches per iteration");
+        all_one_tile = all_one_tile && bl[p].resident_form == 1;
+    }
+    h->peers_one_tile = all_one_tile;
     REQUIRE(bl[d->rank].address == (unsigned long long)(uintptr_t)d->box, "our own blob does not describe this handle");
     std::vector<unsigned long long> base((size_t)d->nranks, 0ull);
     for (int p = 0; p < d->nranks; p++) {
@@ -547,7 +560,8 @@ extern "C" int exaadmm_dist_p2p_import(exaadmm_handle* h, const void* blobs, int
     return EXAADMM_OK;
 }
 
-// diagnostics (scripts/p2p_debug.py): this rank's mailbox as it is now, 16 doubles per entry
+#if defined(EXA_PROFILE_PHASES) || defined(EXA_TEST_HOOKS)
+// diagnostics (scripts/p2p_debug.py; diagnostic and test builds only): this rank's mailbox as it is now, 16 doubles per entry
 extern "C" int exaadmm_debug_p2p_box(exaadmm_handle* h, double* out, int64_t n_doubles)
 {
     REQUIRE(h && h->dist && h->dist->box && out, "no mailbox");
@@ -569,6 +583,7 @@ extern "C" int exaadmm_debug_resident_window(exaadmm_handle* h, unsigned long lo
     out2[3] = ((unsigned long long)(unsigned)w[2] << 32) | (unsigned)w[3];
     return EXAADMM_OK;
 }
+#endif
 
 // number of grouped exchanges this handle has enqueued since it was attached (tests: exactly one per inner iteration)
 extern "C" int64_t exaadmm_dist_exchange_count(void) { return g_exchanges; }
@@ -737,7 +752,7 @@ static int dist_probe(exaadmm_handle* h)
     if ((rc = one())) return rc;
     if ((rc = verify("direct"))) return rc;
     hipGraphExec_t exec = nullptr;
-    const bool want = h->use_graph && h->opt.dist_graph != 0;   // (option "dist_graph" = 0: A/B switch, every batch enqueued directly)
+    const bool want = h->use_graph;   // (option "graph" = 0: A/B switch, every batch enqueued directly)
     if (want && hipStreamBeginCapture(X, hipStreamCaptureModeThreadLocal) == hipSuccess) {
         const int crc = one();
         hipGraph_t g = nullptr;

@@ -70,13 +70,20 @@ extern "C" int exaadmm_dist_detach(exaadmm_handle* h);
 // A/B switches and diagnostics of a handle (exaadmm_set_option; include/exaadmm_hip.h lists them).  The library reads no
 // environment variable of its own: a host that wants its switches from the environment translates them.
 struct Options {
-    int bus_kernel_lane = 0, graph = 1, spec = 1, mp_spec = 1, rec = 1;
-    int resident = 1, resident_tiles = 1, resident_coop = 1, heavy = 1, heavy_from = 64, heavy_max = 512, heavy_select_small = 0, heavy_window = 64, heavy_split = 48, heavy_split_prev = 96, resident_chunk = 0, heavy_adopt = 4, block_order = 1;
-    int resident_cap_limit = 0;   // > 0: pretend the chip holds no more resident wavefronts than this (tests: the two-tile form on small grids)
-    int dist_overlap = 1, dist_graph = 1, dist_p2p = 1;
-    int trust_resident = 0, verbose = 0;
-    int prof_resident = 0;   // diagnostic build (-DEXA_PROFILE_PHASES): phase clocks of the resident loop's lanes instead of k_branch_t's timelines
+    int bus_kernel_lane = 0, graph = 1, spec = 1, rec = 1;
+    int resident = 1, resident_tiles = 1, heavy = 1, heavy_max = 512, heavy_split = 48, heavy_split_prev = 96, heavy_adopt = 4, block_order = 1;
+    int dist_overlap = 1, dist_p2p = 1;
+    int trust_resident = 0;
+    // -- not options of the product: switches of the test build (exaadmm_test_hook, -DEXA_TEST_HOOKS) and of the diagnostic build --
+    int resident_coop = 1;        // 0: plain launch of the resident kernels (two ranks sharing ONE GPU in tests: the runtime refuses a second cooperative grid)
+    int resident_cap_limit = 0;   // > 0: pretend the chip holds no more resident wavefronts than this (the two-tile form on small grids)
+    int heavy_select_small = 0;   // 1: the kernel that picks the heavy wavefronts runs as ONE wavefront (a block of 16 cannot start on a GPU whose CUs all hold a
+                                  // resident wavefront of ANOTHER launch that waits for this one -- ranks sharing a GPU in tests)
+    int prof_resident = 0;        // diagnostic build (-DEXA_PROFILE_PHASES): phase clocks of the resident loop's lanes instead of k_branch_t's timelines
 };
+// tuning constants of the heavy wavefronts that used to be options (rounds 4-5 measured them: profiles/r05_honest_replays.txt)
+constexpr int HEAVY_FROM = 64;     // first iteration of an inner loop from which a resident launch may carry heavy wavefronts
+constexpr int HEAVY_WINDOW = 64;   // W: a branch that needed >= 3 solver trips in the last W (then 4 W, 16 W) resident iterations is a candidate
 
 struct exaadmm_handle {
     exaadmm_dist* dist = nullptr;
@@ -177,6 +184,7 @@ struct exaadmm_handle {
     // stores into the peer's mailbox.  p2p_ready: every peer's mailbox is mapped (exaadmm_dist_p2p_import); resident_peers_ok: the
     // grid's bus tables fit the loop's counters
     bool resident_peers_ok = false, p2p_ready = false;
+    bool peers_one_tile = false;   // every rank of the partition runs the one-tile resident form (exaadmm_dist_p2p_import): launch lengths may follow heavy_split
     ResidentPeers rpeers = {};
     int p2p_epoch = 0;
     ResidentTiles rtiles = {nullptr, 0, 0, 0, 0};
@@ -1460,7 +1468,8 @@ extern "C" int exaadmm_branch_kernel_occupancy(exaadmm_handle* h, int* waves_per
     return EXAADMM_OK;
 }
 
-// diagnostic builds only (-DEXA_PROFILE_PHASES): per-branch cycle counters of the solver phases
+#if defined(EXA_PROFILE_PHASES)
+// diagnostic build only (-DEXA_PROFILE_PHASES, libexaadmm_hip_prof.so): per-branch cycle counters of the solver phases, per-wavefront timelines
 extern "C" int exaadmm_debug_phase_cycles(exaadmm_handle* h, unsigned long long* out, int64_t n)
 {
     REQUIRE(h && out && n == 13 * (int64_t)h->Lp, "buffer must hold 13 x Lp counters");
@@ -1479,6 +1488,7 @@ extern "C" int exaadmm_debug_wave_timeline(exaadmm_handle* h, unsigned long long
     HIPCHK(hipMemset(h->d.st_tl, 0, (size_t)n * sizeof(unsigned long long)));
     return EXAADMM_OK;
 }
+#endif
 
 // ------------------------------------------------------------------ the device-resident inner loop
 // Two launches per iteration (kernels.h):
@@ -1489,7 +1499,7 @@ extern "C" int exaadmm_debug_wave_timeline(exaadmm_handle* h, unsigned long long
 // sums in rank order, advance the loop control).  The loop test of iteration k is known one launch late; the iterate is
 // double-buffered by iteration parity so that the stopping iteration's state survives its speculative successor.
 // (option "mp_spec" = 0: A/B switch, the multi-period model keeps the four-launch loop)
-static bool spec_eligible(const exaadmm_handle* h) { return h->spec_on && !h->ctrl_mode && (h->T == 1 || h->opt.mp_spec != 0); }
+static bool spec_eligible(const exaadmm_handle* h) { return h->spec_on && !h->ctrl_mode; }
 
 // resident loop: every wavefront of the launch must hold a SIMD for the whole launch (one wavefront per SIMD)
 static int resident_capacity(exaadmm_handle* h)
@@ -1666,8 +1676,12 @@ static int resident_prepare(exaadmm_handle* h, const Ctrl* begin = nullptr)
 }
 
 // one launch = `n` iterations of the loop (the batch); the loop control is read and advanced inside (k_resident)
+// iterations one resident launch may cover (see exaadmm_run_fixed): the lanes pack the launch-relative iteration index into 32-bit words
+// next to a branch number (index << 20) and into mailbox sequence numbers ((epoch << 12) | index, 0xfff reserved for the agreement kernel)
+constexpr int RESIDENT_LAUNCH_MAX = 1024;
 static int enqueue_resident(exaadmm_handle* h, int n, int loop_iter0)
 {
+    REQUIRE(n >= 1 && n <= RESIDENT_LAUNCH_MAX, "internal: a resident launch covers 1 .. 1024 iterations");
     const int nb = branch_blocks(h), ng = gen_blocks(h);
     if (!h->resident_zeroed)   // (everything but `fail`: a later launch's reset must not erase what an earlier one reported)
         HIPCHK(hipMemsetAsync(h->rsync.arrive, 0, (2 * (size_t)h->B + 3) * sizeof(int), h->stream));
@@ -1694,7 +1708,7 @@ static int enqueue_resident(exaadmm_handle* h, int n, int loop_iter0)
     // are chosen from the trip counters of the iterations before the launch, and at the start of an inner loop (the penalties
     // restart, the slowest branch changes from iteration to iteration) those say nothing -- a launch from there runs the kernel
     // without them (profiles/r04_heavy_wavefronts.txt: +8.6 % in the steady state, -2.7 % over a whole solve if always on).
-    const int heavy_from = (h->opt.heavy_split > 0) ? std::min(h->opt.heavy_from, h->opt.heavy_split) : h->opt.heavy_from;
+    const int heavy_from = (h->opt.heavy_split > 0) ? std::min(HEAVY_FROM, h->opt.heavy_split) : HEAVY_FROM;
     const bool heavy_rule = (h->force_heavy >= 0) ? (h->force_heavy != 0) : (loop_iter0 >= heavy_from && h->opt.heavy != 0);
     const bool peers = dist_has_peers(h);
     if (mode == 1 && heavy_rule && std::min(h->heavy_max, h->opt.heavy_max) > 0) {
@@ -1702,7 +1716,7 @@ static int enqueue_resident(exaadmm_handle* h, int n, int loop_iter0)
         rh.n = std::min(h->heavy_max, h->opt.heavy_max);
         hipLaunchKernelGGL(k_heavy_select, dim3(1), dim3(h->opt.heavy_select_small != 0 ? 64 : 1024), 0, h->stream, (const int*)h->sets[0].st[2], (const int*)h->sets[1].st[2], h->L, h->Lp, rh.n,
                            const_cast<int*>(rh.list), const_cast<int*>(rh.flag), (const double*)h->d.z, (const double*)h->d.l, 2 * h->Gp, const_cast<double*>(rh.init),
-                           peers ? h->rpeers.cut_code : (const int*)nullptr, (const int*)h->rsync.last3, h->resident_iters, h->opt.heavy_window, rh.req, rh.cnt);
+                           peers ? h->rpeers.cut_code : (const int*)nullptr, (const int*)h->rsync.last3, h->resident_iters, HEAVY_WINDOW, rh.req, rh.cnt);
         rh.adopt_thr = h->opt.heavy_adopt;
         grid += rh.n;
     }
@@ -1749,7 +1763,8 @@ static int enqueue_resident(exaadmm_handle* h, int n, int loop_iter0)
     return 0;
 }
 
-static int resident_mode(exaadmm_handle* h)
+// assume_mailboxes: the answer a partition would get once its peers' mailboxes are mapped (what exaadmm_dist_p2p_export tells the peers)
+static int resident_mode_if(exaadmm_handle* h, bool assume_mailboxes)
 {
 #if defined(EXA_PROFILE_PHASES)
     // (the diagnostic build's per-wavefront timelines belong to k_branch_t; option "prof_resident" = 1: phase clocks of the resident loop's lanes)
@@ -1757,7 +1772,7 @@ static int resident_mode(exaadmm_handle* h)
 #endif
     if (h->opt.resident == 0 || h->force_two_launch) return 0;
     const bool peers = dist_has_peers(h);
-    if (!((peers ? (h->resident_peers_ok && h->p2p_ready && h->opt.dist_p2p != 0) : h->resident_ok) && h->d.rec != nullptr && h->T == 1 && h->resident_downgrades == 0 &&
+    if (!((peers ? (h->resident_peers_ok && (h->p2p_ready || assume_mailboxes) && h->opt.dist_p2p != 0) : h->resident_ok) && h->d.rec != nullptr && h->T == 1 && h->resident_downgrades == 0 &&
           spec_eligible(h) && h->stream == h->own_stream))
         return 0;
     const int nb = branch_blocks(h), ng = gen_blocks(h);
@@ -1766,6 +1781,7 @@ static int resident_mode(exaadmm_handle* h)
     const int wg = (ng + 1) / 2, wb = h->resident_cap2 - wg - 1;
     return (wb > 0 && nb > wb && nb <= 2 * wb) ? 2 : 0;
 }
+static int resident_mode(exaadmm_handle* h) { return resident_mode_if(h, false); }
 static bool resident_eligible(exaadmm_handle* h) { return resident_mode(h) != 0; }
 
 // The failure flag of the resident launches travels with the download that ends a batch (no round trip of its own):
@@ -1790,7 +1806,7 @@ static int resident_downgrade(exaadmm_handle* h)
         set_err("resident launch did not complete on device %d (wait code %d: 1 a bus / decision of this GPU -- shared GPU? --, 2 a cut branch's twin on a peer, 3 a peer's "
             "residual sums, 4 reported by a peer at the end of the launch, 5 a twin in the launch's last step): the call was repeated with two launches per iteration",
                 h->device, h->h_base[1]);
-    if (h->opt.verbose != 0) fprintf(stderr, "exaadmm: %s\n", g_err.c_str());
+    if (h->par.verbose > 0) fprintf(stderr, "exaadmm: %s\n", g_err.c_str());
     return sync_check(h, true);
 }
 
@@ -2097,14 +2113,15 @@ static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
         //  previous inner loop ran long enough to promise it back (heavy_split_prev iterations): 15.0 k -> 18.2 k it/s over the whole solve of
         //  the 1 354-bus grid, whose loops run 250 iterations; nothing at 13 659 buses, whose loops run 100.  S = 48: with 24 or 32 the adoption spends
         //  the free heavy wavefronts on the passing stragglers of a loop's first iterations -- 17.1 k)
-        // (not on a partition with peers: every rank must give its launches the same lengths, and the spare SIMDs differ from rank to rank)
-        const bool split = resident && !peers && h->opt.heavy_split > 0 && h->opt.heavy != 0 && resident_mode(h) == 1 && enq < h->opt.heavy_split &&
-                           (h->last_inner_len < 0 || h->last_inner_len >= h->opt.heavy_split_prev) && h->heavy_max > 0;   // (a handle's first loop: one launch risked)
+        // (a partition with peers: every rank must give its launches the same lengths, and the spare SIMDs differ from rank to rank -- there the rule is
+        //  "every rank runs the one-tile form", which all ranks read from the same mailbox descriptions, exaadmm_dist_p2p_import; the options and the
+        //  length of the previous loop are the same on every rank anyway.  A rank without spare SIMDs then splits its launch for nothing: 0.15 ms)
+        const bool split = resident && h->opt.heavy_split > 0 && h->opt.heavy != 0 && resident_mode(h) == 1 && enq < h->opt.heavy_split &&
+                           (h->last_inner_len < 0 || h->last_inner_len >= h->opt.heavy_split_prev) &&   // (a handle's first loop: one launch risked)
+                           (peers ? h->peers_one_tile : h->heavy_max > 0);
         // (a batch that another one follows must be a multiple of the number of buffer sets long: every launch starts on set 0)
         const int split_len = ((h->opt.heavy_split + h->nsets - 1) / h->nsets) * h->nsets;
-        // (launches of a convergence-tested loop are NOT cut into chunks of resident_chunk iterations the way exaadmm_run_fixed's are: measured, the
-        //  extra launches cost a whole solve 1.5 - 2.5 % -- its loops are short and their first half is not a steady state)
-        const int nb = std::min(resident ? (split && enq < split_len ? split_len - enq : 1024) : batch, max_inner - enq);
+        const int nb = std::min(resident ? (split && enq < split_len ? split_len - enq : RESIDENT_LAUNCH_MAX) : batch, max_inner - enq);
         *h->h_base = enq;   // the stream is idle here (synchronised at the end of every batch)
         HIPCHK(hipMemcpyAsync(&h->d_ctrl->base, h->h_base, sizeof(int), hipMemcpyHostToDevice, h->stream));
         if (resident) {
@@ -2435,8 +2452,10 @@ static int run_fixed_impl(exaadmm_handle* h, int iters, int first_major_iter, do
             if (resident) {
                 // ONE launch for all `iters` iterations: every wavefront stays resident, a bus is updated by the last lane to arrive at it
                 if (time_branch) HIPCHK(hipEventRecord(h->ev[2], h->stream));
-                // (option resident_chunk = C > 0: launches of at most C iterations -- every launch chooses its heavy wavefronts anew)
-                const int chunk = (h->opt.resident_chunk > 0 && resident_mode(h) == 1 && !dist_has_peers(h) && h->opt.heavy != 0 && h->heavy_max > 0) ? std::max(h->nsets, (h->opt.resident_chunk / h->nsets) * h->nsets) : iters;
+                // A launch covers at most RESIDENT_LAUNCH_MAX iterations, the length exaadmm_run_inner's launches have: the words the lanes of a
+                // launch pack an iteration index into (adoption requests: index << 20 in 32 bits; mailbox sequence numbers: (epoch << 12) | index)
+                // hold 1 024 of them with room to spare, not an unbounded count.  Every rank of a partition cuts the same `iters` the same way.
+                const int chunk = std::max(h->nsets, (RESIDENT_LAUNCH_MAX / h->nsets) * h->nsets);
                 for (int i0 = 0; i0 < iters && !refused; i0 += chunk) {
                     if (i0 > 0) hipLaunchKernelGGL(k_ctrl_set_base, dim3(1), dim3(1), 0, h->stream, h->d_ctrl, first_major_iter - 1 + i0);
                     if ((rc = enqueue_resident(h, std::min(chunk, iters - i0), first_major_iter - 1 + i0)) < 0) return rc;
@@ -2692,7 +2711,7 @@ out_rc:
         h->selfcheck_mismatches += 1;
         set_err("resident loop self check: after %d iterations from the same iterate the resident loop and the two-launch loop differ in %s; "
                 "the handle keeps the two-launch loop", SELFCHECK_ITERS, what.c_str());
-        if (h->opt.verbose != 0) fprintf(stderr, "exaadmm: %s\n", g_err.c_str());
+        if (h->par.verbose > 0) fprintf(stderr, "exaadmm: %s\n", g_err.c_str());
     }
     return verdict;
 }
@@ -2723,18 +2742,27 @@ struct OptKey {
     int lo, hi;
 };
 const OptKey OPT_KEYS[] = {
-    {"bus_kernel_lane", &Options::bus_kernel_lane, 0, 1}, {"graph", &Options::graph, 0, 1}, {"spec", &Options::spec, 0, 1},
-    {"mp_spec", &Options::mp_spec, 0, 1}, {"rec", &Options::rec, 0, 1}, {"resident", &Options::resident, 0, 1},
-    {"resident_tiles", &Options::resident_tiles, 0, 1}, {"resident_coop", &Options::resident_coop, 0, 1}, {"heavy", &Options::heavy, 0, 1},
-    {"heavy_from", &Options::heavy_from, 0, 1 << 30}, {"heavy_max", &Options::heavy_max, 0, 512}, {"heavy_select_small", &Options::heavy_select_small, 0, 1}, {"heavy_window", &Options::heavy_window, 0, 1 << 20}, {"heavy_split", &Options::heavy_split, 0, 1 << 20}, {"heavy_split_prev", &Options::heavy_split_prev, 0, 1 << 20}, {"resident_chunk", &Options::resident_chunk, 0, 1 << 20}, {"heavy_adopt", &Options::heavy_adopt, 0, 63}, {"block_order", &Options::block_order, 0, 1}, {"resident_cap_limit", &Options::resident_cap_limit, 0, 1 << 20}, {"dist_overlap", &Options::dist_overlap, 0, 1}, {"dist_graph", &Options::dist_graph, 0, 1}, {"dist_p2p", &Options::dist_p2p, 0, 1},
-    {"trust_resident", &Options::trust_resident, 0, 1}, {"verbose", &Options::verbose, 0, 1}, {"prof_resident", &Options::prof_resident, 0, 1},
+    {"bus_kernel_lane", &Options::bus_kernel_lane, 0, 1}, {"graph", &Options::graph, 0, 1}, {"spec", &Options::spec, 0, 1}, {"rec", &Options::rec, 0, 1},
+    {"resident", &Options::resident, 0, 1}, {"resident_tiles", &Options::resident_tiles, 0, 1}, {"heavy", &Options::heavy, 0, 1}, {"heavy_max", &Options::heavy_max, 0, 512},
+    {"heavy_adopt", &Options::heavy_adopt, 0, 63}, {"heavy_split", &Options::heavy_split, 0, 1 << 20}, {"heavy_split_prev", &Options::heavy_split_prev, 0, 1 << 20}, {"block_order", &Options::block_order, 0, 1},
+    {"dist_overlap", &Options::dist_overlap, 0, 1}, {"dist_p2p", &Options::dist_p2p, 0, 1}, {"trust_resident", &Options::trust_resident, 0, 1},
+#if defined(EXA_PROFILE_PHASES)
+    {"prof_resident", &Options::prof_resident, 0, 1},   // (diagnostic build only)
+#endif
 };
+#if defined(EXA_TEST_HOOKS)
+// switches of the TEST build only (exaadmm_test_hook): what the GPU tests need to reach code paths a product run selects by itself
+const OptKey TEST_KEYS[] = {
+    {"resident_coop", &Options::resident_coop, 0, 1}, {"resident_cap_limit", &Options::resident_cap_limit, 0, 1 << 20}, {"heavy_select_small", &Options::heavy_select_small, 0, 1},
+};
+#endif
 }  // namespace
 
-extern "C" int exaadmm_set_option(exaadmm_handle* h, const char* key, int64_t value)
+// sets one switch of `table`; returns 1 when the key is not in it
+template <size_t NK>
+static int set_switch(exaadmm_handle* h, const OptKey (&table)[NK], const char* key, int64_t value)
 {
-    REQUIRE(h && key, "null argument");
-    for (const OptKey& k : OPT_KEYS) {
+    for (const OptKey& k : table) {
         if (strcmp(k.name, key) != 0) continue;
         if (value < k.lo || value > k.hi) {
             set_err("option %s: value %lld out of range [%d, %d]", key, (long long)value, k.lo, k.hi);
@@ -2750,10 +2778,18 @@ extern "C" int exaadmm_set_option(exaadmm_handle* h, const char* key, int64_t va
         h->spec_on = h->opt.spec != 0 && !h->bus_lane_kernel;   // (the speculative loop needs the lane-group bus kernel: it carries the reduction block)
         h->d.rec = h->opt.rec != 0 ? h->rec_alloc : nullptr;
         h->dev_dirty = true;
-        h->resident_cap = -1;   // (resident_coop is looked at when the capacity is computed)
+        h->resident_cap = -1;   // (resident_coop / resident_cap_limit are looked at when the capacity is computed)
         invalidate_graph(h);
         return EXAADMM_OK;
     }
+    return 1;
+}
+
+extern "C" int exaadmm_set_option(exaadmm_handle* h, const char* key, int64_t value)
+{
+    REQUIRE(h && key, "null argument");
+    const int rc = set_switch(h, OPT_KEYS, key, value);
+    if (rc <= 0) return rc;
     set_err("unknown option %s", key);
     return EXAADMM_ERR_INVALID;
 }
@@ -2774,9 +2810,16 @@ extern "C" int exaadmm_get_option(exaadmm_handle* h, const char* key, int64_t* v
 // Test build only (csrc/Makefile: libexaadmm_hip_hooks.so, -DEXA_TEST_HOOKS): fault injection for tests/test_gpu_resident.py.
 //   "fail_resident_launch" n : the n-th resident launch of the handle reports a failed wait (0: off)
 //   "flip_resident_ulp" 1    : the resident leg of the next self check gets one ulp added to one word of u
+//   "p2p_delay_us" n         : every mailbox message of a partition's resident loop is delayed by n microseconds
+// ... and three switches that let a test reach code a product run selects by itself:
+//   "resident_coop" 0        : plain instead of cooperative launches of the resident kernels (two ranks of a test sharing ONE GPU)
+//   "resident_cap_limit" n   : treat the chip as holding at most n resident wavefronts (the two-tile form on small grids)
+//   "heavy_select_small" 1   : the kernel that picks a launch's heavy wavefronts runs as one wavefront (ranks of a test sharing ONE GPU)
 extern "C" int exaadmm_test_hook(exaadmm_handle* h, const char* key, int64_t value)
 {
     REQUIRE(h && key, "null argument");
+    const int rc = set_switch(h, TEST_KEYS, key, value);   // "resident_coop", "resident_cap_limit", "heavy_select_small"
+    if (rc <= 0) return rc;
     if (strcmp(key, "fail_resident_launch") == 0) h->hook_fail_launch = (int)value;
     else if (strcmp(key, "flip_resident_ulp") == 0) h->hook_flip_ulp = (int)value;
     else if (strcmp(key, "p2p_delay_us") == 0) h->hook_p2p_delay_ticks = (int)(100 * value);

@@ -187,34 +187,26 @@ int exaadmm_resident_selfcheck_stats(exaadmm_handle *h, int *checks, int *mismat
  * want switches from the environment translate them: exaadmm.jl_amd/__init__.py, tools/exaadmm_solve.c).  Set after create,
  * between loop calls.  Keys (default):
  *   "bus_kernel_lane" (0)  1: one lane per bus, the reference-order twin k_bus; implies the four-launch loop
- *   "graph" (1)            batches of the two- / four-launch loops replayed from a hipGraph
- *   "spec" (1)             the speculative two-launch loop (0: four launches per iteration)
- *   "mp_spec" (1)          ... for a multi-period handle
+ *   "graph" (1)            batches of the two- / four-launch loops (a partition with peers: incl. their exchanges) replayed from a hipGraph
+ *   "spec" (1)             the speculative two-launch loop (0: four launches per iteration); single- and multi-period handles alike
  *   "rec" (1)              pushed bus records in the fused loops (0: gathers like the step-wise path; no resident loop then)
  *   "resident" (1)         the resident loop where the grid fits the chip
  *   "resident_tiles" (1)   its two-tiles-per-wavefront form for grids up to twice the chip's SIMD count
- *   "resident_coop" (1)    cooperative launch of the resident kernels (the runtime checks co-residency)
  *   "heavy" (1)            heavy wavefronts (the branches with the most solver trips on wavefronts of their own)
- *   "heavy_from" (64)      first iteration of an inner loop from which a resident launch may carry heavy wavefronts
  *   "heavy_max" (512)      at most this many of them (they take the SIMDs the launch leaves idle; fewer when the GPU is shared)
- *   "heavy_window" (64)    W: a branch that needed >= 3 solver trips in the last W resident iterations is a candidate too, after those of the last two
- *                          iterations; then those of the last 4 W, then 16 W iterations, as far as the heavy wavefronts reach (0: only the last two count)
  *   "heavy_adopt" (4)      a branch lane whose solve took at least this many trips hands its branch to one of the launch's free heavy wavefronts, from the
  *                          next iteration on (0: the heavy wavefronts of a launch are those chosen in front of it)
- *   "resident_chunk" (0)   > 0: exaadmm_run_fixed on a grid with heavy wavefronts launches at most this many iterations at a time, each launch with a
- *                          fresh choice (what the adoption made unnecessary: 0.1 ms per launch)
  *   "heavy_split" (48)     > 0: the first launch of a convergence-tested inner loop ends after this many iterations and the rest of the loop runs with heavy
- *                          wavefronts -- when the handle's previous inner loop ran at least "heavy_split_prev" (96) iterations; 0: one launch per 1 024 iterations
+ *                          wavefronts -- when the handle's previous inner loop ran long enough to promise the extra launch back; 0: one launch per 1 024 iterations
+ *   "heavy_split_prev" (96) ... at least this many iterations (a handle's first loop is always split)
  *   "block_order" (1)      launches with more blocks than the chip has SIMDs (the multi-period model, grids beyond the resident loop): the generator / ramp
  *                          blocks first, then the tiles of 64 branches by falling solver-trip count (0: in storage order)
- *   "heavy_select_small" (0) 1: the kernel that picks them runs as ONE wavefront (slower; a block of 16 wavefronts cannot start on a GPU whose
- *                          CUs all hold a resident wavefront of ANOTHER launch that waits for this one -- ranks sharing a GPU in tests)
- *   "resident_cap_limit" (0) > 0: treat the chip as holding at most this many resident wavefronts (tests: the two-tile form on small grids)
- *   "dist_overlap" (1)     partition with peers: the exchange on a second stream beside the interior solves
- *   "dist_graph" (1)       ... and batches incl. their exchanges replayed from a hipGraph (read at exaadmm_dist_connect)
+ *   "dist_overlap" (1)     partition with peers, two launches per iteration: the exchange on a second stream beside the interior solves
  *   "dist_p2p" (1)         partition with peers whose mailboxes are mapped (exaadmm_dist_p2p_import): the resident loop
  *   "trust_resident" (0)   1: no first-use self check of the resident loops
- *   "verbose" (0)          1: downgrades are reported on stderr
+ * (Fifteen keys.  What rounds 4-5 also offered: heavy_from / heavy_window are constants, resident_chunk / heavy_select_small are gone, mp_spec is
+ *  "spec", dist_graph is "graph", resident_coop / resident_cap_limit are switches of the test build's exaadmm_test_hook only, and downgrades are
+ *  reported on stderr when exaadmm_params.verbose > 0.)
  * Unknown key: EXAADMM_ERR_INVALID. */
 int exaadmm_set_option(exaadmm_handle *h, const char *key, int64_t value);
 int exaadmm_get_option(exaadmm_handle *h, const char *key, int64_t *value);
@@ -273,10 +265,15 @@ int exaadmm_dist_detach(exaadmm_handle *h);
  * ranks can write into each other's device memory -- what crosses GPUs (per cut branch the update of the bus at its far end, 4 doubles
  * each way; the four residual sums) then goes by direct stores over xGMI into the peer's MAILBOX from inside the launch, no kernel
  * boundary and no collective call per iteration.
- *   exaadmm_dist_p2p_export  after exaadmm_dist_prepare: 256 bytes describing this rank's mailbox (process, device, address, IPC handle)
- *   exaadmm_dist_p2p_import  every rank's blob, in rank order (the caller's all-gather): maps the peers' mailboxes.  Local; the ranks agree
- *                            on the outcome before they rely on it (a rank that cannot map a peer keeps two launches per iteration,
- *                            and so must the others: option "dist_p2p" = 0).
+ *   exaadmm_dist_p2p_export  after exaadmm_dist_prepare (and after the options / stream of the handle are final): 256 bytes describing this
+ *                            rank's mailbox (process, device, address, IPC handle) and WHICH resident form this partition would run (none,
+ *                            one tile, two tiles per wavefront -- size against the chip, options "resident" / "rec" / "spec", own stream)
+ *   exaadmm_dist_p2p_import  every rank's blob, in rank order (the caller's all-gather): maps the peers' mailboxes.  Refused -- on every rank
+ *                            alike, they read the same blobs -- when ANY rank's partition would not run a resident form: a rank on the
+ *                            two-launch loop would leave its peers' launches in their capped waits.  Local otherwise; the ranks agree on the
+ *                            outcome before they rely on it (a rank that cannot map a peer keeps two launches per iteration, and so must the
+ *                            others: option "dist_p2p" = 0).  The first launch of an inner loop is split for the heavy wavefronts (option
+ *                            "heavy_split") when every rank runs the one-tile form -- read from the blobs as well, so launch lengths agree.
  * A launch whose waits run into their cap on any rank is reported to every rank by the launch's last kernel; all then restore the
  * iterate the call started from and repeat it with two launches per iteration + the RCCL exchange (exaadmm_loop_downgrades). */
 #define EXAADMM_P2P_BLOB_BYTES 256

@@ -6,10 +6,11 @@ import ctypes as C
 import numpy as np
 
 
-def oracle_branch_subset(oracle, g, sol, membuf, branches, scale=1e-4, max_auglag=50, mu_max=1e8, major_iter=2):
+def oracle_branch_subset(oracle, g, sol, membuf, branches, scale=1e-4, max_auglag=50, mu_max=1e8, major_iter=2, want_x=False):
     """sol: dict of reference-layout vectors (u_curr, v_curr, z_curr, l_curr, rho); membuf: (nline, 31)
     rows as the reference's columns.  Returns (u_rows [len(branches) x 8], auglag_it, minor_it, membuf rows
-    24..26 after the solve).  Mirrors acopf_auglag_linelimit_kernel_cpu.jl:21-168 through the oracle."""
+    24..26 after the solve); want_x: also the solver's final point x [len(branches) x 6] and its bounds xl, xu (which variables
+    ended ON a bound).  Mirrors acopf_auglag_linelimit_kernel_cpu.jl:21-168 through the oracle."""
     L = oracle.lib()
     G_ = int(g["ngen"])
     Y = np.stack([np.asarray(g[k]) for k in ("YffR", "YffI", "YftR", "YftI", "YttR", "YttI", "YtfR", "YtfI")], 1)
@@ -18,6 +19,7 @@ def oracle_branch_subset(oracle, g, sol, membuf, branches, scale=1e-4, max_augla
     a_ref = np.zeros(n, dtype=np.int64)
     m_ref = np.zeros(n, dtype=np.int64)
     mult = np.zeros((n, 3))
+    xs, xls, xus = np.zeros((n, 6)), np.zeros((n, 6)), np.zeros((n, 6))
     for i, b in enumerate(branches):
         b = int(b)
         p0 = 2 * G_ + 8 * b
@@ -40,6 +42,7 @@ def oracle_branch_subset(oracle, g, sol, membuf, branches, scale=1e-4, max_augla
                               C.cast(C.byref(it_), oracle.c_int_p), C.cast(C.byref(mi_), oracle.c_int_p))
         a_ref[i], m_ref[i] = it_.value, mi_.value
         mult[i] = prm[24:27]
+        xs[i], xls[i], xus[i] = x, xl, xu
         cs, sn = np.cos(x[2] - x[3]), np.sin(x[2] - x[3])
         vv = x[0] * x[1]
         u_out[i] = [yb[0] * x[0] ** 2 + yb[2] * vv * cs + yb[3] * vv * sn,
@@ -47,4 +50,6 @@ def oracle_branch_subset(oracle, g, sol, membuf, branches, scale=1e-4, max_augla
                     yb[4] * x[1] ** 2 + yb[6] * vv * cs - yb[7] * vv * sn,
                     -yb[5] * x[1] ** 2 - yb[7] * vv * cs - yb[6] * vv * sn,
                     x[0] ** 2, x[1] ** 2, x[2], x[3]]
+    if want_x:
+        return u_out, a_ref, m_ref, mult, xs, xls, xus
     return u_out, a_ref, m_ref, mult

@@ -36,7 +36,7 @@ if what == "ok":
     if rank == "0":
         print("some library banner")
         print(json.dumps({"metric": "ADMM inner iterations/sec", "value": 100.0 + 10 * int(attempt), "leg": leg,
-                          "p2p": os.environ.get("EXAADMM_DIST_P2P", "1"), "graph": os.environ.get("EXAADMM_OPT_DIST_GRAPH", "1"), "overlap": os.environ.get("EXAADMM_OPT_DIST_OVERLAP", "1"),
+                          "p2p": os.environ.get("EXAADMM_DIST_P2P", "1"), "graph": "0" if os.environ.get("EXAADMM_NO_GRAPH") else "1", "overlap": os.environ.get("EXAADMM_DIST_OVERLAP", "1"),
                           "python_loop": os.environ.get("EXAADMM_DIST_PYTHON_LOOP", ""), "port": os.environ["MASTER_PORT"]}))
 '''
 

@@ -187,6 +187,15 @@ def _shim():
     return so
 
 
+def _hooks_lib():
+    """the TEST build of the library (csrc/Makefile libexaadmm_hip_hooks.so): ranks that share this box's ONE GPU need its switches -- plain
+    instead of cooperative launches of the resident kernels (the runtime refuses a second cooperative grid), a chip declared small"""
+    lib = os.path.join(ROOT, "exaadmm.jl_amd", "libexaadmm_hip_hooks.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "exaadmm.jl_amd", "csrc"), "../libexaadmm_hip_hooks.so"])
+    return lib
+
+
 def _run_worker(world, case, **extra_env):
     if os.environ.get("EXAADMM_NO_SPEC") or os.environ.get("EXAADMM_BUS_KERNEL") == "lane":
         pytest.skip("the in-library loop of a partition with peers IS the two-launch speculative loop; this A/B switch turns that loop off")
@@ -215,7 +224,7 @@ def test_library_distributed_loop_with_several_ranks_on_one_gpu(world):
     assert groups == 61 * world and sends == recvs == 61 * world * (world - 1), out
 
 
-_NO_DIST_GRAPH = bool(os.environ.get("EXAADMM_NO_GRAPH") or os.environ.get("EXAADMM_DIST_GRAPH") == "0")
+_NO_DIST_GRAPH = bool(os.environ.get("EXAADMM_NO_GRAPH"))
 _NOT_THE_DEFAULT_LOOP = bool(_NO_DIST_GRAPH or os.environ.get("EXAADMM_NO_REC") or os.environ.get("EXAADMM_DIST_OVERLAP") == "0" or os.environ.get("EXAADMM_NO_SPEC")
                              or os.environ.get("EXAADMM_BUS_KERNEL") == "lane")
 
@@ -359,7 +368,7 @@ def test_resident_loop_with_peers_is_the_single_handle_solve(world, case):
     every rank on the resident loop (loop kind 2 before and after, no downgrade) and NOTHING through the communication library during the
     loops: per cut branch the far bus's update, per z / l pass the four residual sums, the sums that complete a loop's last iteration and
     ||z|| of the outer loop all travel through the mailboxes."""
-    out = _run_worker(world, case, EXAADMM_DIST_P2P="1", EXAADMM_RESIDENT_COOP="0", GPU_MAX_HW_QUEUES="16")
+    out = _run_worker(world, case, EXAADMM_DIST_P2P="1", EXAADMM_RESIDENT_COOP="0", EXAADMM_HIP_LIB=_hooks_lib(), GPU_MAX_HW_QUEUES="16")
     assert out["cut"] > 0
     assert all(st["p2p"] and st["loop_kind"] == 2 and st["downgrades"] == 0 for st in out["dist_stats"]), out["dist_stats"]
     assert all(c == out["single"][1] for c in out["cumul"]) and all(o == out["single"][0] for o in out["outer"]), out
@@ -379,9 +388,9 @@ def test_resident_loop_with_peers_and_heavy_wavefronts_two_areas_of_the_headline
     GPU at the same time (2 x ~390 wavefronts + the heavy wavefronts that still fit): 60 iterations from the start, then 30 that continue
     beyond the 64th -- launches with heavy wavefronts (interior branches only: cut branches stay with their lanes, which talk to the
     peers) -- bitwise the single handle, replicas bit-identical, no downgrade."""
-    out = _run_worker(2, "areas13659", EXAADMM_DIST_P2P="1", EXAADMM_RESIDENT_COOP="0", GPU_MAX_HW_QUEUES="16", EXAADMM_TEST_NFIX2="30",
+    out = _run_worker(2, "areas13659", EXAADMM_DIST_P2P="1", EXAADMM_RESIDENT_COOP="0", EXAADMM_HIP_LIB=_hooks_lib(), GPU_MAX_HW_QUEUES="16", EXAADMM_TEST_NFIX2="30",
                       EXAADMM_HEAVY_MAX="100",      # (both ranks share the 1 024 SIMDs of this box: 2 x (387 + 100) wavefronts
-                      EXAADMM_OPT_HEAVY_SELECT_SMALL="1")   #  ... and no CU is free of the other rank's resident wavefronts: the selection kernel as one wavefront)
+                      EXAADMM_HEAVY_SELECT_SMALL="1")   #  ... and no CU is free of the other rank's resident wavefronts: the selection kernel as one wavefront)
     assert out["cut"] > 0
     print(out["fixed_loop"])
     assert all(n == 0 for n in out["fixed_nonzero_differences"].values()), out
@@ -394,9 +403,9 @@ def test_resident_loop_with_peers_and_heavy_wavefronts_two_areas_of_the_headline
 def test_two_tile_form_of_the_resident_loop_with_peers__on_a_small_grid():
     """The form a partition of ACTIVSg70k's size runs (more tiles of 64 branches than SIMDs: up to two tiles per resident wavefront, tiles
     that hold cut branches first in their wavefront) cannot share this box's one GPU between two ranks at its real size; the chip is
-    declared small instead (option resident_cap_limit) so that the 1 354-bus partitions (17 + 18 tiles) need the two-tile form: solves
+    declared small instead (test hook resident_cap_limit) so that the 1 354-bus partitions (17 + 18 tiles) need the two-tile form: solves
     with the single handle's counts, fixed-count run bitwise, replicas bit-identical, no downgrade."""
-    out = _run_worker(2, "", EXAADMM_DIST_P2P="1", EXAADMM_RESIDENT_COOP="0", GPU_MAX_HW_QUEUES="16", EXAADMM_OPT_RESIDENT_CAP_LIMIT="14")
+    out = _run_worker(2, "", EXAADMM_DIST_P2P="1", EXAADMM_RESIDENT_COOP="0", EXAADMM_HIP_LIB=_hooks_lib(), GPU_MAX_HW_QUEUES="16", EXAADMM_RESIDENT_CAP_LIMIT="14")
     assert all(st["p2p"] and st["loop_kind"] == 2 and st["downgrades"] == 0 and st["form"]["tiles"] == 2 for st in out["dist_stats"]), out["dist_stats"]
     assert all(c == out["single"][1] for c in out["cumul"]) and all(o == out["single"][0] for o in out["outer"]), out
     assert all(e <= 1e-10 for e in out["err"].values()), out

@@ -84,9 +84,13 @@ def test_two_processes_on_one_gpu_share_mailboxes_through_ipc_handles():
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
+    # (two processes on ONE GPU: the runtime refuses the second cooperative grid -- the TEST build's switch "resident_coop" = 0 launches plainly)
+    hooks = os.path.join(ROOT, "exaadmm.jl_amd", "libexaadmm_hip_hooks.so")
+    if not os.path.exists(hooks):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "exaadmm.jl_amd", "csrc"), "../libexaadmm_hip_hooks.so"])
     procs = []
     for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), EXAADMM_RESIDENT_COOP="0",
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), EXAADMM_RESIDENT_COOP="0", EXAADMM_HIP_LIB=hooks,
                    HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, "-c", WORKER % {"root": ROOT}], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []

@@ -317,10 +317,80 @@ def test_branch_kernel_vs_oracle_on_perturbed_states(pkg, oracle, syn, seed, noi
     u_gpu = mod.solution.u_curr
     err = np.abs(u_gpu[2 * G_:] - u_ref[2 * G_:]).reshape(L_, 8).max(axis=1)
     same = (a_gpu == a_ref) & (m_gpu == m_ref)
-    assert same.mean() >= 0.995, (same.mean(), a_gpu.max(), a_ref.max())
+    print("seed %d noise %g: %d of %d branches with other iteration counts than the oracle's; max auglag %d, max TRON minor %d"
+          % (seed, noise, int((~same).sum()), L_, int(a_ref.max()), int(m_ref.max())))
+    # the shipped (fast-arithmetic) build: measured 0 / 0 / 5 of 20 467 on these three states (tests/test_gpu_exact_arith.py reports them;
+    # the exact-arithmetic build: 0) -- the gate is 10 of 20 467 = 5e-4, not the 0.5 % of rounds 1-5
+    assert int((~same).sum()) <= 10, (int((~same).sum()), a_gpu.max(), a_ref.max())
     assert (err[same] <= 1e-7).all(), err[same].max()
     assert np.quantile(err, 0.999) <= 1e-5 and np.isfinite(u_gpu).all()
     assert a_ref.max() >= 3   # the sample does contain multi-iteration augmented-Lagrangian solves
+
+
+def test_branch_kernel_on_the_first_iterations_of_outer_iteration_2__long_tron_paths_and_active_bounds(pkg, oracle, syn):
+    """Where the solver works hardest: the first iterations of an outer iteration restart every branch's penalty at 10
+    (acopf_auglag_linelimit_kernel_cpu.jl:74-79, major_iter == 1) and TRON makes 20 - 25 trips on the thermal-limit-binding branches
+    (profiles/r04_iteration_cost_vs_iteration_index_case13659_whole_solve.txt) -- the samples of the tests above (states after 3 - 6 iterations
+    of outer iteration 1, plus noise) only had to contain an augmented-Lagrangian count of 3.  Here the GPU runs outer
+    iteration 1 of the headline-size grid to its stop (step-wise control as admm_two_level.jl:29-77), updates lz and beta, and the x-updates of
+    iterations 1, 2, 3 of OUTER ITERATION 2 are compared branch by branch with the oracle's single-branch solve from the same (downloaded)
+    state: the sample must CONTAIN branches with >= 10 TRON minor iterations and branches that end on a bound (a binding thermal limit:
+    s = -rateA; a voltage magnitude at its box), and those groups must AGREE with the oracle like the rest -- iteration counts equal on all but
+    a handful, u within 1e-7 wherever they are."""
+    from branch_ref import oracle_branch_subset
+    g = syn.sized_like("case13659pegase", seed=0)
+    rho = (5e1, 5e3)
+    env = pkg.AdmmEnv("syn", rho[0], rho[1], verbose=0, grid=g)
+    mod = pkg.ModelAcopf(env)
+    G_, L_ = int(g["ngen"]), int(g["nline"])
+    beta = env.params.initial_beta
+    # outer iteration 1 (admm_two_level.jl:29-77): norm of z, inner loop to its stop test, lz update, beta rule
+    env.params.beta = beta
+    mod.info.outer = 1
+    pkg.admm_outer_prestep(env, mod)
+    inner, res = mod.run_inner(1, 1000, beta)
+    assert 50 <= inner < 1000, inner
+    pkg.admm_update_lz(env, mod)
+    if res[2] > env.params.theta * mod.info.norm_z_prev:
+        beta = min(env.params.inc_c * beta, 1e24)
+    env.params.beta = beta
+    mod.info.outer = 2
+    seen_long, seen_bound, total_mis = 0, 0, 0
+    for it in (1, 2, 3):
+        sol = {k: getattr(mod.solution, k).copy() for k in ("u_curr", "v_curr", "z_curr", "l_curr", "rho")}
+        membuf = np.ascontiguousarray(mod.membuf.T).copy()
+        u_ref, a_ref, m_ref, mult, x, xl, xu = oracle_branch_subset(oracle, g, sol, membuf, np.arange(L_), major_iter=it, want_x=True)
+        mod.info.inner = it
+        pkg.admm_inner_prestep(env, mod)
+        pkg.admm_update_x(env, mod)
+        a_gpu, m_gpu, _ = mod.branch_counters()
+        u_gpu = mod.solution.u_curr[2 * G_:].reshape(L_, 8)
+        err = np.abs(u_gpu - u_ref).max(axis=1)
+        same = (a_gpu == a_ref) & (m_gpu == m_ref)
+        long_path = m_ref >= 10
+        on_bound = ((x == xl) | (x == xu))[:, [0, 1, 4, 5]].any(axis=1) & (xl != xu)[:, [0, 1, 4, 5]].any(axis=1)   # (x[4] = x[5] = 0 = xu is every
+        on_bound &= ((x[:, 4] == xl[:, 4]) | (x[:, 5] == xl[:, 5]) | (x[:, 0] == xl[:, 0]) | (x[:, 0] == xu[:, 0]) |     #  idle branch: only the LOWER
+                     (x[:, 1] == xl[:, 1]) | (x[:, 1] == xu[:, 1]))                                                  #  bound of s is a binding limit)
+        print("outer 2 iteration %d: %d branches with other counts than the oracle's; %d with >= 10 TRON minor iterations (max %d, %d of them agree); "
+              "%d ending on a bound (%d agree); max auglag %d" % (it, int((~same).sum()), int(long_path.sum()), int(m_ref.max()), int((same & long_path).sum()),
+                                                                  int(on_bound.sum()), int((same & on_bound).sum()), int(a_ref.max())))
+        assert int((~same).sum()) <= 10, (it, int((~same).sum()))
+        assert (err[same] <= 1e-7).all(), (it, err[same].max())
+        assert np.quantile(err, 0.999) <= 1e-5 and np.isfinite(u_gpu).all()
+        for grp in (long_path, on_bound):
+            if grp.sum():
+                assert (same & grp).sum() >= grp.sum() - 5, (it, int(grp.sum()), int((same & grp).sum()))
+        seen_long += int(long_path.sum())
+        seen_bound += int(on_bound.sum())
+        total_mis += int((~same).sum())
+        # the rest of the iteration on the GPU (admm_two_level.jl:38-42), so that the next comparison starts from iteration it + 1's state
+        pkg.admm_update_xbar(env, mod)
+        pkg.admm_update_z(env, mod)
+        pkg.admm_update_l(env, mod)
+        pkg.admm_update_residual(env, mod)
+    assert seen_long >= 100, seen_long     # the 20 - 25-trip TRON paths ARE in the sample ...
+    assert seen_bound >= 20, seen_bound    # ... and so are solutions on a binding thermal limit / voltage bound
+    mod.close()
 
 
 def test_full_solve_to_convergence_matches_oracle(pkg, oracle, syn):
@@ -535,11 +605,11 @@ def test_rolling_horizon_on_the_118_bus_system_matches_oracle(pkg, oracle, tmp_p
     assert np.abs(mod.solution.u_curr - ref.sol["u_curr"]).max() <= 1e-6 * max(1.0, np.abs(ref.sol["u_curr"]).max())
 
 
-@pytest.mark.parametrize("case,cumul,objval,tol", [("case9.m", 705, 5303.435, 1e-2), ("case118.m", 1232, 129645.676, 0.13)])
+@pytest.mark.parametrize("case,cumul,objval,tol", [("case9.m", 705, 5303.435, 1e-3), ("case118.m", 1232, 129645.676, 0.13)])
 def test_plain_c_driver_solves_the_reference_anchors(case, cumul, objval, tol):
     """tools/exaadmm_solve (C, no Python in the loop): native MATPOWER loader + C ABI + fused two-level
     solve; prints the reference's statistics block.  Anchors (acopf_update_cpu.jl:168-179): Solved / 20 / 705 /
-    5303.435 and Solved / 20 / 1232 / 129645.676."""
+    5303.435 (atol 1e-3, the reference's) and Solved / 20 / 1232 / 129645.676 (rtol 1e-6)."""
     import re
     import subprocess
     from conftest import ROOT
@@ -553,7 +623,8 @@ def test_plain_c_driver_solves_the_reference_anchors(case, cumul, objval, tol):
     assert "Solved" in out
     assert int(re.search(r"Cumulative iterations[ .]*(\d+)", out).group(1)) == cumul
     assert int(re.search(r"Outer iterations[ .]*(\d+)", out).group(1)) == 20
-    assert abs(float(re.search(r"Objective value[ .]*([-+0-9.eE]+)", out).group(1)) - objval) <= tol
+    assert abs(float(re.search(r"Objective value[ .]*([-+0-9.eE]+)", out).group(1)) - objval) <= tol + 0.5e-6 * objval   # (the block prints 7 digits)
+    assert abs(float(re.search(r"^objval=([-+0-9.eE]+)", out, flags=re.M).group(1)) - objval) <= tol
 
 
 def test_relaxed_check_every_is_opt_in_and_bounded(pkg):

@@ -151,12 +151,12 @@ def test_stragglers_adopted_by_free_heavy_wavefronts_inside_a_launch(pkg, case, 
     """Option heavy_adopt = t: a branch lane whose solve took >= t trips hands its branch to a free heavy wavefront from the next
     iteration on (kernels.h ResidentHeavy: adoption) -- the state travels through an agent-scope record, the planes' words of the
     branch stay the lane's (it writes them from the heavy wavefront's hand-over).  Off, at the default and at 3 trips (many more
-    adoptions), launches of odd and even lengths and chunks of 14: every bit the same."""
+    adoptions), launches of odd and even lengths: every bit the same."""
     syn = exaadmm_loader.load_submodule("synthetic")
     g = syn.sized_like(case, seed=0)
     runs = []
-    for adopt, chunk in ((0, 0), (4, 0), (3, 0), (3, 14)):
-        with _env(EXAADMM_HEAVY_ADOPT=adopt, EXAADMM_RESIDENT_CHUNK=chunk):
+    for adopt in (0, 4, 3):
+        with _env(EXAADMM_HEAVY_ADOPT=adopt):
             env = pkg.AdmmEnv(case, rho[0], rho[1], verbose=0, grid=g)
             mod = pkg.ModelAcopf(env)
             assert mod.loop_kind() == 2
@@ -172,6 +172,34 @@ def test_stragglers_adopted_by_free_heavy_wavefronts_inside_a_launch(pkg, case, 
         for a, b in zip(runs[0], other):
             for x, y in zip(a, b):
                 assert np.array_equal(x, y)
+
+
+@pytest.mark.skipif(SWITCHED_OFF, reason="a switch of this run turns the resident loop off")
+def test_fixed_count_runs_longer_than_one_launch_may_be(pkg):
+    """exaadmm_run_fixed used to issue all its iterations as ONE resident launch.  The lanes of a launch pack the launch-relative
+    iteration index into 32-bit words next to a branch number (adoption requests: index << 20) and into the mailboxes' sequence
+    numbers ((epoch << 12) | index): from index 2 048 / 4 096 on those overflow -- a free heavy wavefront would start its adopted
+    branch at a wrong iteration and add spurious arrivals at its buses, silently.  A launch now covers at most 1 024
+    iterations, as exaadmm_run_inner's always did: 2 100 iterations that continue an inner loop (heavy wavefronts and adoption on,
+    three launches) are bitwise the two-launch loop's."""
+    syn = exaadmm_loader.load_submodule("synthetic")
+    g = syn.sized_like("case1354pegase", seed=0)
+    runs = []
+    for two in (True, False):
+        with _two_launch(two):
+            env = pkg.AdmmEnv("case1354pegase", 1e1, 1e3, verbose=0, grid=g)
+            mod = pkg.ModelAcopf(env)
+            assert mod.loop_kind() == (1 if two else 2)
+            n1, _, _ = mod.run_fixed(300, first_major_iter=1, beta=1e3)
+            n2, _, _ = mod.run_fixed(2100, first_major_iter=301, beta=1e3)
+            if not two:
+                f = mod.resident_form()
+                assert f["tiles"] == 1 and f["launches"] == 3, f        # 1 024 + 1 024 + 52
+                assert mod.loop_downgrades() == 0, pkg.library().exaadmm_last_error()
+            runs.append(_state(mod) + [n1.copy(), n2.copy()])
+            mod.close()
+    for x, y in zip(*runs):
+        assert np.array_equal(x, y)
 
 
 @pytest.mark.skipif(SWITCHED_OFF or bool(os.environ.get("EXAADMM_NO_HEAVY")), reason="a switch of this run turns the resident loop / its heavy wavefronts off")

@@ -98,7 +98,7 @@ def test_properties_at_scale(pkg, case):
 def test_branch_kernel_vs_oracle_on_a_sample_at_scale(pkg, oracle, case):
     """20 000 seeded branches: the GPU x-update of iteration 4 against the oracle's single-branch solve from
     the same state (the GPU's own state after 3 iterations, downloaded).  u within 1e-7 wherever the
-    per-branch (augmented-Lagrangian, TRON minor) iteration counts agree, which must be >= 99.5 %."""
+    per-branch (augmented-Lagrangian, TRON minor) iteration counts agree -- on all but at most 10 of the 20 000."""
     g, env, mod = _model(pkg, case)
     cfg = CONFIGS[case]
     mod.run_fixed(3, first_major_iter=1, beta=1e3)
@@ -117,7 +117,11 @@ def test_branch_kernel_vs_oracle_on_a_sample_at_scale(pkg, oracle, case):
     err = np.abs(u_gpu - u_ref).max(axis=1)
     same = (a_gpu[sample] == a_ref) & (m_gpu[sample] == m_ref)
     assert np.isfinite(u_gpu).all()
-    assert same.mean() >= 0.995, (same.mean(), int((~same).sum()))
+    print("%s: %d of %d sampled branches with other iteration counts than the oracle's (max auglag %d, max TRON minor %d)"
+          % (case, int((~same).sum()), len(sample), int(a_ref.max()), int(m_ref.max())))
+    # shipped (fast-arithmetic) build: the gate is 10 of 20 000 = 5e-4 (the headline grid measures 0 - 5 of 20 467 per state,
+    # tests/test_gpu_exact_arith.py), not the 0.5 % of rounds 1-5
+    assert int((~same).sum()) <= 10, (same.mean(), int((~same).sum()))
     assert (err[same] <= 1e-7).all(), err[same].max()
     assert np.quantile(err, 0.999) <= 1e-5
     # penalties are powers of ten: equal exactly wherever the counts agree.  The multipliers accumulate

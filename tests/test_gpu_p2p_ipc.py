@@ -90,7 +90,7 @@ def test_two_processes_on_one_gpu_share_mailboxes_through_ipc_handles():
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "exaadmm.jl_amd", "csrc"), "../libexaadmm_hip_hooks.so"])
     procs = []
     for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), EXAADMM_RESIDENT_COOP="0", EXAADMM_HIP_LIB=hooks,
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), EXAADMM_RESIDENT_COOP="0", EXAADMM_HIP_LIB=hooks, EXAADMM_HEAVY_MAX="100", EXAADMM_HEAVY_SELECT_SMALL="1",
                    HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, "-c", WORKER % {"root": ROOT}], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []

@@ -94,11 +94,10 @@ def test_properties_at_scale(pkg, case):
     mod.close()
 
 
-@pytest.mark.parametrize("case", list(CONFIGS))
-def test_branch_kernel_vs_oracle_on_a_sample_at_scale(pkg, oracle, case):
-    """20 000 seeded branches: the GPU x-update of iteration 4 against the oracle's single-branch solve from
-    the same state (the GPU's own state after 3 iterations, downloaded).  u within 1e-7 wherever the
-    per-branch (augmented-Lagrangian, TRON minor) iteration counts agree -- on all but at most 10 of the 20 000."""
+def _sample_against_oracle(pkg, oracle, case):
+    """20 000 seeded branches: the GPU x-update of iteration 4 against the oracle's single-branch solve from the same state (the GPU's own
+    state after 3 iterations, downloaded).  Returns the comparison (used with the shipped library in this process and with the
+    reference-arithmetic build in a worker process)."""
     g, env, mod = _model(pkg, case)
     cfg = CONFIGS[case]
     mod.run_fixed(3, first_major_iter=1, beta=1e3)
@@ -116,12 +115,27 @@ def test_branch_kernel_vs_oracle_on_a_sample_at_scale(pkg, oracle, case):
     mb_gpu = mod.membuf.T[sample]
     err = np.abs(u_gpu - u_ref).max(axis=1)
     same = (a_gpu[sample] == a_ref) & (m_gpu[sample] == m_ref)
+    mod.close()
+    return dict(n=len(sample), same=same, err=err, u_gpu=u_gpu, mb_gpu=mb_gpu, mult=mult, a_ref=a_ref, m_ref=m_ref)
+
+
+# count mismatches the shipped (fast-arithmetic) build may show on the 20 000-branch sample: measured 42 at ACTIVSg70k's settings (scale 1e-5 puts
+# the projected-gradient test gtol = 1e-6 within rounding distance of more branches' final gradients) and 0 at 1M branches; the headline grid
+# measures 0 - 5 of 20 467 per state (tests/test_gpu_exact_arith.py).  The reference-arithmetic build must show (essentially) none on the same
+# samples -- which is what says the shipped build's mismatches are its arithmetic, not an error (test below).
+FAST_BUILD_GATE = {"case_ACTIVSg70k": 64, "synthetic1M": 10}
+
+
+@pytest.mark.parametrize("case", list(CONFIGS))
+def test_branch_kernel_vs_oracle_on_a_sample_at_scale(pkg, oracle, case):
+    """u within 1e-7 wherever the per-branch (augmented-Lagrangian, TRON minor) iteration counts agree -- on all but a measured handful of the
+    20 000 (FAST_BUILD_GATE; rounds 1-5 allowed 0.5 %)."""
+    r = _sample_against_oracle(pkg, oracle, case)
+    same, err, u_gpu, mb_gpu, mult, a_ref, m_ref = (r[k] for k in ("same", "err", "u_gpu", "mb_gpu", "mult", "a_ref", "m_ref"))
     assert np.isfinite(u_gpu).all()
     print("%s: %d of %d sampled branches with other iteration counts than the oracle's (max auglag %d, max TRON minor %d)"
-          % (case, int((~same).sum()), len(sample), int(a_ref.max()), int(m_ref.max())))
-    # shipped (fast-arithmetic) build: the gate is 10 of 20 000 = 5e-4 (the headline grid measures 0 - 5 of 20 467 per state,
-    # tests/test_gpu_exact_arith.py), not the 0.5 % of rounds 1-5
-    assert int((~same).sum()) <= 10, (same.mean(), int((~same).sum()))
+          % (case, int((~same).sum()), r["n"], int(a_ref.max()), int(m_ref.max())))
+    assert int((~same).sum()) <= FAST_BUILD_GATE[case], (same.mean(), int((~same).sum()))
     assert (err[same] <= 1e-7).all(), err[same].max()
     assert np.quantile(err, 0.999) <= 1e-5
     # penalties are powers of ten: equal exactly wherever the counts agree.  The multipliers accumulate
@@ -130,4 +144,28 @@ def test_branch_kernel_vs_oracle_on_a_sample_at_scale(pkg, oracle, case):
     assert np.array_equal(mb_gpu[same, 26], mult[same, 2])
     dmult = np.abs(mb_gpu[same, 24:26] - mult[same, 0:2])
     assert (dmult <= 1e-6 * np.abs(mult[same, 0:2]) + 4e-7 * mult[same, 2:3]).all(), dmult.max()
-    mod.close()
+
+
+def test_reference_arithmetic_build_on_the_70k_sample():
+    """The same 20 000-branch sample of the ACTIVSg70k-sized grid through libexaadmm_hip_exact.so (-DEXA_EXACT_ORACLE_ARITH: every expression in
+    the CPU path's operation order; a worker process, the package binds one library per process): at most 2 branches may take other iteration
+    counts than the oracle (device libm), u within 1e-10 elsewhere."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    lib = os.path.join(ROOT, "exaadmm.jl_amd", "libexaadmm_hip_exact.so")
+    code = ("import sys, json; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import numpy as np, exaadmm_loader, test_gpu_scale as T\n"
+            "from oracle import oracle as O\n"
+            "pkg = exaadmm_loader.load_package(); pkg.library(); O.lib()\n"
+            "assert '-DEXA_EXACT_ORACLE_ARITH' in pkg.library().exaadmm_version().decode()\n"
+            "r = T._sample_against_oracle(pkg, O, 'case_ACTIVSg70k')\n"
+            "print('RESULT ' + json.dumps({'n': r['n'], 'mismatches': int((~r['same']).sum()), 'max_err_same': float(r['err'][r['same']].max())}))\n"
+            % (ROOT, os.path.join(ROOT, "tests")))
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, EXAADMM_HIP_LIB=lib), capture_output=True, text=True, timeout=1200)
+    assert p.returncode == 0, p.stderr[-3000:]
+    rep = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    print("reference-arithmetic build, ACTIVSg70k-sized sample:", rep)
+    assert rep["mismatches"] <= 2 and rep["max_err_same"] <= 1e-10, rep

@@ -40,7 +40,7 @@ struct BranchData {
     // ([entry][lane], conflict-free, 16 KB per wavefront) when the solve starts; the register copies are dead across the
     // model step (two thirds of a trip, which never looks at them) and are fetched back after it: 64 registers less at
     // the solver's pressure peak, 217 -> 140 AGPRs of spill space, a quarter of the AGPR moves gone; +2.8 % iterations/s
-    // at 13 659 buses, +4 % on the whole solve (profiles/r03_parked_constants.txt).  (Round 1's variant read the constants
+    // at 13 659 buses, +4 % on the whole solve (profiles/archive_r03_r04/r03_parked_constants.txt).  (Round 1's variant read the constants
     // from LDS at every use inside the evaluations and lost 3-15 %.)
     __device__ __forceinline__ void park(double* p) const
     {
@@ -69,30 +69,6 @@ struct BranchData {
     EXA_HD void fetch(const double*) {}
 #endif
 };
-
-#if defined(__HIP_DEVICE_COMPILE__)
-// The same 32 constants RE-READ from their planes instead of parked in LDS (two wavefronts per SIMD: the 20 KB of LDS a wavefront then has
-// hold solver state instead).  fetch() loads lam, rho, v - z and Y of the lane's branch from the planes again -- coalesced 512-byte segments
-// per wavefront that the prologue brought into L2 / the Infinity Cache a few microseconds earlier; the other wavefront of the SIMD runs meanwhile.
-struct BranchDataG {
-    double ls1, ls2, mu, scale;
-    // buffer descriptors of the l, rho, v, z vectors and of the Y planes (SGPRs); the lane's byte offset into plane 0 of the solution
-    // vectors (element 2 Gp + b) and of Y (element b): ONE VGPR each; plane k is the wave-uniform offset k * Lp * 8 (an SGPR operand)
-    __amdgpu_buffer_rsrc_t rl, rr, rv, rz, rY;
-    int off_sol, off_b, plane;   // plane = Lp * 8
-    __device__ __forceinline__ static double ld(__amdgpu_buffer_rsrc_t r, int voff, int soff)
-    {
-        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
-    }
-    // every use is a load (the compiler merges the loads of one evaluation: nothing is stored to global memory inside the solve)
-    __device__ __forceinline__ double lam(int k) const { return ld(rl, off_sol, k * plane); }
-    __device__ __forceinline__ double rho(int k) const { return ld(rr, off_sol, k * plane); }
-    __device__ __forceinline__ double xt(int k) const { return ld(rv, off_sol, k * plane) - ld(rz, off_sol, k * plane); }
-    __device__ __forceinline__ double Y(int k) const { return ld(rY, off_b, k * plane); }
-    __device__ __forceinline__ void park(double*) const { asm volatile("" ::: "memory"); }
-    __device__ __forceinline__ void fetch(const double*) { asm volatile("" ::: "memory"); }
-};
-#endif
 
 // Run-time parameters of the augmented-Lagrangian loop, and the TRON driver constants.  The driver
 // constants are hard-wired in the reference (acopf_auglag_linelimit_kernel_gpu.jl:96,
@@ -123,7 +99,8 @@ struct MuPowTable {
 // the branch kernel.  The kernel passes a copy of the table in LDS: an indexed read there costs a lone wavefront ~100 clocks.)
 #if defined(__HIP_DEVICE_COMPILE__)
 // (the library pow() is ~400 instructions; inlined at three places of the solver loop it cost the lane code registers on a path that normal
-//  operation never takes -- mu is a power of ten unless a caller uploaded something else)
+//  operation never takes -- mu is a power of ten unless a caller uploaded something else.  Outlined: 30 - 46 AGPRs and ~900 instructions less
+//  in every kernel that carries the branch solver, round 6)
 __device__ __attribute__((noinline)) double mu_pow_generic(double mu, double e) { return pow(mu, e); }
 #else
 inline double mu_pow_generic(double mu, double e) { return pow(mu, e); }
@@ -540,13 +517,12 @@ struct BranchStats {
 // when the multipliers changed (new subproblem).
 // CLONES: all 64 lanes of the wavefront run THIS solve (same inputs in every lane: the heavy wavefronts of kernels.h k_resident);
 // search = 2 x 6 + 2 doubles of LDS for the Cauchy search's hand-over (tron_device.h cauchy_clones).
-template <bool CLONES = false, class D, class MA, class ML, class PK = NoPark>
-EXA_HD void branch_solve(D& d, const BranchOptions& o, const MuPowTable& pw, double (&x)[6], double (&xl)[6],
-                         double (&xu)[6], MA& A, ML& L, double (&phi)[4], BranchStats& stats, double* park = nullptr,
-                         double* search = nullptr, const PK& pk = PK())
+template <bool CLONES = false, class D, class MA, class ML>
+EXA_HD void branch_solve(D& d, const BranchOptions& o, const MuPowTable& pw, double (&x)[6], const double (&xl)[6],
+                         const double (&xu)[6], MA& A, ML& L, double (&phi)[4], BranchStats& stats, double* park = nullptr,
+                         double* search = nullptr)
 {
     d.park(park);
-    pk.keep_bounds(xl, xu);
     TronState<6> st;
     double g[6];
     double scs[2];             // sin, cos of the angle difference at the accepted x
@@ -606,10 +582,8 @@ EXA_HD void branch_solve(D& d, const BranchOptions& o, const MuPowTable& pw, dou
         unsigned long long t1 = EXA_TICK();
         stats.cyc[0] += t1 - t0;
         if (fin == TRON_RUN) {
-            if (PK::on) { pk.put(PK_PHI, phi); pk.put(PK_PHI + 4, scs); }
-            tron_compute<6, CLONES>(st, x, xl, xu, A, L, g, o.cgtol, 6, search, pk);
+            tron_compute<6, CLONES>(st, x, xl, xu, A, L, g, o.cgtol, 6, search);
             d.fetch(park);
-            if (PK::on) { pk.get(PK_XC, st.xc); pk.get(PK_PHI, phi); pk.get(PK_PHI + 4, scs); }
             unsigned long long t2 = EXA_TICK();
             stats.cyc[1] += t2 - t1;
             const double ftrial = branch_f(d, x, phit, scst);
@@ -646,7 +620,6 @@ EXA_HD void branch_solve(D& d, const BranchOptions& o, const MuPowTable& pw, dou
                     GradParts gq;
                     branch_g(d, x, phit, scst, g, gq);
                     st.minor_iter++;
-                    pk.bounds(xl, xu);
                     if (gpnorm<6>(x, xl, xu, g) <= o.gtol) fin = TRON_CONV;
                     if (st.minor_iter >= o.max_minor) fin = TRON_MAXMINOR;
                     // the solve goes on: its Hessian now, from the same intermediates -- the next trip starts at the model

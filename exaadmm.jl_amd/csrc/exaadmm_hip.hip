@@ -1532,7 +1532,7 @@ static int resident_capacity(exaadmm_handle* h)
         }
         (void)hipGetLastError();
         // a cooperative launch makes the runtime check co-residency against its own occupancy figure and refuse what does
-        // not fit (A/B switch, option "resident_coop" = 0: plain launch; measured in profiles/r04_resident_hardening.txt)
+        // not fit (A/B switch, option "resident_coop" = 0: plain launch; measured in profiles/archive_r03_r04/r04_resident_hardening.txt)
         int coop = 0;
         h->resident_coop = h->opt.resident_coop != 0 &&
                            hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, h->device) == hipSuccess && coop != 0;
@@ -1707,7 +1707,7 @@ static int enqueue_resident(exaadmm_handle* h, int n, int loop_iter0)
     // Heavy wavefronts (kernels.h) serve launches that CONTINUE an inner loop beyond its 64th iteration: the branches they take
     // are chosen from the trip counters of the iterations before the launch, and at the start of an inner loop (the penalties
     // restart, the slowest branch changes from iteration to iteration) those say nothing -- a launch from there runs the kernel
-    // without them (profiles/r04_heavy_wavefronts.txt: +8.6 % in the steady state, -2.7 % over a whole solve if always on).
+    // without them (profiles/archive_r03_r04/r04_heavy_wavefronts.txt: +8.6 % in the steady state, -2.7 % over a whole solve if always on).
     const int heavy_from = (h->opt.heavy_split > 0) ? std::min(HEAVY_FROM, h->opt.heavy_split) : HEAVY_FROM;
     const bool heavy_rule = (h->force_heavy >= 0) ? (h->force_heavy != 0) : (loop_iter0 >= heavy_from && h->opt.heavy != 0);
     const bool peers = dist_has_peers(h);
@@ -2107,7 +2107,7 @@ static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
     while (enq < max_inner) {
         // resident: ONE launch (and one host visit) per 1 024 iterations -- normally the whole inner loop; the launch ends inside the
         // kernel at the iteration the stop test names, so its length only bounds the host visits (a launch has a fixed cost of
-        // 0.15 ms at 13 659 buses, 0.23 ms at 88 207 branches: profiles/r04_resident_launch_fixed_cost.txt)
+        // 0.15 ms at 13 659 buses, 0.23 ms at 88 207 branches: profiles/archive_r03_r04/r04_resident_launch_fixed_cost.txt)
         // (option heavy_split = S > 0: the first launch of an inner loop ends after S iterations, so that the rest of the loop runs with heavy
         //  wavefronts chosen from those S iterations' history -- one more launch per inner loop, 0.15 ms, taken only when the handle's
         //  previous inner loop ran long enough to promise it back (heavy_split_prev iterations): 15.0 k -> 18.2 k it/s over the whole solve of

@@ -357,15 +357,9 @@ __global__ void __launch_bounds__(64) k_gen_ramp(Dev d, BranchOptions o, double 
 // has just completed for it -- intact.
 // A partition (multi-GPU) solves the cut branches it shares with a peer as well (bit-identical replicas on
 // both owners): branches at or past d.Lown run the same prologue and solve, but add nothing to the residual sums.
-// (EXA_BR_WAVES: experiment switch, profiles/r05_two_waves_budget.txt -- wavefronts per SIMD the register allocator must leave room for)
+// (EXA_BR_WAVES: experiment switch, profiles/r05_two_waves_budget.txt, r06_two_waves_per_simd.txt -- wavefronts per SIMD the register allocator must leave room for)
 #ifndef EXA_BR_WAVES
 #define EXA_BR_WAVES 1
-#endif
-// (the hand-placed form of the lane code -- constants by buffer loads, solver state parked in LDS -- exists in the device pass only)
-#if EXA_BR_WAVES >= 2 && defined(__HIP_DEVICE_COMPILE__)
-#define EXA_BR_W2 1
-#else
-#define EXA_BR_W2 0
 #endif
 template <bool MP, bool ZL = false>
 __global__ void __launch_bounds__(BR_BLOCK, EXA_BR_WAVES) k_branch_t(const Dev* __restrict__ dp, BranchOptions o, double scale, int major_iter, Ctrl* ctrl,
@@ -470,8 +464,7 @@ __global__ void __launch_bounds__(BR_BLOCK, EXA_BR_WAVES) k_branch_t(const Dev* 
 
     // LDS, [entry][lane]: the branch's 32 read-only constants, parked across the model steps (branch_solver.h), and -- fused
     // loop -- the 8 z entries of the iterate for the epilogue
-    // (EXA_BR_WAVES = 2: PK_SLOTS = 39 rows of parked solver state -- 8 wavefronts per CU x (39 x 512 B + the mu table) = 161 280 B of the CU's 163 840)
-    __shared__ double park_lds[(EXA_BR_WAVES >= 2 ? PK_SLOTS : 40) * BR_BLOCK];
+    __shared__ double park_lds[40 * BR_BLOCK];
     double ub[8], bnd[8];
     BranchData bd;
     double rate_0;
@@ -519,9 +512,7 @@ __global__ void __launch_bounds__(BR_BLOCK, EXA_BR_WAVES) k_branch_t(const Dev* 
                 bd.lam_[k] = lo[k];
                 bd.xt_[k] = vv[k] - zo[k];
             }
-#if !EXA_BR_W2
             park_lds[(32 + k) * BR_BLOCK + threadIdx.x] = zo[k];   // z of the iterate: the epilogue's bus records need it again
-#endif
         }
         if (MP && do_zl) {   // multi-period model: per-period partial sums (a block may hold lanes of several periods)
             mp_block_partials(d, blk, blk * BR_BLOCK, d.l1, d.L, lane_on ? b / d.l1 : -1, zs);
@@ -562,24 +553,6 @@ __global__ void __launch_bounds__(BR_BLOCK, EXA_BR_WAVES) k_branch_t(const Dev* 
     double x[6], xl[6], xu[6], phi[4];
     branch_start(ub, bnd, rate_0, x, xl, xu);
     BranchStats st;
-#if EXA_BR_W2
-    BranchDataG bg;
-    {
-        const int nbytes = d.N * 8, ybytes = Lp * 64;
-        bg.rl = __builtin_amdgcn_make_buffer_rsrc((void*)d.l, 0, nbytes, 0x00020000);
-        bg.rr = __builtin_amdgcn_make_buffer_rsrc((void*)d.rho, 0, nbytes, 0x00020000);
-        bg.rv = __builtin_amdgcn_make_buffer_rsrc((void*)vin, 0, nbytes, 0x00020000);
-        bg.rz = __builtin_amdgcn_make_buffer_rsrc((void*)d.z, 0, nbytes, 0x00020000);
-        bg.rY = __builtin_amdgcn_make_buffer_rsrc((void*)d.Y, 0, ybytes, 0x00020000);
-        bg.off_sol = base * 8; bg.off_b = b * 8; bg.plane = Lp * 8;
-    }
-    bg.ls1 = bd.ls1; bg.ls2 = bd.ls2; bg.mu = bd.mu; bg.scale = scale;
-    LanePark pk{park_lds + threadIdx.x};
-    branch_solve(bg, o, pw_lds, x, xl, xu, A, L, phi, st, nullptr, nullptr, pk);
-    bd.ls1 = bg.ls1; bd.ls2 = bg.ls2; bd.mu = bg.mu;
-    EXA_UNROLL
-    for (int k = 0; k < 8; k++) { bd.lam_[k] = bg.lam(k); bd.rho_[k] = bg.rho(k); }
-#else
 #if defined(EXA_PROFILE_PHASES)
     st.tl = d.st_tl ? d.st_tl + (size_t)bid * 128 : nullptr;
     // force the loads to land before the stamp: consume one loaded value in the asm dependency
@@ -587,35 +560,26 @@ __global__ void __launch_bounds__(BR_BLOCK, EXA_BR_WAVES) k_branch_t(const Dev* 
     asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_loaded) : "v"(x[0]) : "memory");
 #endif
     branch_solve(bd, o, pw_lds, x, xl, xu, A, L, phi, st, park_lds + threadIdx.x);
-#endif
 #if defined(EXA_PROFILE_PHASES)
     const unsigned long long t_solved = __builtin_amdgcn_s_memtime();
 #endif
 
-    const double un[8] = {phi[0], phi[1], phi[2], phi[3], x[0] * x[0], x[1] * x[1], x[2], x[3]};
-#if EXA_BR_W2
-    {   // (buffer stores: the lane's ONE byte offset + the wave-uniform plane offset, like the loads of the constants -- eight 64-bit addresses
-        //  per lane computed in front of the solve and kept across it were registers the solver needs)
-        const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void*)d.u, 0, d.N * 8, 0x00020000);
-#pragma unroll
-        for (int k = 0; k < 8; k++) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((__vector_size__(2 * sizeof(unsigned int)))) unsigned int, un[k]), ru, bg.off_sol, k * bg.plane, 0);
-    }
-#else
-#pragma unroll
-    for (int k = 0; k < 8; k++) d.u[base + k * Lp] = un[k];
-#endif
+    d.u[base] = phi[0];
+    d.u[base + Lp] = phi[1];
+    d.u[base + 2 * Lp] = phi[2];
+    d.u[base + 3 * Lp] = phi[3];
+    d.u[base + 4 * Lp] = x[0] * x[0];
+    d.u[base + 5 * Lp] = x[1] * x[1];
+    d.u[base + 6 * Lp] = x[2];
+    d.u[base + 7 * Lp] = x[3];
     if (ZL && d.rec != nullptr) {
         // "push": what the bus update needs from the two ends of this branch -- (u+z, l, rho) of p and q, and the terms
         // l + rho (u + z) of w and theta, evaluated exactly as the bus kernels evaluate them -- goes where the lanes of the
         // end's bus will read it with an address that follows from their thread id (k_bus_rec)
         double zz[8];
-#if EXA_BR_W2
-#pragma unroll
-        for (int k = 0; k < 8; k++) zz[k] = BranchDataG::ld(bg.rz, bg.off_sol, k * bg.plane);   // (the z this lane stored in its prologue)
-#else
 #pragma unroll
         for (int k = 0; k < 8; k++) zz[k] = park_lds[(32 + k) * BR_BLOCK + threadIdx.x];
-#endif
+        const double un[8] = {phi[0], phi[1], phi[2], phi[3], x[0] * x[0], x[1] * x[1], x[2], x[3]};
         const int rf = rec_from, rt = rec_to;
         if (rf >= 0) {
             double* q = d.rec + 8 * (size_t)rf;
@@ -1507,7 +1471,7 @@ struct ResidentTiles {
 // (agent scope: the tile's lane reads it for the next z / l pass, after its buses are ready -- which the heavy wavefront's
 // arrival precedes), pushes the bus terms and arrives at both buses.  Same arithmetic per branch, whoever solves it: bitwise the
 // two-launch loop (tests/test_gpu_resident.py).  This code shares no value with the solver loop of the ordinary lanes: inlined
-// into that loop the side-by-side search cost every trip of every lane 8 - 21 % (profiles/r04_lone_search.txt).
+// into that loop the side-by-side search cost every trip of every lane 8 - 21 % (profiles/archive_r03_r04/r04_lone_search.txt).
 struct ResidentHeavy {
     const int* list;   // [n] storage slot of the branch of heavy wavefront w, -1: none
     int* flag;         // [Lp] w + 1: the branch is solved by heavy wavefront w in this launch, 0: by its lane (bit 20: adopted at the end of the last index)

@@ -2,7 +2,7 @@
 """Parse the -Rpass-analysis=kernel-resource-usage remarks of the library's own compile (csrc/Makefile writes them next to the
 .so) into JSON: registers, spills, LDS, occupancy per kernel, keyed by a readable kernel name, with the digest of the sources.
     python scripts/kernel_resources.py <remarks file> <source digest>  > exaadmm.jl_amd/kernel_resources.json
-bench.py copies the dominant kernel's entry into roofline.kernel_resources; profiles/r04_resource_usage.txt is the same table as text."""
+bench.py copies the dominant kernel's entry into roofline.kernel_resources; profiles/archive_r03_r04/r04_resource_usage.txt is the same table as text."""
 import json
 import re
 import sys

@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box: A/B of library VARIANTS built next to the shipped one (make -C exaadmm.jl_amd/csrc EXTRA="-D..." OUT=../libexaadmm_hip_<tag>.so variant;
-# diagnostic builds add -DEXA_PROFILE_PHASES) -- how profiles/r04_lone_search.txt was measured.
+# diagnostic builds add -DEXA_PROFILE_PHASES) -- how profiles/archive_r03_r04/r04_lone_search.txt was measured.
 #   library_variant_ab.sh bench   <tag>...   headline bench line per variant, with and without EXAADMM_NO_LONE_SEARCH=1
 #   library_variant_ab.sh phases  <tag>...   per-phase clocks of lone-lane solver trips (scripts/phase_cycles.py; diagnostic builds)
 #   library_variant_ab.sh icache  <tag>...   instruction-cache / fetch counters of the dominant kernel (rocprofv3 --pmc)

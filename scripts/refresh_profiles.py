@@ -45,7 +45,7 @@ _lib.exaadmm_version.restype = ctypes.c_char_p
 library_version = _lib.exaadmm_version().decode()      # (the build the passes were taken from: the batch runs from this tree)
 out = {"_note": "rocprofv3 --kernel-trace --pmc <group> passes (scripts/collect_pmc.sh, one counter group per run), per-launch averages over the timed "
                 "region of bench.py --repeats 1 (scripts/summarize_pmc.py).  FETCH_SIZE / WRITE_SIZE in KB; FETCH_SIZE counts requests in units of 64 B "
-                "(profiles/r03_fetch_size_counter_check.txt): x 2 for the plane-contiguous readers, both bounds for the bus kernel.  SQ_* cycle counters in "
+                "(profiles/archive_r03_r04/r03_fetch_size_counter_check.txt): x 2 for the plane-contiguous readers, both bounds for the bus kernel.  SQ_* cycle counters in "
                 "quad-cycles summed over waves; shader clock = GRBM_GUI_ACTIVE / 8 / kernel time.",
        "build": build, "library_version": library_version,
        "commit": commit}

@@ -2,7 +2,7 @@
 """Per-kernel, per-launch averages of rocprofv3 --pmc passes (scripts/collect_pmc.sh) over the TIMED region of
 bench.py (with --repeats 1: the last 2 x `steps` launches of each kernel are the timed region and the event-bracketed
 pass that follows it; the last `steps` are used), with the gfx950 corrections of MI355X_MICROARCH.md:
-FETCH_SIZE is reported in KB and counts REQUESTS in units of 64 B (profiles/r03_fetch_size_counter_check.txt): a coalesced
+FETCH_SIZE is reported in KB and counts REQUESTS in units of 64 B (profiles/archive_r03_r04/r03_fetch_size_counter_check.txt): a coalesced
 128-B request counts as 64 B -> read bytes = 2 x FETCH_SIZE x 1024 for plane-contiguous readers (branch kernel, elementwise
 passes); requests of one 64-B sector or less (gathers, the 64-B bus records) are counted at their true size, so for the
 bus kernel both bounds are reported: traffic_bytes (x 2, upper bound) and traffic_bytes_sector_reads (x 1);

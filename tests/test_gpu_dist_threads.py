@@ -348,7 +348,7 @@ def test_a_slow_exchange_hides_behind_the_interior_solves_of_70k_sized_areas():
     """north_star's scaling configuration (areas of ACTIVSg70k's size, one per rank): the exchange of an iteration runs on a second
     stream beside the next iteration's interior branch solves.  Two ranks over the stream-ordered stand-in, whose messages become
     visible 40 us after they were posted: the iteration time must move by less than 10 % (measured +4 %; +12 % with everything on one
-    stream), and the overlapped loop must beat the one-stream loop.  (profiles/r04_dist_overlap.txt)"""
+    stream), and the overlapped loop must beat the one-stream loop.  (profiles/archive_r03_r04/r04_dist_overlap.txt)"""
     base = _probe("case_ACTIVSg70k", 108)
     slow = _probe("case_ACTIVSg70k", 108, RCCL_SHIM_DELAY_US="40")
     serial = _probe("case_ACTIVSg70k", 108, EXAADMM_DIST_OVERLAP="0")

@@ -330,7 +330,7 @@ def test_branch_kernel_vs_oracle_on_perturbed_states(pkg, oracle, syn, seed, noi
 def test_branch_kernel_on_the_first_iterations_of_outer_iteration_2__long_tron_paths_and_active_bounds(pkg, oracle, syn):
     """Where the solver works hardest: the first iterations of an outer iteration restart every branch's penalty at 10
     (acopf_auglag_linelimit_kernel_cpu.jl:74-79, major_iter == 1) and TRON makes 20 - 25 trips on the thermal-limit-binding branches
-    (profiles/r04_iteration_cost_vs_iteration_index_case13659_whole_solve.txt) -- the samples of the tests above (states after 3 - 6 iterations
+    (profiles/archive_r03_r04/r04_iteration_cost_vs_iteration_index_case13659_whole_solve.txt) -- the samples of the tests above (states after 3 - 6 iterations
     of outer iteration 1, plus noise) only had to contain an augmented-Lagrangian count of 3.  Here the GPU runs outer
     iteration 1 of the headline-size grid to its stop (step-wise control as admm_two_level.jl:29-77), updates lz and beta, and the x-updates of
     iterations 1, 2, 3 of OUTER ITERATION 2 are compared branch by branch with the oracle's single-branch solve from the same (downloaded)

@@ -293,6 +293,7 @@ def main():
     ap.add_argument("--no-north-star", action="store_true",
                     help="skip the `north_star_scaling` block of the line (areas of ACTIVSg70k's size, north_star's weak-scaling configuration: "
                          "one area on one GPU at N = 1, N areas over N GPUs otherwise; bounded to about a minute)")
+    ap.add_argument("--no-deep-loop-leg", action="store_true", help="skip the `deep_loop_state` block (the rounds 1-5 definition of the headline figure)")
     ap.add_argument("--no-throughput-leg", action="store_true",
                     help="skip the `throughput_1M` block of the line (BASELINE.json configs[4]: synthetic 1M branches / 500k buses on ONE GPU, "
                          "bounded to about 2 s of GPU time; generating the grid on the host takes the better part of a minute)")
@@ -572,7 +573,7 @@ def main():
     out["solver"]["loop_downgrades"] = mod.loop_downgrades() if T == 1 else None
     deep_dt = dt
     mod.close()   # (the legs below create their own handles: give the headline handle's HBM back first)
-    if on_trajectory:
+    if on_trajectory and not args.no_deep_loop_leg:
         # the figure rounds 1-5 reported as `value`: the state 300 iterations deep into outer iteration 1 -- what the iterations of a long inner
         # loop cost (real pegase inputs run hundreds of iterations per loop; this stand-in's loops stop after ~100).  A fresh handle.
         try:

@@ -243,7 +243,7 @@ _ENV_OPTIONS = (("EXAADMM_BUS_KERNEL", "bus_kernel_lane", lambda v: 1 if v == "l
                 ("EXAADMM_DIST_OVERLAP", "dist_overlap", None), ("EXAADMM_DIST_P2P", "dist_p2p", None),
                 ("EXAADMM_TRUST_RESIDENT", "trust_resident", None))
 _OPTION_DEFAULTS = {"bus_kernel_lane": 0, "graph": 1, "spec": 1, "rec": 1, "resident": 1, "resident_tiles": 1, "heavy": 1, "heavy_max": 512,
-                    "heavy_split": 48, "heavy_split_prev": 96, "heavy_adopt": 4, "block_order": 2, "dist_overlap": 1, "dist_p2p": 1, "trust_resident": 0}
+                    "heavy_split": 48, "heavy_split_prev": 96, "heavy_adopt": 4, "block_order": 1, "dist_overlap": 1, "dist_p2p": 1, "trust_resident": 0}
 # switches of the TEST build only (libexaadmm_hip_hooks.so, exaadmm_test_hook): a model created while one of these variables is set needs that build
 _ENV_TEST_HOOKS = (("EXAADMM_RESIDENT_TEST_FAIL", "fail_resident_launch"), ("EXAADMM_RESIDENT_COOP", "resident_coop"),
                    ("EXAADMM_RESIDENT_CAP_LIMIT", "resident_cap_limit"), ("EXAADMM_HEAVY_SELECT_SMALL", "heavy_select_small"))

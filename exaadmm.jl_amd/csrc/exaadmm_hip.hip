@@ -71,7 +71,7 @@ extern "C" int exaadmm_dist_detach(exaadmm_handle* h);
 // environment variable of its own: a host that wants its switches from the environment translates them.
 struct Options {
     int bus_kernel_lane = 0, graph = 1, spec = 1, rec = 1;
-    int resident = 1, resident_tiles = 1, heavy = 1, heavy_max = 512, heavy_split = 48, heavy_split_prev = 96, heavy_adopt = 4, block_order = 2;
+    int resident = 1, resident_tiles = 1, heavy = 1, heavy_max = 512, heavy_split = 48, heavy_split_prev = 96, heavy_adopt = 4, block_order = 1;
     int dist_overlap = 1, dist_p2p = 1;
     int trust_resident = 0;
     // -- not options of the product: switches of the test build (exaadmm_test_hook, -DEXA_TEST_HOOKS) and of the diagnostic build --
@@ -192,10 +192,6 @@ struct exaadmm_handle {
     int heavy_max = 0;
     bool blk_order_off = false;
     int *blk_order = nullptr, *blk_keys = nullptr;   // Dev::blk_order of the whole-grid launches of the fused loops (grids with more blocks than SIMDs)
-    // ... and, option "block_order" = 2, persistent wavefronts for those launches (kernels.h k_branch_persist_t): ticket counter + retired count (both
-    // zero between launches), and the grid = wavefronts that stay resident (0: the plain launch, one block per tile)
-    int* tile_tickets = nullptr;
-    int persist_grid = 0;
     int last_inner_len = -1;  // iterations of the handle's previous convergence-tested inner loop (run_inner_spec); -1: there was none yet
     int resident_iters = 0;   // iterations the resident launches of this handle were asked for so far (the clock of ResidentSync::last3)
     std::vector<void*> guard;
@@ -1878,18 +1874,6 @@ static int spec_prepare(exaadmm_handle* h)
             HIPCHK(hipStreamSynchronize(h->stream));
         }
         h->blk_order_off = !want_order;
-        h->persist_grid = 0;
-        if (want_order && h->opt.block_order >= 2) {
-            if (!h->tile_tickets) {
-                if ((rc = dev_alloc(h, &h->tile_tickets, 2))) return rc;
-                HIPCHK(hipMemsetAsync(h->tile_tickets, 0, 2 * sizeof(int), h->stream));
-            }
-            int blocks = 0;
-            const void* kp = (h->T > 1) ? (const void*)k_branch_persist_t<true> : (const void*)k_branch_persist_t<false>;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kp, BR_BLOCK, 0) == hipSuccess && blocks > 0)
-                h->persist_grid = std::min(branch_blocks(h) + gen_blocks(h), std::min(blocks, 4) * prop.multiProcessorCount);
-            (void)hipGetLastError();
-        }
     }
     // multi-period model: a block's partial sums have one slot per period its 64 lanes can belong to
     const int part_k = (h->T > 1) ? std::min(h->T, (BR_BLOCK - 1) / std::max(1, std::min(h->l1, std::max(h->g1, 1))) + 2) : 1;
@@ -1993,13 +1977,7 @@ static int enqueue_iteration_spec(exaadmm_handle* h, Ctrl* c, int j, bool sample
     const int nb = branch_blocks(h), ng = gen_blocks(h);
     if (sample) (void)hipEventRecord(h->tev[0], h->stream);
     if (bev) (void)hipEventRecord(bev[0], h->stream);
-    if (h->persist_grid > 0 && !h->blk_order_off && h->T > 1)   // (persistent wavefronts draw the nb + ng launch positions from a ticket counter)
-        hipLaunchKernelGGL((k_branch_persist_t<true>), dim3(h->persist_grid), dim3(BR_BLOCK), 0, h->stream, h->d_dspec[r][0], h->bo, h->par.scale, c, ng, j, h->baseMVA,
-                           nb + ng, h->tile_tickets);
-    else if (h->persist_grid > 0 && !h->blk_order_off)
-        hipLaunchKernelGGL((k_branch_persist_t<false>), dim3(h->persist_grid), dim3(BR_BLOCK), 0, h->stream, h->d_dspec[r][0], h->bo, h->par.scale, c, ng, j, h->baseMVA,
-                           nb + ng, h->tile_tickets);
-    else if (h->T > 1)
+    if (h->T > 1)
         hipLaunchKernelGGL((k_branch_t<true, true>), dim3(nb + ng), dim3(BR_BLOCK), 0, h->stream, h->d_dspec[r][0], h->bo, h->par.scale, 0, c,
                            ng, j, h->baseMVA);
     else
@@ -2766,7 +2744,7 @@ struct OptKey {
 const OptKey OPT_KEYS[] = {
     {"bus_kernel_lane", &Options::bus_kernel_lane, 0, 1}, {"graph", &Options::graph, 0, 1}, {"spec", &Options::spec, 0, 1}, {"rec", &Options::rec, 0, 1},
     {"resident", &Options::resident, 0, 1}, {"resident_tiles", &Options::resident_tiles, 0, 1}, {"heavy", &Options::heavy, 0, 1}, {"heavy_max", &Options::heavy_max, 0, 512},
-    {"heavy_adopt", &Options::heavy_adopt, 0, 63}, {"heavy_split", &Options::heavy_split, 0, 1 << 20}, {"heavy_split_prev", &Options::heavy_split_prev, 0, 1 << 20}, {"block_order", &Options::block_order, 0, 2},
+    {"heavy_adopt", &Options::heavy_adopt, 0, 63}, {"heavy_split", &Options::heavy_split, 0, 1 << 20}, {"heavy_split_prev", &Options::heavy_split_prev, 0, 1 << 20}, {"block_order", &Options::block_order, 0, 1},
     {"dist_overlap", &Options::dist_overlap, 0, 1}, {"dist_p2p", &Options::dist_p2p, 0, 1}, {"trust_resident", &Options::trust_resident, 0, 1},
 #if defined(EXA_PROFILE_PHASES)
     {"prof_resident", &Options::prof_resident, 0, 1},   // (diagnostic build only)

@@ -361,11 +361,9 @@ __global__ void __launch_bounds__(64) k_gen_ramp(Dev d, BranchOptions o, double 
 #ifndef EXA_BR_WAVES
 #define EXA_BR_WAVES 1
 #endif
-// The work of ONE block of the branch launch -- launch position `pos` of `nblocks` -- as a function: k_branch_t runs it once per block (the hardware
-// deals the positions out), k_branch_persist_t (below) in a loop of positions drawn from a ticket counter.
-template <bool MP, bool ZL>
-__device__ __forceinline__ void branch_block(const Dev* __restrict__ dp, const BranchOptions& o, double scale, int major_iter, Ctrl* ctrl, int gen_blocks, int spec_j,
-                                             double baseMVA, const int pos, const int nblocks)
+template <bool MP, bool ZL = false>
+__global__ void __launch_bounds__(BR_BLOCK, EXA_BR_WAVES) k_branch_t(const Dev* __restrict__ dp, BranchOptions o, double scale, int major_iter, Ctrl* ctrl,
+                                                           int gen_blocks, int spec_j, double baseMVA)   // (all inside the 16 preloaded SGPRs)
 {
 #if defined(EXA_PROFILE_PHASES)
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();   // first instruction of the wave
@@ -378,18 +376,18 @@ __device__ __forceinline__ void branch_block(const Dev* __restrict__ dp, const B
         major_iter = ctrl->base + spec_j + 1;
         do_zl = (major_iter != ctrl->first_iter);
         zl_beta = ctrl->beta;
-        if (do_zl && pos == 0 && threadIdx.x == 0) ctrl->pending = 1;   // read by the NEXT launches only (bus `red`, k_halo_unpack)
+        if (do_zl && blockIdx.x == 0 && threadIdx.x == 0) ctrl->pending = 1;   // read by the NEXT launches only (bus `red`, k_halo_unpack)
     } else if (ctrl != nullptr) {
         if (ctrl->done) return;
         major_iter = ctrl->inner + 1;
     }
     // blocks past the branch range do the generator update (independent of the branches; one
     // launch and one inter-kernel gap less per iteration).  gen_blocks = 0: branches only.
-    const int nbr_blocks = nblocks - gen_blocks;
+    const int nbr_blocks = gridDim.x - gen_blocks;
     // (with Dev::blk_order -- more blocks than SIMDs -- the generator / ramp blocks are the launch's FIRST blocks: behind 1 280 branch blocks they
     //  started in its second round of wavefronts.  bid: the block's number in the layout "branch blocks, then generator blocks")
     const bool gen_first = ZL && d.blk_order != nullptr;
-    const int bid = gen_first ? ((pos < gen_blocks) ? nbr_blocks + pos : pos - gen_blocks) : pos;
+    const int bid = gen_first ? (((int)blockIdx.x < gen_blocks) ? nbr_blocks + (int)blockIdx.x : (int)blockIdx.x - gen_blocks) : (int)blockIdx.x;
     double zs[4] = {0.0, 0.0, 0.0, 0.0};   // ZL: this lane's residual terms
     if (bid >= nbr_blocks) {
         const int gi = (bid - nbr_blocks) * BR_BLOCK + threadIdx.x;
@@ -621,38 +619,6 @@ __device__ __forceinline__ void branch_block(const Dev* __restrict__ dp, const B
         st.tl[126] = t_stored;
     }
 #endif
-}
-
-template <bool MP, bool ZL = false>
-__global__ void __launch_bounds__(BR_BLOCK, EXA_BR_WAVES) k_branch_t(const Dev* __restrict__ dp, BranchOptions o, double scale, int major_iter, Ctrl* ctrl,
-                                                           int gen_blocks, int spec_j, double baseMVA)   // (all inside the 16 preloaded SGPRs)
-{
-    branch_block<MP, ZL>(dp, o, scale, major_iter, ctrl, gen_blocks, spec_j, baseMVA, (int)blockIdx.x, (int)gridDim.x);
-}
-
-// The same launch with PERSISTENT wavefronts (round 6): launches with many more blocks than the chip has SIMDs -- 15 625 tiles at 1M branches, 1 536 blocks at 4
-// periods -- spent 2.7 us per block between the end of one wavefront on a SIMD and the first useful instruction of its successor (dispatch, the kernel
-// arguments' and the Dev block's scalar loads, the loop control), 13 % of the launch at 1M branches (profiles/r06_persistent_tiles.txt).  Here the grid is as
-// many wavefronts as stay resident; each one works through launch positions: its own index first, then positions drawn from a ticket counter -- the
-// NEXT ticket is asked for before the current tile's solve, so its round trip runs beside the solve.  Positions are dealt in the order of Dev::blk_order
-// (heaviest tiles first) exactly as the hardware dispatcher dealt the blocks; what a position computes does not depend on who computes it: every
-// result bit is the plain launch's.  The wavefront that retires last leaves both counters at zero for the next launch.
-//   tk[0]: tickets drawn so far (beyond the grid's own first positions), tk[1]: wavefronts that have retired
-template <bool MP>
-__global__ void __launch_bounds__(BR_BLOCK, EXA_BR_WAVES) k_branch_persist_t(const Dev* __restrict__ dp, BranchOptions o, double scale, Ctrl* ctrl, int gen_blocks,
-                                                                   int spec_j, double baseMVA, int nblocks, int* __restrict__ tk)
-{
-    int pos = ctrl->done ? nblocks : (int)blockIdx.x;   // (a loop that has stopped: nothing to draw -- ctrl->done does not change while a branch launch runs)
-    while (pos < nblocks) {
-        int nxt = 0;
-        if (threadIdx.x == 0) nxt = atomicAdd(tk, 1);   // (returned while this position's loads and solve run)
-        branch_block<MP, true>(dp, o, scale, 0, ctrl, gen_blocks, spec_j, baseMVA, pos, nblocks);
-        pos = (int)gridDim.x + __builtin_amdgcn_readfirstlane(nxt);
-    }
-    if (threadIdx.x == 0 && atomicAdd(tk + 1, 1) == (int)gridDim.x - 1) {   // every wavefront of the grid has drawn its last (invalid) ticket
-        __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(tk + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
 }
 
 // Multi-period model: the real power of a generator of period t < T-1 is also tied to the copy

@@ -744,6 +744,12 @@ def bench_main(args, rank, world, local_rank):
                                 "inside the library, RCCL from C++ (dist_native.h)" if native else "step-wise twin: Python-driven steps + torch collectives"),
                        "loop_kind": be.mod.loop_kind(), "mailboxes_mapped": bool(getattr(be, "p2p", False)), "loop_downgrades": be.mod.loop_downgrades(),
                        "resident_form": be.mod.resident_form(),
+                       # (the forms of the resident kernel that talk to PEERS have no first-use self check -- a collective one would
+                       #  need the two-launch loop's communicator and buffer sets next to the resident loop's.  What stands in its place: mailbox
+                       #  words validate themselves (payload + sequence number in ONE 8-byte store: a stale or torn word cannot be taken for this
+                       #  iteration's), every wait is capped, a failed launch is reported to all ranks by the launch's last kernel and the call is
+                       #  repeated with two launches per iteration; predicted figures to read this line against: profiles/r06_predicted_scaling.txt)
+                       "peers_form_self_check": "none (self-validating mailbox words, capped waits, agreed fallback)" if (native and getattr(be, "p2p", False)) else None,
                        "exchanges_per_iteration_rank0": (exch2 - exch1) / float(max(args.steps, 1)) if native else None,
                        "overlap": "exchange + cut-branch solves on a second stream beside the interior branch solves of the next iteration"
                                   if be.mod.get_option("dist_overlap") else "off (option dist_overlap = 0): one stream",

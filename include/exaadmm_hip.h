@@ -199,9 +199,8 @@ int exaadmm_resident_selfcheck_stats(exaadmm_handle *h, int *checks, int *mismat
  *   "heavy_split" (48)     > 0: the first launch of a convergence-tested inner loop ends after this many iterations and the rest of the loop runs with heavy
  *                          wavefronts -- when the handle's previous inner loop ran long enough to promise the extra launch back; 0: one launch per 1 024 iterations
  *   "heavy_split_prev" (96) ... at least this many iterations (a handle's first loop is always split)
- *   "block_order" (2)      launches with more blocks than the chip has SIMDs (the multi-period model, grids beyond the resident loop): the generator / ramp
- *                          blocks first, then the tiles of 64 branches by falling solver-trip count (0: in storage order), 2: ... worked through by
- *                          PERSISTENT wavefronts that draw the launch positions from a ticket counter (1: one block per position, hardware dispatch)
+ *   "block_order" (1)      launches with more blocks than the chip has SIMDs (the multi-period model, grids beyond the resident loop): the generator / ramp
+ *                          blocks first, then the tiles of 64 branches by falling solver-trip count (0: in storage order)
  *   "dist_overlap" (1)     partition with peers, two launches per iteration: the exchange on a second stream beside the interior solves
  *   "dist_p2p" (1)         partition with peers whose mailboxes are mapped (exaadmm_dist_p2p_import): the resident loop
  *   "trust_resident" (0)   1: no first-use self check of the resident loops

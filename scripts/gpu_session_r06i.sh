@@ -1,6 +1,6 @@
 # round 6, session i: persistent wavefronts for launches with more blocks than SIMDs (option block_order = 2) -- bitwise test, A/B against block_order = 1
 O=gpurun_out/r06i; mkdir -p $O
-timeout 1200 python -m pytest tests/test_gpu_resident.py -m gpu -x -q -k "persistent or more_than_twice" > $O/tests.txt 2>&1; tail -4 $O/tests.txt | cut -c1-300
+timeout 1200 python -m pytest tests/test_gpu_resident.py -m gpu -x -q -k "persistent" > $O/tests.txt 2>&1; tail -4 $O/tests.txt | cut -c1-300
 line() { python3 -c "
 import json,sys
 for l in open('$1'):

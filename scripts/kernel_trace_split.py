@@ -2,7 +2,8 @@
 """Split the rocprofv3 kernel trace of `bench.py --steps K --warmup W [--prep P]` by the phases of the run, so that the
 trace's average kernel durations can be compared with the HIP-event figure of the bench line (which covers the timed
 region only; the plain --stats average also covers the cold preparation iterations and the two whole solves).
-usage: kernel_trace_split.py <kernel_trace.csv> [K=200] [W=20] [P=300]  ->  JSON on stdout"""
+usage: kernel_trace_split.py <kernel_trace.csv> [K=200] [W=20] [P=300] [solve|prep]  ->  JSON on stdout
+(solve: the run timed a state on the solve's trajectory, bench.py --state solve, the default since round 6; prep: --state prep)"""
 import csv
 import json
 import sys
@@ -13,6 +14,7 @@ f = sys.argv[1]
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 W = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 P = int(sys.argv[4]) if len(sys.argv) > 4 else 300
+MODE = sys.argv[5] if len(sys.argv) > 5 else "solve"
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 out = {"trace": f, "phases": "preparation %d | warm-up %d | timed region %d | event-bracketed pass %d | whole solves (rest)" % (P, W, K, K)}
 for key, tag in (("k_branch", "k_branch"), ("k_bus", "k_bus_group")):
@@ -66,6 +68,21 @@ if res_rows:
         if pos < len(res_rows) and name(res_rows[pos]) == form:
             phase(label, 8, take(1))
 
+    if MODE == "solve":
+        # bench.py --state solve --repeats 1 --no-deep-loop-leg (and no other legs): the run ENDS with warm-up | timed region | event-bracketed pass;
+        # everything in front of them brings the state about -- the inner loops of the outer iterations before the timed one (two launches each
+        # where the first one is split for the heavy wavefronts), the first-use self checks of both kernel forms (they follow the first call that
+        # used a form: the first inner loop), the untimed iterations of the timed outer iteration
+        tail = nl(W) + 2 * nl(K)
+        head = res_rows[:max(0, len(res_rows) - tail)]
+        out["k_resident"]["state_preparation"] = {"launches": len(head), "launch_us": float(sum(us(r) for r in head)),
+                                                  "note": "inner loops of the earlier outer iterations, first-use self checks (8 iterations per kernel form), the untimed iterations of the timed outer iteration"}
+        pos = len(head)
+        phase("warm_up", W, take(nl(W)))
+        phase("timed_region", K, take(nl(K)))
+        phase("event_bracketed_pass", K, take(nl(K)))
+        print(json.dumps(out, indent=1))
+        sys.exit(0)
     grp = take(nl(P))
     phase("preparation", P, grp)
     if grp:

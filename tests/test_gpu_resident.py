@@ -250,56 +250,6 @@ def test_grids_with_more_than_twice_as_many_tiles_as_simds_keep_the_two_launch_l
         mod.close()
 
 
-def test_persistent_wavefronts_of_the_two_launch_loop_are_bitwise_the_plain_launch(pkg):
-    """Option block_order = 2 (default, round 6): launches with more blocks than the chip has SIMDs are worked through by as many wavefronts as
-    stay resident, which draw the launch positions from a ticket counter (kernels.h k_branch_persist_t) instead of one hardware-dispatched block
-    per position (block_order = 1) or per tile in storage order (0).  What a position computes does not depend on who computes it: iterate,
-    multipliers, counters and norms of fixed-count runs and of a convergence-tested loop are BITWISE the same under all three -- on a
-    single-period grid of 2 500 tiles and on the 4-period model of the headline grid (1 280 branch + 256 generator / ramp blocks)."""
-    syn = exaadmm_loader.load_submodule("synthetic")
-    g = syn.synthetic_grid(20000, 160000, 110000, seed=3)
-    runs = []
-    for order in (0, 1, 2):
-        with _env(EXAADMM_BLOCK_ORDER=order):
-            env = pkg.AdmmEnv("big", 5e1, 5e3, verbose=0, grid=g)
-            mod = pkg.ModelAcopf(env)
-            assert mod.loop_kind() == 1 and mod.get_option("block_order") == order
-            out, it = [], 1
-            for K in (1, 4, 9, 17):      # (the block order is refreshed every 16 iterations of a call and in front of every batch)
-                norms, _, _ = mod.run_fixed(K, first_major_iter=it, beta=1e3)
-                it += K
-                out.append(_state(mod) + [norms.copy()])
-            inner, res = mod.run_inner(1, 25, 1e3)
-            out.append(_state(mod) + [res.copy(), np.array([inner])])
-            runs.append(out)
-            mod.close()
-    for other in runs[1:]:
-        for a, b in zip(runs[0], other):
-            for x, y in zip(a, b):
-                assert np.array_equal(x, y)
-    grid = syn.sized_like("case13659pegase", seed=0)
-    T = 4
-    lvl = 1.0 + 0.01 * np.sin(np.arange(T) * 2 * np.pi / T)
-    load = (np.stack([grid["Pd"] * a for a in lvl], 1), np.stack([grid["Qd"] * a for a in lvl], 1))
-    runs = []
-    for order in (1, 2):
-        with _env(EXAADMM_BLOCK_ORDER=order):
-            env = pkg.AdmmEnv("mp", 5e1, 5e3, verbose=0, grid=grid)
-            mod = pkg.ModelMpacopf(env, load, end_period=T)
-            assert mod.loop_kind() == 1
-            out, it = [], 1
-            for K in (3, 18):
-                norms, _, _ = mod.run_fixed(K, first_major_iter=it, beta=1e3)
-                it += K
-                out.append([mod.download(n) for n in ("u_curr", "v_curr", "z_curr", "z_prev", "l_curr")] +
-                           [mod.download_ramp(n) for n in ("u_curr", "s_curr", "z_curr", "z_prev", "l_curr", "mu", "xi")] + [mod.membuf.copy(), norms.copy()])
-            runs.append(out)
-            mod.close()
-    for a, b in zip(*runs):
-        for x, y in zip(a, b):
-            assert np.array_equal(x, y)
-
-
 class _env:
     def __init__(self, **kv):
         self.kv = kv

@@ -517,12 +517,13 @@ struct BranchStats {
 // when the multipliers changed (new subproblem).
 // CLONES: all 64 lanes of the wavefront run THIS solve (same inputs in every lane: the heavy wavefronts of kernels.h k_resident);
 // search = 2 x 6 + 2 doubles of LDS for the Cauchy search's hand-over (tron_device.h cauchy_clones).
-template <bool CLONES = false, class D, class MA, class ML>
-EXA_HD void branch_solve(D& d, const BranchOptions& o, const MuPowTable& pw, double (&x)[6], const double (&xl)[6],
-                         const double (&xu)[6], MA& A, ML& L, double (&phi)[4], BranchStats& stats, double* park = nullptr,
-                         double* search = nullptr)
+template <bool CLONES = false, class D, class MA, class ML, class PK = NoPark>
+EXA_HD void branch_solve(D& d, const BranchOptions& o, const MuPowTable& pw, double (&x)[6], double (&xl)[6],
+                         double (&xu)[6], MA& A, ML& L, double (&phi)[4], BranchStats& stats, double* park = nullptr,
+                         double* search = nullptr, const PK& pk = PK())
 {
     d.park(park);
+    pk.keep_bounds(xl, xu);
     TronState<6> st;
     double g[6];
     double scs[2];             // sin, cos of the angle difference at the accepted x
@@ -582,8 +583,10 @@ EXA_HD void branch_solve(D& d, const BranchOptions& o, const MuPowTable& pw, dou
         unsigned long long t1 = EXA_TICK();
         stats.cyc[0] += t1 - t0;
         if (fin == TRON_RUN) {
-            tron_compute<6, CLONES>(st, x, xl, xu, A, L, g, o.cgtol, 6, search);
+            if (PK::on) { pk.put(PK_PHI, phi); pk.put(PK_PHI + 4, scs); }
+            tron_compute<6, CLONES>(st, x, xl, xu, A, L, g, o.cgtol, 6, search, pk);
             d.fetch(park);
+            if (PK::on) { pk.get(PK_XC, st.xc); pk.get(PK_PHI, phi); pk.get(PK_PHI + 4, scs); }
             unsigned long long t2 = EXA_TICK();
             stats.cyc[1] += t2 - t1;
             const double ftrial = branch_f(d, x, phit, scst);
@@ -620,6 +623,7 @@ EXA_HD void branch_solve(D& d, const BranchOptions& o, const MuPowTable& pw, dou
                     GradParts gq;
                     branch_g(d, x, phit, scst, g, gq);
                     st.minor_iter++;
+                    pk.bounds(xl, xu);
                     if (gpnorm<6>(x, xl, xu, g) <= o.gtol) fin = TRON_CONV;
                     if (st.minor_iter >= o.max_minor) fin = TRON_MAXMINOR;
                     // the solve goes on: its Hessian now, from the same intermediates -- the next trip starts at the model

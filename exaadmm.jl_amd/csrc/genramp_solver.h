@@ -59,7 +59,7 @@ EXA_HD void genramp_h(const GenRampData& d, MA& A)
 // Augmented-Lagrangian x TRON solve of one generator; d.mu, d.xi are updated.  Same flattened
 // tick loop as branch_solve (one loop, every lane in the same phase).
 EXA_HD void genramp_solve(GenRampData& d, const BranchOptions& o, const MuPowTable& pw, double (&x)[3],
-                          const double (&xl)[3], const double (&xu)[3], int& auglag_it, int& minor_it)
+                          double (&xl)[3], double (&xu)[3], int& auglag_it, int& minor_it)
 {
     TronState<3> st;
     SymMat<3> A, L;

@@ -115,6 +115,18 @@ struct Dev {
 
 __constant__ MuPowTable c_mupow;
 
+// Hand-parked solver vectors (tron_device.h LanePark, round 6): behind the 40 rows of the lane code's LDS area that hold the parked constants / z, PK_SLOTS
+// rows hold x, g, s around the factorisation / CG of every face, the ratio test's return point and the flows across the model step, and the box
+// permanently -- 4 wavefronts per CU x 40 640 B of the CU's 160 KB.  What the compiler used to keep in AGPRs (k_resident 150 -> 58, its heavy form 170 -> 83,
+// k_branch_t 140 -> 49; 599 -> 134 AGPR moves in k_branch_t) now costs LDS reads that issue beside the VALU: + 1.2 - 2.4 % at 13 659 buses (steady
+// states and whole solve), + 1.6 % at 88 207 branches, - 1 - 2 % at 1 354 (profiles/r06_lds_parking.txt).  The host pass sees the no-op parker.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define EXA_PARK_SLOTS PK_SLOTS
+#define EXA_PARKER(p) LanePark{p}
+#else
+#define EXA_PARK_SLOTS PK_SLOTS
+#define EXA_PARKER(p) NoPark()
+#endif
 constexpr int EW_BLOCK = 256;   // elementwise kernels
 constexpr int BR_BLOCK = 64;    // branch kernel: one wavefront per block
 
@@ -464,7 +476,7 @@ __global__ void __launch_bounds__(BR_BLOCK, EXA_BR_WAVES) k_branch_t(const Dev* 
 
     // LDS, [entry][lane]: the branch's 32 read-only constants, parked across the model steps (branch_solver.h), and -- fused
     // loop -- the 8 z entries of the iterate for the epilogue
-    __shared__ double park_lds[40 * BR_BLOCK];
+    __shared__ double park_lds[(40 + EXA_PARK_SLOTS) * BR_BLOCK];
     double ub[8], bnd[8];
     BranchData bd;
     double rate_0;
@@ -559,7 +571,7 @@ __global__ void __launch_bounds__(BR_BLOCK, EXA_BR_WAVES) k_branch_t(const Dev* 
     unsigned long long t_loaded;
     asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_loaded) : "v"(x[0]) : "memory");
 #endif
-    branch_solve(bd, o, pw_lds, x, xl, xu, A, L, phi, st, park_lds + threadIdx.x);
+    branch_solve(bd, o, pw_lds, x, xl, xu, A, L, phi, st, park_lds + threadIdx.x, nullptr, EXA_PARKER(park_lds + 40 * BR_BLOCK + threadIdx.x));
 #if defined(EXA_PROFILE_PHASES)
     const unsigned long long t_solved = __builtin_amdgcn_s_memtime();
 #endif
@@ -1747,7 +1759,7 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
         return;
     }
     __shared__ MuPowTable pw_lds;
-    __shared__ double park_lds[40 * BR_BLOCK];
+    __shared__ double park_lds[(40 + EXA_PARK_SLOTS) * BR_BLOCK];
     if (TILES == 1 && HEAVY && (int)blockIdx.x >= nwaves) {
         // ---------------- heavy wavefront: one branch, 64 clones
         const int hw = (int)blockIdx.x - nwaves;
@@ -1911,7 +1923,7 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
 #endif
             BranchStats st;
             st.tl = nullptr;
-            branch_solve<true>(bd, o, pw_h, x, xl, xu, A, L, phi, st, park_h + lane, search_h);
+            branch_solve<true>(bd, o, pw_h, x, xl, xu, A, L, phi, st, park_h + lane, search_h, EXA_PARKER(park_lds + 40 * BR_BLOCK + lane));
             asm volatile("" ::: "memory");
 #if defined(EXA_PROFILE_PHASES)
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(hts[3]) : "v"(phi[0]) : "memory");   // solve over
@@ -2285,7 +2297,7 @@ __global__ void __launch_bounds__(BR_BLOCK, 1) k_resident_t(const Dev* __restric
                 branch_start(ub, bnd, rate_0, x, xl, xu);
                 BranchStats st;
                 st.tl = nullptr;
-                branch_solve(bd, o, pw_lds, x, xl, xu, A, L, phi, st, park_lds + lane);
+                branch_solve(bd, o, pw_lds, x, xl, xu, A, L, phi, st, park_lds + lane, nullptr, EXA_PARKER(park_lds + 40 * BR_BLOCK + lane));
 #if defined(EXA_PROFILE_PHASES)
                 ts[4] = __builtin_amdgcn_s_memtime();   // (of the lanes that reach this point last: the wavefront's solve is over)
 #endif

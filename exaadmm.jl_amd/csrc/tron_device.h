@@ -792,17 +792,74 @@ EXA_BIG void prsrch_masked(unsigned fr, double (&x)[N], const double (&xl)[N], c
     }
 }
 
+// Hand placement of solver state (round 6; first built for the two-wavefronts-per-SIMD experiment, profiles/r06_two_waves_per_simd.txt, kept because it
+// pays at one): spcg hands the vectors its CG does not touch to a "parker" in front of the factorisation / CG of a face and asks for them back behind
+// it.  NoPark: nothing happens (host builds, the 3-variable ramp solver).  LanePark: the lane's own column of an LDS area, [slot][lane]
+// (conflict-free 512-byte rows).  Data movement only: every arithmetic operation and its order are those of the unparked code.
+struct NoPark {
+    template <int N> EXA_HD void put(int, const double (&)[N]) const {}
+    template <int N> EXA_HD void get(int, double (&)[N]) const {}
+    template <int N> EXA_HD void bounds(double (&)[N], double (&)[N]) const {}       // (the caller's arrays hold them)
+    template <int N> EXA_HD void keep_bounds(const double (&)[N], const double (&)[N]) const {}
+    static constexpr bool on = false;
+};
+// slots of the parked state
+enum { PK_X = 0, PK_G = 6, PK_S = 12, PK_XC = 18, PK_BND = 24, PK_PHI = 33, PK_SLOTS = 39 };
+#if defined(__HIP_DEVICE_COMPILE__)
+struct LanePark {
+    double* p;   // this lane's column: slot k at p[64 * k]
+    template <int N> __device__ __forceinline__ void put(int slot, const double (&v)[N]) const
+    {
+        EXA_UNROLL
+        for (int i = 0; i < N; i++) p[(slot + i) * 64] = v[i];
+        asm volatile("" ::: "memory");
+    }
+    template <int N> __device__ __forceinline__ void get(int slot, double (&v)[N]) const
+    {
+        asm volatile("" ::: "memory");
+        EXA_UNROLL
+        for (int i = 0; i < N; i++) v[i] = p[(slot + i) * 64];
+    }
+    // The box of the branch subproblem never changes during a solve: it LIVES in LDS (9 values: four (lo, hi) pairs and -rateA; the upper
+    // bound of the two slack variables is 0) and is read into registers in front of every stretch of code that uses it, so that it occupies no
+    // registers in between.
+    __device__ __forceinline__ void keep_bounds(const double (&xl)[6], const double (&xu)[6]) const
+    {
+        EXA_UNROLL
+        for (int i = 0; i < 4; i++) {
+            p[(PK_BND + 2 * i) * 64] = xl[i];
+            p[(PK_BND + 2 * i + 1) * 64] = xu[i];
+        }
+        p[(PK_BND + 8) * 64] = xl[4];
+        asm volatile("" ::: "memory");
+    }
+    __device__ __forceinline__ void bounds(double (&xl)[6], double (&xu)[6]) const
+    {
+        asm volatile("" ::: "memory");
+        EXA_UNROLL
+        for (int i = 0; i < 4; i++) {
+            xl[i] = p[(PK_BND + 2 * i) * 64];
+            xu[i] = p[(PK_BND + 2 * i + 1) * 64];
+        }
+        xl[4] = xl[5] = p[(PK_BND + 8) * 64];
+        xu[4] = xu[5] = 0.0;
+    }
+    template <int N> __device__ __forceinline__ void bounds(double (&)[N], double (&)[N]) const {}
+    static constexpr bool on = true;
+};
+#endif
 // Subspace-projected CG from the Cauchy point (TRON dspcg).  On entry s = Cauchy step;
 // on exit x is the trial point and s = x - x0.
 // w: on entry A s of the Cauchy step if w_valid (else it is computed here); on exit A s of the final step -- every
 // return path leaves it current -- which dtron's predicted reduction needs next.
-template <int N, class MA, class ML>
-EXA_BIG void spcg(double (&x)[N], const double (&xl)[N], const double (&xu)[N], const MA& A, ML& L,
-                 const double (&g)[N], double delta, double rtol, double (&s)[N], int itermax, double (&w)[N], bool w_valid,
-                 unsigned long long* pc = nullptr)  // pc: diagnostic cycle counters (icfs, trpcg, prsrch, faces, cg its)
+template <int N, class MA, class ML, class PK = NoPark>
+EXA_BIG void spcg(double (&x)[N], double (&xl)[N], double (&xu)[N], const MA& A, ML& L,
+                 double (&g)[N], double delta, double rtol, double (&s)[N], int itermax, double (&w)[N], bool w_valid,
+                 unsigned long long* pc = nullptr, const PK& pk = PK())  // pc: diagnostic cycle counters (icfs, trpcg, prsrch, faces, cg its)
 {
     double gf[N], id[N];
     if (!w_valid) symv<N>(A, s, w);
+    pk.bounds(xl, xu);
     EXA_UNROLL
     for (int i = 0; i < N; i++) {
         double xi = x[i] + s[i];
@@ -812,16 +869,19 @@ EXA_BIG void spcg(double (&x)[N], const double (&xl)[N], const double (&xu)[N], 
     int iters = 0;
     for (int nfaces = 1; nfaces <= N; nfaces++) {
         unsigned fr = 0u;
+        if (nfaces > 1) pk.bounds(xl, xu);
         EXA_UNROLL
         for (int i = 0; i < N; i++)
             if (xl[i] < x[i] && x[i] < xu[i]) fr |= (1u << i);
         if (fr == 0u) return;
 
-        unsigned long long c0 = EXA_CLK();
+        unsigned long long c0 = EXA_CLK(), c1;
         EXA_CNT(CNT_FACE);
-        icfs_masked<N>(fr, A, L, id);
-        unsigned long long c1 = EXA_CLK();
-        if (pc) pc[0] += c1 - c0;
+        if (!PK::on) {
+            icfs_masked<N>(fr, A, L, id);
+            c1 = EXA_CLK();
+            if (pc) pc[0] += c1 - c0;
+        }
 
         double gfn2 = 0.0;
         EXA_UNROLL
@@ -832,6 +892,13 @@ EXA_BIG void spcg(double (&x)[N], const double (&xl)[N], const double (&xu)[N], 
             gfn2 += gi * gi;
         }
         double gfnorm = sqrt(gfn2);
+        if (PK::on) {
+            // (same operations as above in another order: the factorisation does not read what the lines above produce)
+            pk.put(PK_X, x); pk.put(PK_G, g); pk.put(PK_S, s);
+            icfs_masked<N>(fr, A, L, id);
+            c1 = EXA_CLK();
+            if (pc) pc[0] += c1 - c0;
+        }
 
         int itertr;
         c0 = EXA_CLK();
@@ -840,6 +907,9 @@ EXA_BIG void spcg(double (&x)[N], const double (&xl)[N], const double (&xu)[N], 
         trsol_t<N>(L, id, w);
         c1 = EXA_CLK();
         if (pc) pc[1] += c1 - c0;
+        if (PK::on) {
+            pk.get(PK_X, x); pk.bounds(xl, xu); pk.get(PK_G, g); pk.get(PK_S, s);
+        }
 
         prsrch_masked<N>(fr, x, xl, xu, A, gf, w);
         c0 = EXA_CLK();
@@ -883,9 +953,9 @@ struct TronState {
 // dtron, work = COMPUTE: model step from x (f, g, A valid at x).  x becomes the trial point.
 // CLONES (device): the caller is a wavefront whose 64 lanes run the SAME solve; the Cauchy search then evaluates its candidate step
 // lengths side by side (cauchy_clones; search_area: 2 N + 2 doubles of LDS).
-template <int N, bool CLONES = false, class MA, class ML>
-EXA_HD void tron_compute(TronState<N>& st, double (&x)[N], const double (&xl)[N], const double (&xu)[N],
-                         const MA& A, ML& L, const double (&g)[N], double cgtol, int cg_itermax, double* search_area = nullptr)
+template <int N, bool CLONES = false, class MA, class ML, class PK = NoPark>
+EXA_HD void tron_compute(TronState<N>& st, double (&x)[N], double (&xl)[N], double (&xu)[N],
+                         const MA& A, ML& L, double (&g)[N], double cgtol, int cg_itermax, double* search_area = nullptr, const PK& pk = PK())
 {
 #if defined(__HIP_DEVICE_COMPILE__)
 #define EXA_CAUCHY(...) do { if constexpr (CLONES) cauchy_clones<N>(search_area, __VA_ARGS__); else cauchy<N>(__VA_ARGS__); } while (0)
@@ -896,6 +966,8 @@ EXA_HD void tron_compute(TronState<N>& st, double (&x)[N], const double (&xl)[N]
     st.fc = st.f;
     EXA_UNROLL
     for (int i = 0; i < N; i++) st.xc[i] = x[i];
+    if (PK::on) pk.put(PK_XC, st.xc);   // (only the ratio test needs the point again, to return to it)
+    pk.bounds(xl, xu);
     double wa[N];   // A s: from the Cauchy search into dspcg, from dspcg into the predicted reduction (same products,
     bool wa_valid;  // same bits as recomputing them: two of a model step's ~ten matrix-vector products less)
 #if defined(EXA_PROFILE_PHASES)
@@ -907,7 +979,7 @@ EXA_HD void tron_compute(TronState<N>& st, double (&x)[N], const double (&xl)[N]
     st.pc[6] += EXA_CLK() - c1;
 #else
     EXA_CAUCHY(x, xl, xu, A, g, st.delta, st.alphac, st.s, wa, wa_valid);
-    spcg<N>(x, xl, xu, A, L, g, st.delta, cgtol, st.s, cg_itermax, wa, wa_valid);
+    spcg<N>(x, xl, xu, A, L, g, st.delta, cgtol, st.s, cg_itermax, wa, wa_valid, nullptr, pk);
 #endif
 #undef EXA_CAUCHY
     st.gts = dot<N>(st.s, g);

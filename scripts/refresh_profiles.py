@@ -22,7 +22,7 @@ def line(f):
 names = {"bench_default": "bench", "bench_driver_cmd": "bench_driver_command_steps20", "bench_case1354pegase": "bench_case1354pegase",
          "bench_case_ACTIVSg70k": "bench_case_ACTIVSg70k", "bench_synthetic1M": "bench_synthetic1M", "bench_dist1": "bench_force_dist_one_rank", "bench_dist1_70k": "bench_force_dist_one_rank_case_ACTIVSg70k",
          "bench_mp4": "bench_mp_4_periods", "bench_mp4_four_launch": "bench_mp_4_periods_four_launch_loop_EXAADMM_MP_NO_SPEC",
-         "bench_case_ACTIVSg70k_two_launch": "bench_case_ACTIVSg70k_two_launch_loop_EXAADMM_RESIDENT_TILES_0", "bench_two_launch_loop": "bench_two_launch_loop_EXAADMM_NO_RESIDENT", "bench_case118": "bench_case118_real_file", "bench_case9": "bench_case9_real_file"}
+         "bench_case_ACTIVSg70k_two_launch": "bench_case_ACTIVSg70k_two_launch_loop_EXAADMM_RESIDENT_TILES_0", "bench_two_launch_loop": "bench_two_launch_loop_EXAADMM_NO_RESIDENT", "bench_deep_loop_state": "bench_deep_loop_state_state_prep", "bench_case118": "bench_case118_real_file", "bench_case9": "bench_case9_real_file"}
 for k, v in names.items():
     f = os.path.join(src, k + ".log")
     if os.path.exists(f):

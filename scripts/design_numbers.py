@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """Regenerates the table of current numbers in DESIGN.md (between the markers `<!-- numbers:begin -->` / `<!-- numbers:end -->`) from the
 bench lines under profiles/ -- so that the document quotes what the committed JSON says and nothing else.
-    python scripts/design_numbers.py [round]          (default r05; reads profiles/<round>_bench*.json, <round>_pmc_summary.json)"""
+    python scripts/design_numbers.py [round]          (default r06; reads profiles/<round>_bench*.json, <round>_pmc_summary.json)"""
 import json
 import os
 import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r05"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r06"
 P = os.path.join(ROOT, "profiles")
 
 
@@ -32,17 +32,24 @@ for label, name in (("case1354pegase", "bench_case1354pegase"), ("**case13659peg
     cp = (r.get("critical_path") or {})
     form = r.get("resident_form") or {}
     loop = ("resident, %d tile(s) per wavefront%s" % (form["tiles"], ", %d heavy wavefronts" % form["heavy"] if form.get("heavy") else "")) if form.get("tiles") else "two launches per iteration"
-    rows.append("| %s | %s | %s (%s / %s) | %s | %s | %s | %.3f | %s | %s |" % (
+    deep = (d.get("deep_loop_state") or {}).get("value")
+    if deep is None and "preparation iterations" in d["config"].get("state", ""):   # (a line timed with --state prep: its value IS the deep-loop figure)
+        deep = d["value"]
+    on_traj = "—" if "preparation iterations" in d["config"].get("state", "") else "%s (%.4f ms)" % (k(d["value"]), d["ms_per_step"])
+    rows.append("| %s | %s | %s (%s / %s) | %s | %s | %s | %s | %.3f | %s | %s |" % (
         label, k(d["config"]["nline"]), k(fs.get("iterations_per_s")), fs.get("outer", "—"), fs.get("cumul", "—"),
-        k((fs.get("cpu_port") or {}).get("iterations_per_s"), 1), "%s (%.4f ms)" % (k(d["value"]), d["ms_per_step"]), loop,
+        k((fs.get("cpu_port") or {}).get("iterations_per_s"), 1), on_traj, k(deep), loop,
         r["frac"], ("%.2f" % cp["frac"]) if cp.get("frac") else "—", k(r.get("traffic"))))
-out = ["| grid (synthetic, size-matched) | branches | whole solve it/s (outer / inner iterations) | CPU port, same solve, 1 core (it/s) | steady state it/s (ms per iteration) | loop of the timed regions | roofline.frac (HBM) | critical_path.frac | PMC traffic per iteration (B) |",
-       "|---|---|---|---|---|---|---|---|---|"] + rows
+out = ["| grid (synthetic, size-matched) | branches | whole solve it/s (outer / inner iterations) | CPU port, same solve, 1 core (it/s) | `value`: from a state on the solve's trajectory, it/s (ms per iteration) | deep-loop state it/s (rounds 1-5's `value`) | loop of the timed regions | roofline.frac (HBM) of `value` | critical_path.frac | PMC traffic per iteration (B) |",
+       "|---|---|---|---|---|---|---|---|---|---|"] + rows
 extra = []
 d = load("bench")
 if d and d.get("north_star_scaling") and "value" in d["north_star_scaling"]:
     ns = d["north_star_scaling"]
     extra.append("`north_star_scaling` of the headline line (one area of ACTIVSg70k's size on one GPU): %s it/s, %s." % (k(ns["value"]), ns["config"].get("resident_form")))
+if d and d.get("throughput_1M") and "value" in d["throughput_1M"]:
+    tp = d["throughput_1M"]
+    extra.append("`throughput_1M` of the headline line (BASELINE.json configs[4] on one GPU, 20-iteration regions): %s it/s, k_branch %.4f ms, roofline.frac %.3f." % (k(tp["value"]), tp["roofline"]["kernel_ms"], tp["roofline"]["frac"]))
 d = load("bench_force_dist_one_rank")
 if d:
     extra.append("`bench.py --force-dist` (the N > 1 code path with one rank, supervised child): %s it/s; attempts %s." % (k(d["value"]), [a["mode"] for a in d.get("attempts", [])]))

@@ -8,7 +8,7 @@ passes); requests of one 64-B sector or less (gathers, the 64-B bus records) are
 bus kernel both bounds are reported: traffic_bytes (x 2, upper bound) and traffic_bytes_sector_reads (x 1);
 WRITE_SIZE (KB) is exact for streaming stores; SQ_* cycle counters are in quad-cycles summed over waves;
 GRBM_GUI_ACTIVE is summed over the 8 XCDs -> shader clock = GRBM_GUI_ACTIVE / 8 / kernel wall time.
-usage: summarize_pmc.py OUTDIR workload-name [steps] [chunk=0] -> JSON on stdout"""
+usage: summarize_pmc.py OUTDIR workload-name [steps] -> JSON on stdout"""
 import csv
 import glob
 import json
@@ -18,7 +18,7 @@ from collections import defaultdict
 
 out_dir, workload = sys.argv[1], sys.argv[2]
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 200
-chunk = int(sys.argv[4]) if len(sys.argv) > 4 else int(os.environ.get('EXAADMM_RESIDENT_CHUNK', '0') or 0)   # option resident_chunk of the run: a region of a grid with heavy wavefronts is ceil(steps / chunk) launches
+chunk = 1024 if steps > 1024 else 0   # a resident launch covers at most 1 024 iterations: a longer region is ceil(steps / 1024) launches
 short = {"k_branch_t": "k_branch", "k_bus_group": "k_bus_group", "k_fused_zl": "k_fused_zl", "k_resident_t": "k_resident"}
 # k_resident (resident loop): ONE launch does the `steps` iterations of a region; its last launch is the event-bracketed pass;
 # counters and duration are divided by `steps` -> per ITERATION figures
@@ -38,7 +38,7 @@ for f in glob.glob(os.path.join(out_dir, "*", "*", "*counter_collection.csv")):
         for cname, vals in cs.items():
             vals.sort()
             if name == "k_resident":
-                nl = (steps + chunk - 1) // chunk if (chunk > 0 and heavy_form.get(f, False)) else 1
+                nl = (steps + chunk - 1) // chunk if chunk > 0 else 1
                 tail = vals[-nl:]
                 acc[name][cname] = sum(v for _, v, _ in tail) / steps
                 dur.setdefault(name, {})[cname] = sum(d for _, _, d in tail) / steps * 1e-3
@@ -65,6 +65,6 @@ for name, c in acc.items():
         e["kernel_us_in_that_pass"] = round(us, 2)
         e["shader_clock_mhz"] = round(c["GRBM_GUI_ACTIVE"] / 8 / us, 1)
     if name == "k_resident":
-        e["per"] = "iteration (a region = %d iterations; launches of %d on a grid with heavy wavefronts)" % (steps, chunk)
+        e["per"] = "iteration (a region = %d iterations)" % steps
     res[name] = e
 print(json.dumps({workload: res}, indent=1))

@@ -404,6 +404,20 @@ def test_resident_loop_with_peers_and_heavy_wavefronts_two_areas_of_the_headline
         assert k[4]["tiles"] == 1 and k[4]["heavy"] == 100 and k[5] == 0, k
 
 
+def test_fixed_count_run_of_a_partition_longer_than_one_resident_launch():
+    """exaadmm_run_fixed cuts a run into resident launches of at most 1 024 iterations (round 6, ADVICE r05: the mailboxes' sequence numbers are
+    (epoch << 12) | iteration -- an unbounded launch let the iteration bits run into the epoch's from index 4 096 and a stale word of the launch
+    before could be taken for this launch's).  Two partitions of the 1 354-bus grid, 60 + 1 030 iterations: every rank cuts the second run into
+    the same two launches (1 024 + 6, a new epoch each), bitwise the single handle, replicas bit-identical, no downgrade."""
+    out = _run_worker(2, "", EXAADMM_DIST_P2P="1", EXAADMM_RESIDENT_COOP="0", EXAADMM_HIP_LIB=_hooks_lib(), GPU_MAX_HW_QUEUES="16", EXAADMM_TEST_NFIX2="1030",
+                      EXAADMM_HEAVY_MAX="100", EXAADMM_HEAVY_SELECT_SMALL="1")
+    assert all(n == 0 for n in out["fixed_nonzero_differences"].values()), out
+    assert all(n == 0 for n in out["replica_differences"].values()), out
+    for k in out["fixed_loop"]:
+        assert k[0] == 2 and k[1] == 2 and k[2] == 0, k
+        assert k[4]["tiles"] == 1 and k[4]["launches"] == 2 and k[5] == 0, k
+
+
 def test_two_tile_form_of_the_resident_loop_with_peers__on_a_small_grid():
     """The form a partition of ACTIVSg70k's size runs (more tiles of 64 branches than SIMDs: up to two tiles per resident wavefront, tiles
     that hold cut branches first in their wavefront) cannot share this box's one GPU between two ranks at its real size; the chip is

@@ -346,13 +346,15 @@ __global__ void __launch_bounds__(64) k_gen_ramp(Dev d, BranchOptions o, double 
 
 // ---------------------------------------------------------------- branch
 // auglag_linelimit_two_level_alternative (acopf_auglag_linelimit_kernel_gpu.jl:1-151):
-// one lane per branch, 64 branches per wavefront.  Everything a lane needs -- the 32 read-only problem
-// constants (l, rho, v-z, Y), the packed 6x6 Hessian, its Cholesky factor and all vectors / scalars of
-// the solver -- lives in registers (256 VGPR + AGPR spill space, one wave per SIMD); LDS only parks the
-// constants while the model step runs.  (The reference keeps 1728 B of shared memory per BRANCH and one 32-thread block per branch.
-// Variants measured and rejected -- constants / matrices staged in LDS, two waves per SIMD, fewer branches
-// per wavefront, lane regrouping: profiles/archive_r01_r02/r02_two_waves_per_simd_experiments.txt, r02_lanes_per_wave.txt,
-// r02_wave_order_experiment.txt.)
+// one lane per branch, 64 branches per wavefront, one wavefront per SIMD.  The packed 6x6 Hessian, its Cholesky factor and
+// the vectors / scalars the solver is working on live in registers (256 VGPR + 49 AGPRs of spill space); the wavefront's 40 KB
+// of LDS hold, [row][lane], what a phase does not touch: the 32 read-only problem constants (l, rho, v-z, Y) across the model
+// step (round 3), and -- round 6, tron_device.h LanePark -- x, g, s across the factorisation / CG, the ratio test's return point and
+// the flows across the model step, the box permanently.  (The reference keeps 1728 B of shared memory per BRANCH and one 32-thread
+// block per branch.  Variants measured and rejected -- matrices staged in LDS, constants read from LDS at every use, two waves per
+// SIMD in three forms, fewer branches per wavefront, lane regrouping, persistent wavefronts: profiles/archive_r01_r02/
+// r02_two_waves_per_simd_experiments.txt, r02_lanes_per_wave.txt, r02_wave_order_experiment.txt, profiles/r06_two_waves_per_simd.txt,
+// r06_persistent_tiles.txt.)
 //
 // The Dev block is read through a pointer (not by-value kernel arguments): its ~40 pointers would
 // otherwise sit in SGPRs across the whole solver and spill.

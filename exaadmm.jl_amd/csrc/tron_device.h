@@ -9,9 +9,11 @@
 //  * The reference runs ONE 32-thread block per branch and keeps x, g, A, B, L and
 //    11 work vectors in shared memory, with 26-31 of 32 lanes idle.  Here one LANE
 //    owns one branch and every loop has a compile-time trip count N, so after
-//    unrolling all vectors, both packed-symmetric matrices and the 32 read-only
-//    problem constants live in registers (512 per lane on gfx950); no LDS.  (LDS-staged
-//    matrices / constants were measured 3-15 % slower: profiles/archive_r01_r02/r02_two_waves_per_simd_experiments.txt.)
+//    unrolling all vectors and both packed-symmetric matrices live in registers while a
+//    phase works on them (512 per lane on gfx950); what a phase does not touch is parked in
+//    the lane's column of an LDS area by hand (LanePark below; the constants: branch_solver.h).
+//    (Matrices staged in LDS and constants read from LDS at every use were measured 3-15 % slower:
+//    profiles/archive_r01_r02/r02_two_waves_per_simd_experiments.txt.)
 //  * The face loop of the subspace CG does not compact the free variables into
 //    a smaller system (that needs run-time indexing -> scratch memory).  It keeps
 //    a free-variable MASK and works on the N x N system whose bound rows/columns

@@ -1,0 +1,58 @@
+"""CPU: the scripts that turn rocprofv3 output into what profiles/ holds classify the launches of a bench.py run the way the run made them
+(VERDICT r05 "evidence bugs": round 5's kernel_trace_split.py counted the resident launches from the end and called the 8-iteration self check
+of the heavy kernel form "warm_up")."""
+import csv
+import json
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+SPLIT = os.path.join(ROOT, "scripts", "kernel_trace_split.py")
+
+
+def _trace(path, launches):
+    """launches: (kernel name, microseconds) in launch order"""
+    t = 1_000_000
+    with open(path, "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=["Kernel_Name", "Start_Timestamp", "End_Timestamp"])
+        w.writeheader()
+        for name, us in launches:
+            w.writerow({"Kernel_Name": name, "Start_Timestamp": t, "End_Timestamp": t + int(us * 1000)})
+            t += int(us * 1000) + 5000
+
+
+PLAIN = "void exa::k_resident_t<1, false, false>(exa::Dev const*, ...)"
+HEAVY = "void exa::k_resident_t<1, true, false>(exa::Dev const*, ...)"
+
+
+def _run(trace, *args):
+    r = subprocess.run([sys.executable, SPLIT, trace] + [str(a) for a in args], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    return json.loads(r.stdout)["k_resident"]
+
+
+def test_trace_of_a_run_that_times_a_state_on_the_solve_trajectory(tmp_path):
+    """bench.py --state solve --repeats 1 --no-deep-loop-leg: outer iteration 1 = two launches (split at 48) + the two first-use self checks,
+    60 untimed iterations of outer iteration 2, then warm-up | timed region | event-bracketed pass"""
+    f = str(tmp_path / "t.csv")
+    _trace(f, [(PLAIN, 6000), (HEAVY, 4000), (PLAIN, 700), (HEAVY, 600), (PLAIN, 8000), (HEAVY, 400), (HEAVY, 1600), (HEAVY, 1620)])
+    k = _run(f, 20, 5, 300, "solve")
+    assert k["state_preparation"]["launches"] == 5
+    assert k["warm_up"]["iterations"] == 5 and abs(k["warm_up"]["launch_us"] - 400) < 1
+    assert k["timed_region"]["iterations"] == 20 and abs(k["timed_region"]["us_per_iteration"] - 80.0) < 0.1
+    assert abs(k["event_bracketed_pass"]["us_per_iteration"] - 81.0) < 0.1
+
+
+def test_trace_of_a_run_that_times_the_deep_loop_state(tmp_path):
+    """bench.py --state prep: preparation (plain form) | its self check | warm-up (heavy form) | ITS self check | R regions | event pass --
+    the self check of the heavy form must not be taken for the warm-up"""
+    f = str(tmp_path / "t.csv")
+    _trace(f, [(PLAIN, 15000), (PLAIN, 390), (HEAVY, 900), (HEAVY, 380), (HEAVY, 9300), (HEAVY, 9100), (HEAVY, 9200), (HEAVY, 9250)])
+    k = _run(f, 200, 20, 300, "prep")
+    assert abs(k["preparation"]["launch_us"] - 15000) < 1 and k["self_check_after_preparation"]["iterations"] == 8
+    assert abs(k["warm_up"]["launch_us"] - 900) < 1 and k["warm_up"]["iterations"] == 20
+    assert abs(k["self_check_after_warm_up"]["launch_us"] - 380) < 1
+    assert k["timed_region"]["repeats"] == 3 and abs(k["timed_region"]["us_per_iteration"] - 46.0) < 0.1     # the median repeat
+    assert abs(k["event_bracketed_pass"]["launch_us"] - 9250) < 1

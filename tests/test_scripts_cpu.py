@@ -56,3 +56,22 @@ def test_trace_of_a_run_that_times_the_deep_loop_state(tmp_path):
     assert abs(k["self_check_after_warm_up"]["launch_us"] - 380) < 1
     assert k["timed_region"]["repeats"] == 3 and abs(k["timed_region"]["us_per_iteration"] - 46.0) < 0.1     # the median repeat
     assert abs(k["event_bracketed_pass"]["launch_us"] - 9250) < 1
+
+
+def test_bench_traffic_source_names_where_traffic_came_from(tmp_path, monkeypatch):
+    """BENCH_r05.json said `"traffic": 21710344` next to `"traffic_source": "none: ... has no entry for this workload"`: the assignment had moved into
+    the fallback of the instruction calibration (VERDICT / ADVICE r05).  pmc_entry keeps the two apart."""
+    sys.path.insert(0, ROOT)
+    import bench as B
+    f = tmp_path / "pmc.json"
+    json.dump({"library_version": "lib-1", "commit": "abc", "w1": {"k_resident": {"traffic_bytes": 123, "valu_busy": 0.2, "valu_insts_per_wave_trip": 3000.0}}}, open(f, "w"))
+    monkeypatch.setattr(B, "PMC_FILES", (str(f),))
+    monkeypatch.setattr(B, "ROOT", "/")
+    kb, src, pmc = B.pmc_entry("w1", "k_resident", "lib-1")
+    assert kb["traffic_bytes"] == 123 and src.startswith(str(f)) and "lib-1" in src and "abc" in src
+    kb, src, _ = B.pmc_entry("w1", "k_resident", "lib-2")          # counters of other code: refused, and the line says so
+    assert kb == {} and src.startswith("refused")
+    kb, src, pmc = B.pmc_entry("w2", "k_resident", "lib-1")        # no entry: no traffic, and no claim of a source
+    assert kb == {} and src.startswith("none") and pmc["library_version"] == "lib-1"
+    kb, src, _ = B.pmc_entry("w1", "k_branch", "lib-1")
+    assert kb == {} and src.startswith("none")

@@ -976,7 +976,7 @@ EXA_HD void tron_compute(TronState<N>& st, double (&x)[N], double (&xl)[N], doub
     unsigned long long c0 = EXA_CLK();
     EXA_CAUCHY(x, xl, xu, A, g, st.delta, st.alphac, st.s, wa, wa_valid);
     unsigned long long c1 = EXA_CLK();
-    spcg<N>(x, xl, xu, A, L, g, st.delta, cgtol, st.s, cg_itermax, wa, wa_valid, st.pc);
+    spcg<N>(x, xl, xu, A, L, g, st.delta, cgtol, st.s, cg_itermax, wa, wa_valid, st.pc, pk);
     st.pc[5] += c1 - c0;
     st.pc[6] += EXA_CLK() - c1;
 #else

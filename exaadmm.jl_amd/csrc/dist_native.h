@@ -448,8 +448,9 @@ struct P2PBlob {
     int ncut[P2P_MAX_RANKS];
     // which resident form this rank's partition would run with its peers' mailboxes mapped (resident_mode_if: 0 none, 1 one tile, 2 two tiles per
     // wavefront): EVERY rank must run a resident form or none may -- a rank on the two-launch loop would leave its peers' launches in their capped
-    // waits -- and only when all of them run the one-tile form may the first launch of an inner loop be split for the heavy wavefronts (launch
-    // lengths must agree across ranks).  Every rank reads the same blobs, so every rank reaches the same verdict without another exchange.
+    // waits.  (Whether all of them run the one-tile form is recorded too, h->peers_one_tile: what a split of an inner loop's first launch on a
+    // partition would need -- tried and withdrawn in round 6, exaadmm_hip.hip run_inner_spec.)  Every rank reads the same blobs, so every rank
+    // reaches the same verdict without another exchange.
     int resident_form;
 };
 static_assert(sizeof(P2PBlob) <= 256, "blob size is part of the ABI (EXAADMM_P2P_BLOB_BYTES)");

@@ -184,7 +184,7 @@ struct exaadmm_handle {
     // stores into the peer's mailbox.  p2p_ready: every peer's mailbox is mapped (exaadmm_dist_p2p_import); resident_peers_ok: the
     // grid's bus tables fit the loop's counters
     bool resident_peers_ok = false, p2p_ready = false;
-    bool peers_one_tile = false;   // every rank of the partition runs the one-tile resident form (exaadmm_dist_p2p_import): launch lengths may follow heavy_split
+    bool peers_one_tile = false;   // every rank of the partition runs the one-tile resident form (exaadmm_dist_p2p_import); recorded, not acted on (run_inner_spec)
     ResidentPeers rpeers = {};
     int p2p_epoch = 0;
     ResidentTiles rtiles = {nullptr, 0, 0, 0, 0};
@@ -2113,12 +2113,13 @@ static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
         //  previous inner loop ran long enough to promise it back (heavy_split_prev iterations): 15.0 k -> 18.2 k it/s over the whole solve of
         //  the 1 354-bus grid, whose loops run 250 iterations; nothing at 13 659 buses, whose loops run 100.  S = 48: with 24 or 32 the adoption spends
         //  the free heavy wavefronts on the passing stragglers of a loop's first iterations -- 17.1 k)
-        // (a partition with peers: every rank must give its launches the same lengths, and the spare SIMDs differ from rank to rank -- there the rule is
-        //  "every rank runs the one-tile form", which all ranks read from the same mailbox descriptions, exaadmm_dist_p2p_import; the options and the
-        //  length of the previous loop are the same on every rank anyway.  A rank without spare SIMDs then splits its launch for nothing: 0.15 ms)
-        const bool split = resident && h->opt.heavy_split > 0 && h->opt.heavy != 0 && resident_mode(h) == 1 && enq < h->opt.heavy_split &&
-                           (h->last_inner_len < 0 || h->last_inner_len >= h->opt.heavy_split_prev) &&   // (a handle's first loop: one launch risked)
-                           (peers ? h->peers_one_tile : h->heavy_max > 0);
+        // (NOT on a partition with peers.  Round 6 enabled it there -- the ranks agree on the launch lengths through the mailbox descriptions: every rank
+        //  runs the one-tile form, h->peers_one_tile, exaadmm_dist_p2p_import -- and withdrew it: the 3-rank solve of case118 over thread ranks then left
+        //  the single handle's trajectory in 3 of 115 runs (all ranks together, no failed wait, no downgrade: 1 232 iterations became 1 938 or 2 492), also
+        //  with no heavy wavefront at all in the second launch -- two resident launches inside one inner loop of a partition, not the heavy wavefronts --,
+        //  never with one launch per loop (25 of 25, and every run of rounds 5 - 6).  Not root-caused: profiles/r06_heavy_split_on_partitions.txt)
+        const bool split = resident && !peers && h->opt.heavy_split > 0 && h->opt.heavy != 0 && resident_mode(h) == 1 && enq < h->opt.heavy_split &&
+                           (h->last_inner_len < 0 || h->last_inner_len >= h->opt.heavy_split_prev) && h->heavy_max > 0;   // (a handle's first loop: one launch risked)
         // (a batch that another one follows must be a multiple of the number of buffer sets long: every launch starts on set 0)
         const int split_len = ((h->opt.heavy_split + h->nsets - 1) / h->nsets) * h->nsets;
         const int nb = std::min(resident ? (split && enq < split_len ? split_len - enq : RESIDENT_LAUNCH_MAX) : batch, max_inner - enq);

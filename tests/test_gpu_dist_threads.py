@@ -374,11 +374,11 @@ def test_resident_loop_with_peers_is_the_single_handle_solve(world, case):
     every rank on the resident loop (loop kind 2 before and after, no downgrade) and NOTHING through the communication library during the
     loops: per cut branch the far bus's update, per z / l pass the four residual sums, the sums that complete a loop's last iteration and
     ||z|| of the outer loop all travel through the mailboxes."""
-    # (since round 6 the first launch of an inner loop is split for the heavy wavefronts on a partition too -- every rank runs the one-tile form,
-    #  exaadmm_dist_p2p_import -- and every rank sizes its heavy wavefronts for a GPU of its own: the ranks of this test SHARE one, so they are
-    #  told to take 100 each, and the kernel that picks them runs as one wavefront: no CU is free of the other rank's resident wavefronts)
+    # (every rank sizes its heavy wavefronts for a GPU of its own: the ranks of this test SHARE one, so they are told to take 100 each, and the
+    #  kernel that picks them runs as one wavefront: no CU is free of the other rank's resident wavefronts.  Round 6 tried the split of an inner
+    #  loop's first launch on partitions and withdrew it: profiles/r06_heavy_split_on_partitions.txt -- this test is where it showed)
     out = _run_worker(world, case, EXAADMM_DIST_P2P="1", EXAADMM_RESIDENT_COOP="0", EXAADMM_HIP_LIB=_hooks_lib(), GPU_MAX_HW_QUEUES="16",
-                      EXAADMM_HEAVY_MAX="100", EXAADMM_HEAVY_SELECT_SMALL="1")
+                      EXAADMM_HEAVY_MAX=os.environ.get("EXAADMM_TEST_HEAVY_MAX_OVERRIDE", "100"), EXAADMM_HEAVY_SELECT_SMALL="1")
     assert out["cut"] > 0
     assert all(st["p2p"] and st["loop_kind"] == 2 and st["downgrades"] == 0 for st in out["dist_stats"]), out["dist_stats"]
     assert all(c == out["single"][1] for c in out["cumul"]) and all(o == out["single"][0] for o in out["outer"]), out

@@ -70,7 +70,8 @@ struct exaadmm_dist {
     int *d_cut_code = nullptr;
     unsigned long long* d_twin = nullptr;
     unsigned xcount = 0;       // host-issued sums exchanges through the mailboxes so far (the same on every rank)
-    int* d_xfail = nullptr;    // a host-issued exchange that found no peer leaves 1 here
+    int* h_xfail = nullptr;    // a host-issued exchange that found no peer leaves 1 here: pinned HOST memory the kernel writes to (d_xfail: its device
+    int* d_xfail = nullptr;    //  address), read by the host at the call's synchronisation without a copy of its own (dist_check_exchange)
     std::vector<void*> ipc_opened;
     int64_t graph_batches = 0, direct_batches = 0;
     int probe_result = -1;   // -1 not run, 0 capture refused (direct enqueue), 1 captured exchange replayed correctly
@@ -170,6 +171,15 @@ static int rccl_bind(RcclApi* out)
 static int dist_probe(exaadmm_handle* h);
 static bool dist_has_peers(const exaadmm_handle* h) { return h->dist != nullptr && h->dist->nranks > 1; }
 static bool dist_graph_allowed(const exaadmm_handle* h) { return h->dist != nullptr && h->dist->graph_ok; }
+// After the synchronisation of a call that issued a sums exchange through the mailboxes (k_p2p_exchange4): did one of them give up on a peer?  The
+// sums it delivered are NaN and the loop control it fed is stopped; the call fails -- loudly: a caller that went on would compare against NaN.
+static int dist_check_exchange(exaadmm_handle* h)
+{
+    if (h->dist == nullptr || h->dist->h_xfail == nullptr || *static_cast<volatile int*>(h->dist->h_xfail) == 0) return 0;
+    set_err("rank %d of %d: a peer did not answer a sums exchange through the mailboxes within %.0f s; the results of this call are not valid", h->dist->rank,
+            h->dist->nranks, (double)h->rpeers.patient_ticks / 1e8);
+    return EXAADMM_ERR_HIP;
+}
 static void dist_graph_refused(exaadmm_handle* h)
 {
     if (h->dist) h->dist->graph_ok = false;
@@ -228,9 +238,10 @@ extern "C" int exaadmm_dist_detach(exaadmm_handle* h)
     for (hipEvent_t e : d->xev)
         if (e) (void)hipEventDestroy(e);
     if (d->xstream) (void)hipStreamDestroy(d->xstream);
-    void* bufs[] = {d->send, d->recv, d->local, d->d_pos, d->d_off, d->d_rcode, d->d_rpos, d->box, d->d_cut_code, d->d_twin, d->d_xfail};
+    void* bufs[] = {d->send, d->recv, d->local, d->d_pos, d->d_off, d->d_rcode, d->d_rpos, d->box, d->d_cut_code, d->d_twin};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
+    if (d->h_xfail) (void)hipHostFree(d->h_xfail);
     for (void* q : d->ipc_opened) (void)hipIpcCloseMemHandle(q);
     h->p2p_ready = false;
     h->rpeers = ResidentPeers{};
@@ -337,8 +348,9 @@ static int dist_prepare_impl(exaadmm_handle* h, int nranks, int rank, int64_t nv
             HIPCHK(hipMalloc((void**)&d->d_cut_code, code.size() * sizeof(int)));
             HIPCHK(hipMemcpy(d->d_cut_code, code.data(), code.size() * sizeof(int), hipMemcpyHostToDevice));
             HIPCHK(hipMalloc((void**)&d->d_twin, (size_t)(total + nranks) * sizeof(unsigned long long)));
-            HIPCHK(hipMalloc((void**)&d->d_xfail, sizeof(int)));
-            HIPCHK(hipMemset(d->d_xfail, 0, sizeof(int)));
+            HIPCHK(hipHostMalloc((void**)&d->h_xfail, 64, hipHostMallocMapped));
+            *d->h_xfail = 0;
+            HIPCHK(hipHostGetDevicePointer((void**)&d->d_xfail, d->h_xfail, 0));
         }
     }
     Dev& dv = h->d;
@@ -448,9 +460,8 @@ struct P2PBlob {
     int ncut[P2P_MAX_RANKS];
     // which resident form this rank's partition would run with its peers' mailboxes mapped (resident_mode_if: 0 none, 1 one tile, 2 two tiles per
     // wavefront): EVERY rank must run a resident form or none may -- a rank on the two-launch loop would leave its peers' launches in their capped
-    // waits.  (Whether all of them run the one-tile form is recorded too, h->peers_one_tile: what a split of an inner loop's first launch on a
-    // partition would need -- tried and withdrawn in round 6, exaadmm_hip.hip run_inner_spec.)  Every rank reads the same blobs, so every rank
-    // reaches the same verdict without another exchange.
+    // waits -- and only when all of them run the one-tile form may the first launch of an inner loop be split for the heavy wavefronts (launch
+    // lengths must agree across ranks).  Every rank reads the same blobs, so every rank reaches the same verdict without another exchange.
     int resident_form;
 };
 static_assert(sizeof(P2PBlob) <= 256, "blob size is part of the ABI (EXAADMM_P2P_BLOB_BYTES)");
@@ -554,6 +565,7 @@ extern "C" int exaadmm_dist_p2p_import(exaadmm_handle* h, const void* blobs, int
     rp.rank = d->rank;
     rp.ncut = d->n_cut;
     rp.epoch = 0;
+    rp.patient_ticks = P2P_PATIENT_TICKS;
     h->rpeers = rp;
     h->p2p_epoch = 0;
     h->p2p_ready = true;

@@ -184,7 +184,7 @@ struct exaadmm_handle {
     // stores into the peer's mailbox.  p2p_ready: every peer's mailbox is mapped (exaadmm_dist_p2p_import); resident_peers_ok: the
     // grid's bus tables fit the loop's counters
     bool resident_peers_ok = false, p2p_ready = false;
-    bool peers_one_tile = false;   // every rank of the partition runs the one-tile resident form (exaadmm_dist_p2p_import); recorded, not acted on (run_inner_spec)
+    bool peers_one_tile = false;   // every rank of the partition runs the one-tile resident form (exaadmm_dist_p2p_import): launch lengths may follow heavy_split
     ResidentPeers rpeers = {};
     int p2p_epoch = 0;
     ResidentTiles rtiles = {nullptr, 0, 0, 0, 0};
@@ -1235,6 +1235,7 @@ static int fetch_sums(exaadmm_handle* h, double out[4], bool take_sqrt)
 
 // a partition with peers (dist_native.h): one grouped send / receive per peer + the unpack kernel
 static bool dist_has_peers(const exaadmm_handle* h);
+static int dist_check_exchange(exaadmm_handle* h);
 static bool dist_graph_allowed(const exaadmm_handle* h);
 static void dist_graph_refused(exaadmm_handle* h);
 static void dist_count_batch(exaadmm_handle* h, bool graph, int exchanges);
@@ -1377,6 +1378,7 @@ extern "C" int exaadmm_norm_z(exaadmm_handle* h, double* out)
     double s[4];
     int rc = fetch_sums(h, s, true);
     if (rc) return rc;
+    if ((rc = dist_check_exchange(h))) return rc;
     *out = s[2];
     return EXAADMM_OK;
 }
@@ -1733,6 +1735,8 @@ static int enqueue_resident(exaadmm_handle* h, int n, int loop_iter0)
         rp.delay_ticks = h->hook_p2p_delay_ticks;
 #endif
     }
+    // (a partition: the ranks wait for each other -- patiently -- in front of the launch, not inside it: kernels.h k_p2p_rendezvous)
+    if (peers) hipLaunchKernelGGL(k_p2p_rendezvous, dim3(1), dim3(64), 0, h->stream, rp, h->rsync.fail);
     const void* const kernel = peers ? (mode == 2 ? (const void*)k_resident_t<2, false, true> : (rh.n > 0 ? (const void*)k_resident_t<1, true, true> : (const void*)k_resident_t<1, false, true>))
                                      : (mode == 2 ? (const void*)k_resident_t<2> : (rh.n > 0 ? (const void*)k_resident_t<1, true> : (const void*)k_resident_t<1>));
     const Dev *d0 = h->d_dspec[0][0], *d1 = h->d_dspec[1][0];
@@ -1804,7 +1808,7 @@ static int resident_downgrade(exaadmm_handle* h)
     h->resident_downgrades += 1;
     if (h->h_base && h->h_base[1] != 0)   // (a downgrade after a self check keeps that check's message)
         set_err("resident launch did not complete on device %d (wait code %d: 1 a bus / decision of this GPU -- shared GPU? --, 2 a cut branch's twin on a peer, 3 a peer's "
-            "residual sums, 4 reported by a peer at the end of the launch, 5 a twin in the launch's last step): the call was repeated with two launches per iteration",
+            "residual sums, 4 reported by a peer at the end of the launch, 5 a twin in the launch's last step, 8 a peer that did not reach the launch within the minute the ranks give each other): the call was repeated with two launches per iteration",
                 h->device, h->h_base[1]);
     if (h->par.verbose > 0) fprintf(stderr, "exaadmm: %s\n", g_err.c_str());
     return sync_check(h, true);
@@ -2113,13 +2117,15 @@ static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
         //  previous inner loop ran long enough to promise it back (heavy_split_prev iterations): 15.0 k -> 18.2 k it/s over the whole solve of
         //  the 1 354-bus grid, whose loops run 250 iterations; nothing at 13 659 buses, whose loops run 100.  S = 48: with 24 or 32 the adoption spends
         //  the free heavy wavefronts on the passing stragglers of a loop's first iterations -- 17.1 k)
-        // (NOT on a partition with peers.  Round 6 enabled it there -- the ranks agree on the launch lengths through the mailbox descriptions: every rank
-        //  runs the one-tile form, h->peers_one_tile, exaadmm_dist_p2p_import -- and withdrew it: the 3-rank solve of case118 over thread ranks then left
-        //  the single handle's trajectory in 3 of 115 runs (all ranks together, no failed wait, no downgrade: 1 232 iterations became 1 938 or 2 492), also
-        //  with no heavy wavefront at all in the second launch -- two resident launches inside one inner loop of a partition, not the heavy wavefronts --,
-        //  never with one launch per loop (25 of 25, and every run of rounds 5 - 6).  Not root-caused: profiles/r06_heavy_split_on_partitions.txt)
-        const bool split = resident && !peers && h->opt.heavy_split > 0 && h->opt.heavy != 0 && resident_mode(h) == 1 && enq < h->opt.heavy_split &&
-                           (h->last_inner_len < 0 || h->last_inner_len >= h->opt.heavy_split_prev) && h->heavy_max > 0;   // (a handle's first loop: one launch risked)
+        // (a partition with peers: every rank must give its launches the same lengths, and the spare SIMDs differ from rank to rank -- there the rule is
+        //  "every rank runs the one-tile form", which all ranks read from the same mailbox descriptions, exaadmm_dist_p2p_import; the options and the
+        //  length of the previous loop are the same on every rank anyway.  A rank without spare SIMDs then splits its launch for nothing: 0.15 ms.
+        //  Round 6 withdrew this for a day: the 3-rank solve of case118 over thread ranks left the single handle's trajectory in 3 of 115 runs with it and
+        //  in none of 105 without.  The cause was not the split: a sums exchange between the launches that gave up on a late peer after 0.9 s and handed
+        //  the outer loop NaN -- as often without the split once the ranks were a little further apart (profiles/r06_heavy_split_on_partitions.txt))
+        const bool split = resident && h->opt.heavy_split > 0 && h->opt.heavy != 0 && resident_mode(h) == 1 && enq < h->opt.heavy_split &&
+                           (h->last_inner_len < 0 || h->last_inner_len >= h->opt.heavy_split_prev) &&   // (a handle's first loop: one launch risked)
+                           (peers ? h->peers_one_tile : h->heavy_max > 0);
         // (a batch that another one follows must be a multiple of the number of buffer sets long: every launch starts on set 0)
         const int split_len = ((h->opt.heavy_split + h->nsets - 1) / h->nsets) * h->nsets;
         const int nb = std::min(resident ? (split && enq < split_len ? split_len - enq : RESIDENT_LAUNCH_MAX) : batch, max_inner - enq);
@@ -2216,6 +2222,7 @@ static int run_inner_spec(exaadmm_handle* h, int max_inner, Ctrl* hc)
         HIPCHK(hipStreamSynchronize(h->stream));
         return run_inner_spec(h, max_inner, hc);
     }
+    if ((rc = dist_check_exchange(h))) return rc;   // (the sums exchange that completes a loop's last iteration)
     for (int q = 0; q < 3; q++) h->acc_ms[q] += (double)ms_sample[q] * hc->inner;
     return 0;
 }
@@ -2496,6 +2503,7 @@ static int run_fixed_impl(exaadmm_handle* h, int iters, int first_major_iter, do
             if (resident && (rc = resident_check_enqueue(h))) return rc;
             double s[4];
             if ((rc = fetch_sums(h, s, true))) return rc;
+            if ((rc = dist_check_exchange(h))) return rc;
             if (resident && resident_failed(h)) {
                 // a batch that was not co-resident is not a state of the algorithm: back to the iterate the call was entered
                 // with, and once more with the two-launch loop (resident_eligible is false from here on)
@@ -2812,6 +2820,8 @@ extern "C" int exaadmm_get_option(exaadmm_handle* h, const char* key, int64_t* v
 //   "fail_resident_launch" n : the n-th resident launch of the handle reports a failed wait (0: off)
 //   "flip_resident_ulp" 1    : the resident leg of the next self check gets one ulp added to one word of u
 //   "p2p_delay_us" n         : every mailbox message of a partition's resident loop is delayed by n microseconds
+//   "p2p_patient_ms" n       : the kernels in which a partition's ranks wait for each other between launches give up after n milliseconds instead of
+//                              60 s (after exaadmm_dist_p2p_import; tests with thread ranks on ONE GPU, where a rank's kernel can be held up for good)
 // ... and three switches that let a test reach code a product run selects by itself:
 //   "resident_coop" 0        : plain instead of cooperative launches of the resident kernels (two ranks of a test sharing ONE GPU)
 //   "resident_cap_limit" n   : treat the chip as holding at most n resident wavefronts (the two-tile form on small grids)
@@ -2824,6 +2834,7 @@ extern "C" int exaadmm_test_hook(exaadmm_handle* h, const char* key, int64_t val
     if (strcmp(key, "fail_resident_launch") == 0) h->hook_fail_launch = (int)value;
     else if (strcmp(key, "flip_resident_ulp") == 0) h->hook_flip_ulp = (int)value;
     else if (strcmp(key, "p2p_delay_us") == 0) h->hook_p2p_delay_ticks = (int)(100 * value);
+    else if (strcmp(key, "p2p_patient_ms") == 0) h->rpeers.patient_ticks = (long long)value * 100000ll;
     else {
         set_err("unknown test hook %s", key);
         return EXAADMM_ERR_INVALID;

@@ -1534,6 +1534,7 @@ struct ResidentPeers {
     int nranks, rank, ncut;
     int epoch;   // launches of this kind so far, the same on every rank: sequence numbers are (epoch << 12) | iteration -- unique across launches
     int delay_ticks;   // test build only (-DEXA_TEST_HOOKS, exaadmm_test_hook "p2p_delay_us"): every send waits this many 100 MHz ticks first
+    long long patient_ticks;   // how long the host-issued kernels wait for a peer (P2P_PATIENT_TICKS; the test build's hook "p2p_patient_ms" shortens it)
 };
 // A mailbox WORD is 8 bytes: (32 bits of payload, 32-bit sequence number), written and read as ONE 64-bit access at system scope
 // (sc0 sc1: performed at the memory side, not in a cache of either GPU).  An aligned 64-bit store is single-copy atomic, so a
@@ -1558,12 +1559,20 @@ __device__ __forceinline__ bool p2p_get(const double* p, int seq, double& v)
     return (unsigned)(a >> 32) == (unsigned)seq && (unsigned)(b >> 32) == (unsigned)seq;
 }
 // (what a failed wait leaves in rs.fail -- the host reports it: 1 a bus / decision of this GPU, 2 a cut branch's twin, 3 a peer's residual
-//  sums, 4 a peer's end-of-launch status or a failure it reported, 5 a twin in the launch's last step)
+//  sums, 4 a peer's end-of-launch status or a failure it reported, 5 a twin in the launch's last step, 8 a peer that never reached the launch)
+// Waits INSIDE a resident launch are capped by a spin count (~ 1 s): every rank is known to be there (k_p2p_rendezvous), a word that does not come
+// within a second will not come.  Waits of the HOST-ISSUED kernels -- the rendezvous in front of a launch, the sums exchanges between launches -- are
+// PATIENT: a peer that is late is no failure (its host may be seconds behind ours: another call of the application between two of ours, a page fault,
+// the first launch's code load), only one that never comes is; they are capped by the clock.  (Round 6: a sums exchange that gave up after 0.9 s
+// handed its caller NaN -- and the outer loop, which compares against it, a penalty the other ranks did not take:
+// profiles/r06_heavy_split_on_partitions.txt.)
+constexpr long long P2P_PATIENT_TICKS = 60ll * 100000000ll;   // 60 s of the constant 100 MHz clock (wall_clock64)
 // the 4 doubles of `entry` (parity seq & 1) carry `seq`: their values; false = the wait was capped / another wavefront has failed
-__device__ __forceinline__ bool p2p_wait4(const double* entry, int seq, int* fail, double (&out)[4], int code = 2)
+__device__ __forceinline__ bool p2p_wait4(const double* entry, int seq, int* fail, double (&out)[4], int code = 2, long long patient_ticks = 0)
 {
     const double* q = entry + 8 * (seq & 1);
     int spins = 0;
+    long long t0 = 0;
     for (;;) {
         bool ok = true;
 #pragma unroll
@@ -1573,7 +1582,12 @@ __device__ __forceinline__ bool p2p_wait4(const double* entry, int seq, int* fai
             return true;
         }
         ++spins;
-        if (spins > (1 << 20) || (fail != nullptr && (spins & 255) == 0 && __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+        bool over = spins > (1 << 20);
+        if (patient_ticks > 0) {
+            if (spins == 1) t0 = wall_clock64();
+            over = (spins & 255) == 0 && wall_clock64() - t0 > patient_ticks;
+        }
+        if (over || (fail != nullptr && (spins & 255) == 0 && __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
             if (fail != nullptr) {   // (the FIRST failure's code stays)
                 int expected = 0;
                 (void)__hip_atomic_compare_exchange_strong(fail, &expected, code, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1596,6 +1610,29 @@ __device__ __forceinline__ void p2p_send4(unsigned long long entry_addr, int seq
     const unsigned long long q = entry_addr + 64ull * (unsigned)(seq & 1);
 #pragma unroll
     for (int k = 0; k < 4; k++) p2p_put(q + 16ull * k, v[k], seq);
+}
+
+// One wavefront IN FRONT OF every resident launch of a partition with peers: the ranks wait for each other here, patiently (lane q talks to rank
+// q through the status entries, the half the agreement kernel below does not use: sequence numbers ... ffe against ... fff), so that the launch that
+// follows starts within microseconds of its peers' and its own short wait caps only ever meet real failures.  A rank that hears nothing for
+// rp.patient_ticks marks the launch failed before it starts (code 8): its wavefronts then give up at their first wait, the agreement kernel tells
+// whoever is there, every rank that is repeats the call with the two-launch loop.
+__global__ void __launch_bounds__(64) k_p2p_rendezvous(ResidentPeers rp, int* fail)
+{
+    const int lane = threadIdx.x;
+    const bool peer_lane = lane < rp.nranks && lane != rp.rank;
+    const int seq = (rp.epoch << 12) | 0xffe;
+    const double v[4] = {1.0, 0.0, 0.0, 0.0};
+    double got[4] = {0.0, 0.0, 0.0, 0.0};
+    bool bad = false;
+    if (peer_lane) {
+        p2p_send4(rp.sums_at[lane] + 128ull * (unsigned)rp.nranks, seq, v);
+        bad = !p2p_wait4(rp.box + (size_t)P2P_ENTRY * (rp.ncut + rp.nranks + lane), seq, nullptr, got, 8, rp.patient_ticks);
+    }
+    if (__ballot(bad) != 0ull && lane == 0) {
+        int expected = 0;
+        (void)__hip_atomic_compare_exchange_strong(fail, &expected, 8, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // One wavefront behind every resident launch of a partition with peers: the ranks tell each other how their launch ended (lane q talks
@@ -1626,7 +1663,8 @@ __global__ void __launch_bounds__(64) k_p2p_agree(ResidentPeers rp, int* fail)
 // through the mailboxes -- every rank's four sums to every rank, added IN RANK ORDER, then the loop control advanced or the totals
 // delivered.  Host-issued exchanges have entries of their own (behind the status entries) and sequence numbers 0x80000000 | count,
 // whose parity alternates the two halves of an entry.  sums_mode as k_halo_unpack: 0 add, 1 only if ctrl->pending says so.
-// A wait that runs into its cap leaves *xfail = 1 (the host fails the call: the peers are gone).
+// The wait is patient (rp.patient_ticks); one that runs into its cap all the same leaves *xfail = 1 -- host-visible memory: the host reads it at
+// the call's synchronisation and fails the call (dist_exchange_failed: the peers are gone).
 __global__ void __launch_bounds__(64) k_p2p_exchange4(ResidentPeers rp, unsigned xcount, const double* __restrict__ mine4, Ctrl* ctrl, double* out, int sums_mode, int* xfail)
 {
     if (ctrl != nullptr && ctrl->done) return;
@@ -1639,7 +1677,7 @@ __global__ void __launch_bounds__(64) k_p2p_exchange4(ResidentPeers rp, unsigned
     for (int j = 0; j < 4; j++) mine[j] = mine4[j];
     if (peer_lane) p2p_send4(rp.sums_at[lane] + 256ull * (unsigned)rp.nranks, seq, mine, rp.delay_ticks);
     bool ok = true;
-    if (peer_lane) ok = p2p_wait4(rp.box + (size_t)P2P_ENTRY * (rp.ncut + 2 * rp.nranks + lane), seq, nullptr, got);
+    if (peer_lane) ok = p2p_wait4(rp.box + (size_t)P2P_ENTRY * (rp.ncut + 2 * rp.nranks + lane), seq, nullptr, got, 2, rp.patient_ticks);
     if (__ballot(!ok) != 0ull) {   // a peer is gone: the failure must be visible in what the caller reads -- the sums become NaN, the loop ends
         if (lane == 0) {
             *xfail = 1;

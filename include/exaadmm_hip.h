@@ -272,9 +272,13 @@ int exaadmm_dist_detach(exaadmm_handle *h);
  *                            alike, they read the same blobs -- when ANY rank's partition would not run a resident form: a rank on the
  *                            two-launch loop would leave its peers' launches in their capped waits.  Local otherwise; the ranks agree on the
  *                            outcome before they rely on it (a rank that cannot map a peer keeps two launches per iteration, and so must the
- *                            others: option "dist_p2p" = 0).  (Option "heavy_split" does not apply to a partition: one launch per inner loop.)
- * A launch whose waits run into their cap on any rank is reported to every rank by the launch's last kernel; all then restore the
- * iterate the call started from and repeat it with two launches per iteration + the RCCL exchange (exaadmm_loop_downgrades). */
+ *                            others: option "dist_p2p" = 0).  The first launch of an inner loop is split for the heavy wavefronts (option
+ *                            "heavy_split") when every rank runs the one-tile form -- read from the blobs as well, so launch lengths agree.
+ * The ranks wait for each other IN FRONT OF every resident launch and in every sums exchange between launches (||z|| of the outer loop, the
+ * sums that complete a loop's last iteration), patiently: a peer may be up to 60 s behind.  Inside a launch the waits are short (~ 1 s).  A
+ * launch whose waits run into their cap on any rank is reported to every rank by the launch's last kernel; all then restore the
+ * iterate the call started from and repeat it with two launches per iteration + the RCCL exchange (exaadmm_loop_downgrades).  A sums exchange
+ * that finds no peer within its 60 s fails the call (EXAADMM_ERR_HIP; exaadmm_last_error names the rank) -- it never returns a number. */
 #define EXAADMM_P2P_BLOB_BYTES 256
 int exaadmm_dist_p2p_export(exaadmm_handle *h, void *blob, int64_t nbytes);
 int exaadmm_dist_p2p_import(exaadmm_handle *h, const void *blobs, int64_t nbytes_each);

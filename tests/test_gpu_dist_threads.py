@@ -33,6 +33,7 @@ case = %(case)r
 fixed_only = False
 NFIX = 60
 NFIX2 = int(os.environ.get("EXAADMM_TEST_NFIX2", "0"))
+PATIENT_MS = int(os.environ.get("EXAADMM_TEST_P2P_PATIENT_MS", "0"))   # (test build: how long ranks wait for each other between launches; product: 60 s)
 if case == "areas13659":                  # what `bench.py --gpus 2` runs: two areas of case13659pegase's size, fixed-count mode only
     g = syn.sized_like("case13659pegase", seed=0, areas=world)
     rho, par_over, fixed_only = (5e1, 5e3), {}, True
@@ -91,6 +92,7 @@ infos, errs, dstats = [None] * world, [None] * world, [None] * world
 def run(r):
     try:
         assert bes[r].attach_native(Stub(r))
+        if PATIENT_MS: bes[r].mod.test_hook("p2p_patient_ms", PATIENT_MS)
         e = C.c_double(1.0)
         pkg._check(pkg.library().exaadmm_dist_selftest(bes[r].mod.handle, 1000, C.byref(e)), "selftest")
         assert e.value == 0.0, e.value
@@ -131,6 +133,7 @@ kinds = [None] * world
 def run2(r):
     try:
         assert bes2[r].attach_native(Stub(r))
+        if PATIENT_MS: bes2[r].mod.test_hook("p2p_patient_ms", PATIENT_MS)
         Stub.barrier.wait()
         if r == 0: out["shim_counts_before"] = shim_counts()
         Stub.barrier.wait()
@@ -202,10 +205,25 @@ def _run_worker(world, case, **extra_env):
     # (the mailboxes of the resident loop -- what a partition runs when its peers can write into its memory -- are the subject of the
     #  tests at the end of this file; everything else here is about the two-launch loop with its RCCL exchange)
     env = dict(os.environ, EXAADMM_RCCL_LIB=_shim(), **dict({"EXAADMM_DIST_P2P": "0"}, **extra_env))
-    r = subprocess.run([sys.executable, "-c", WORKER % {"root": ROOT, "world": world, "case": case}], env=env,
-                       capture_output=True, text=True, timeout=900)
+    if extra_env.get("EXAADMM_DIST_P2P") == "1":
+        env.setdefault("EXAADMM_TEST_P2P_PATIENT_MS", "3000")   # (a held-up kernel -- below -- then costs 3 s, not the product's minute)
+    for attempt in (0, 1):
+        r = subprocess.run([sys.executable, "-c", WORKER % {"root": ROOT, "world": world, "case": case}], env=env,
+                           capture_output=True, text=True, timeout=900)
+        # Ranks that are THREADS of one process on ONE GPU -- this file's stand-in for one process per GPU -- can have a kernel of one rank held up
+        # until a kernel of another rank has ended (the runtime maps a process's streams onto a pool of hardware queues; two ranks' streams
+        # sometimes share one: profiles/r06_heavy_split_on_partitions.txt, scripts/microbench/queue_pairs.hip).  With kernels that WAIT FOR
+        # EACH OTHER that is a deadlock until a wait cap ends it -- LOUDLY since round 6: a failed launch (downgrade, message) or a failed call.
+        # Such a loud failure of the mailbox loop is retried once; a wrong number never is.
+        loud = any(t in r.stdout + r.stderr for t in _HELD_UP)
+        if not (loud and attempt == 0 and extra_env.get("EXAADMM_DIST_P2P") == "1"):
+            break
+        print("thread ranks on one GPU: a rank's kernel was held up behind another rank's (loud failure of the mailbox loop); one retry")
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     return json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+
+
+_HELD_UP = ("did not answer a sums exchange", "resident launch did not complete")
 
 
 @pytest.mark.parametrize("world", [2, 3, 4])
@@ -375,8 +393,8 @@ def test_resident_loop_with_peers_is_the_single_handle_solve(world, case):
     loops: per cut branch the far bus's update, per z / l pass the four residual sums, the sums that complete a loop's last iteration and
     ||z|| of the outer loop all travel through the mailboxes."""
     # (every rank sizes its heavy wavefronts for a GPU of its own: the ranks of this test SHARE one, so they are told to take 100 each, and the
-    #  kernel that picks them runs as one wavefront: no CU is free of the other rank's resident wavefronts.  Round 6 tried the split of an inner
-    #  loop's first launch on partitions and withdrew it: profiles/r06_heavy_split_on_partitions.txt -- this test is where it showed)
+    #  kernel that picks them runs as one wavefront: no CU is free of the other rank's resident wavefronts.  The first launch of every long inner
+    #  loop is split for the heavy wavefronts here as on one GPU -- every rank runs the one-tile form, exaadmm_dist_p2p_import)
     out = _run_worker(world, case, EXAADMM_DIST_P2P="1", EXAADMM_RESIDENT_COOP="0", EXAADMM_HIP_LIB=_hooks_lib(), GPU_MAX_HW_QUEUES="16",
                       EXAADMM_HEAVY_MAX=os.environ.get("EXAADMM_TEST_HEAVY_MAX_OVERRIDE", "100"), EXAADMM_HEAVY_SELECT_SMALL="1")
     assert out["cut"] > 0
@@ -441,3 +459,87 @@ def test_two_tile_form_of_the_resident_loop_with_peers__on_a_small_grid():
     assert all(n == 0 for n in out["fixed_nonzero_differences"].values()), out
     assert all(n == 0 for n in out["replica_differences"].values()), out
     assert all(k[0] == 2 and k[2] == 0 and k[3]["tiles"] == 2 for k in out["fixed_loop"]), out["fixed_loop"]
+
+
+ABSENT_PEER = r'''
+import json, os, sys, threading, time
+sys.path.insert(0, %(root)r)
+import numpy as np
+import exaadmm_loader
+pkg = exaadmm_loader.load_package(); pkg.library()
+syn = exaadmm_loader.load_submodule("synthetic")
+dm = exaadmm_loader.load_submodule("distributed")
+import ctypes as C
+world = 2
+g = syn.sized_like("case1354pegase", seed=2)
+st = dm.init_state(g, 1e1, 1e3)
+parts = [dm.Partition(g, world, r) for r in range(world)]
+buf = C.create_string_buffer(128)
+pkg._check(pkg.library().exaadmm_dist_unique_id(buf, 128), "unique_id")
+class Stub:
+    class ReduceOp: MIN = "min"
+    barrier = threading.Barrier(world)
+    slots = [None] * world
+    def __init__(self, rank): self.rank = rank
+    def get_world_size(self): return world
+    def get_rank(self): return self.rank
+    def get_backend(self): return "threads"
+    def broadcast_object_list(self, lst, src=0): lst[0] = buf.raw
+    def all_reduce(self, t, op=None):
+        Stub.slots[self.rank] = int(t[0]); Stub.barrier.wait(); v = min(Stub.slots); Stub.barrier.wait(); t[0] = v
+    def all_gather_object(self, out, obj):
+        Stub.slots[self.rank] = obj; Stub.barrier.wait()
+        for i in range(world): out[i] = Stub.slots[i]
+        Stub.barrier.wait()
+bes = [dm.HipBackend(pkg, p, 1e1, 1e3, device_index=0) for p in parts]
+for p, be in zip(parts, bes):
+    for name in ("v_curr", "rho"):
+        be.upload(name, p.slice_global(st[name]))
+out, errs = {}, [None] * world
+def run(r):
+    try:
+        assert bes[r].attach_native(Stub(r)) and bes[r].p2p
+        bes[r].mod.test_hook("p2p_patient_ms", 300)
+        both = bes[r].norm_z_native()            # every rank is there: a number, the same on both
+        Stub.barrier.wait()
+        out["both_%%d" %% r] = both
+        if r == 0:                               # rank 1 stays away from the next exchange
+            t0 = time.perf_counter()
+            try:
+                v = bes[r].norm_z_native()
+                out["alone"] = "returned %%r" %% v
+            except pkg.ExaAdmmError as e:
+                out["alone"] = str(e)
+            out["alone_seconds"] = time.perf_counter() - t0
+            try:
+                bes[r].norm_z_native()
+                out["again"] = "returned"
+            except pkg.ExaAdmmError as e:
+                out["again"] = str(e)
+        Stub.barrier.wait()
+    except BaseException as ex:
+        errs[r] = repr(ex)
+ths = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+[t.start() for t in ths]; [t.join(120) for t in ths]
+assert not any(t.is_alive() for t in ths), "a rank hung"
+assert not any(errs), errs
+print("RESULT " + json.dumps(out))
+'''
+
+
+@_off
+def test_a_sums_exchange_that_finds_no_peer_fails_the_call_and_never_returns_a_number():
+    """Round 6: between launches the ranks wait for each other patiently (60 s; 300 ms here through the test build's hook) -- and an exchange that
+    gives up all the same FAILS THE CALL.  It used to hand its caller NaN after 0.9 s; admm_two_level compares its penalty rule against that
+    number, so one late rank silently changed the trajectory of the whole solve (profiles/r06_heavy_split_on_partitions.txt).  Two thread ranks:
+    an exchange with both there returns the same ||z|| on both; one that rank 1 stays away from raises on rank 0 after the patience is up, and
+    so does every later one (the peers are gone)."""
+    env = dict(os.environ, EXAADMM_RCCL_LIB=_shim(), EXAADMM_DIST_P2P="1", EXAADMM_RESIDENT_COOP="0", EXAADMM_HIP_LIB=_hooks_lib(), GPU_MAX_HW_QUEUES="16",
+               EXAADMM_HEAVY_MAX="100", EXAADMM_HEAVY_SELECT_SMALL="1")
+    r = subprocess.run([sys.executable, "-c", ABSENT_PEER % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert out["both_0"] == out["both_1"] and out["both_0"] == out["both_0"], out      # (a number, not NaN)
+    assert "did not answer a sums exchange" in out["alone"] and "rank 0 of 2" in out["alone"], out
+    assert 0.25 <= out["alone_seconds"] <= 5.0, out
+    assert "did not answer a sums exchange" in out["again"], out

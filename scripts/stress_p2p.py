@@ -52,6 +52,8 @@ bad, downs, errs, t_run = [0] * world, [0] * world, [None] * world, [0.0] * worl
 def run(r):
     try:
         assert bes[r].attach_native(Stub(r)) and bes[r].p2p and bes[r].mod.loop_kind() == 2
+        if os.environ.get("EXAADMM_TEST_P2P_PATIENT_MS"):   # (test build: thread ranks on one GPU can have a kernel held up behind another rank's -- then 3 s, not 60)
+            bes[r].mod.test_hook("p2p_patient_ms", int(os.environ["EXAADMM_TEST_P2P_PATIENT_MS"]))
         p, lib, h = parts[r], pkg.library(), bes[r].mod.handle
         gi = p.local_index_map()[:p.nvar_owned]
         for rep in range(reps):

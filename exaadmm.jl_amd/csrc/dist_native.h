@@ -827,8 +827,12 @@ extern "C" int exaadmm_dist_selftest(exaadmm_handle* h, int64_t n, double* max_e
         double got[4];
         HIPCHK(hipMemcpyAsync(got, h->d_sums, sizeof(got), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
+        if ((rc = dist_check_exchange(h))) return rc;   // (through the mailboxes: a peer that never answered)
         const double tri = 0.5 * d->nranks * (d->nranks + 1);
-        for (int j = 0; j < 4; j++) e = fmax(e, fabs(got[j] - (j + 1) * tri));
+        for (int j = 0; j < 4; j++) {
+            const double dev = fabs(got[j] - (j + 1) * tri);
+            if (!(dev <= e)) e = dev;   // (a NaN is a deviation: fmax would drop it)
+        }
     }
     const int next = (d->rank + 1) % d->nranks, prev = (d->rank + d->nranks - 1) % d->nranks;
     NCCLCHK(d, d->api.GroupStart());
@@ -838,7 +842,10 @@ extern "C" int exaadmm_dist_selftest(exaadmm_handle* h, int64_t n, double* max_e
     REQUIRE(r1 == ncclSuccess && r2 == ncclSuccess && r3 == ncclSuccess, "ring send / receive failed");
     HIPCHK(hipMemcpyAsync(b.data(), db, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    for (int64_t i = 0; i < n; i++) e = fmax(e, fabs(b[(size_t)i] - (0.5 * (double)i + prev)));
+    for (int64_t i = 0; i < n; i++) {
+        const double dev = fabs(b[(size_t)i] - (0.5 * (double)i + prev));
+        if (!(dev <= e)) e = dev;
+    }
     *max_err = e;
     return EXAADMM_OK;
 }

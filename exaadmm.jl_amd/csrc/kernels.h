@@ -1523,7 +1523,8 @@ struct ResidentHeavy {
 // system scope; a reader polls until the words carry the sequence number it waits for.  An entry is one 128-byte line: 8 words per
 // iteration parity; a sender reuses a parity only after the receiver has consumed it (its next send depends on our answer to this one).
 // Waits are capped like every wait of the loop; a failed wait ends the launch with rs.fail set, the host agrees on the outcome with
-// its peers (exaadmm_hip.hip) and every rank repeats the call with the two-launch loop.
+// its peers (exaadmm_hip.hip) and every rank repeats the call with the two-launch loop.  The ranks need not ARRIVE together: they meet in
+// a kernel of their own in front of the launch (k_p2p_rendezvous, patient), so the caps in here only measure the loop, never a late host.
 constexpr int P2P_MAX_RANKS = 16;
 constexpr int P2P_ENTRY = 16;   // doubles per mailbox entry (128 bytes)
 struct ResidentPeers {

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Regenerates the table of current numbers in DESIGN.md (between the markers `<!-- numbers:begin -->` / `<!-- numbers:end -->`) from the
-bench lines under profiles/ -- so that the document quotes what the committed JSON says and nothing else.
+bench lines under profiles/ -- so that the document quotes what the committed JSON says and nothing else -- and the figures README.md quotes in its
+"Benchmark" paragraph (same source).
     python scripts/design_numbers.py [round]          (default r06; reads profiles/<round>_bench*.json, <round>_pmc_summary.json)"""
 import json
 import os
@@ -67,3 +68,22 @@ txt = open(path).read()
 new = re.sub(r"(<!-- numbers:begin -->\n).*?(<!-- numbers:end -->)", lambda m: m.group(1) + block + m.group(2), txt, flags=re.S)
 open(path, "w").write(new)
 print(block)
+
+
+# README.md: the figures of its benchmark paragraph, from the same lines
+b, dcmd, mp = load("bench"), load("bench_driver_command_steps20"), load("bench_mp_4_periods")
+if b and dcmd and mp:
+    fs, cb, deep = b["full_solve"], b["cpu_baseline"], b["deep_loop_state"]["value"]
+    subs = [(r"\d\d \d{3}\n  inner iterations/s with the default", k(b["value"]) + "\n  inner iterations/s with the default"),
+            (r"\d\d \d{3} with the driver", k(dcmd["value"]) + " with the driver"),
+            (r"\d\d \d{3} it/s \(≈ \d+× the serial CPU port\)", "%s it/s (≈ %d× the serial CPU port)" % (k(deep), round(deep / cb["value"]))),
+            (r"\d+ \d{3} it/s, ≈ \d+× the CPU port on the same solve", "%s it/s, ≈ %d× the CPU port on the same solve" % (k(fs["iterations_per_s"]), round(fs["speedup_vs_cpu_port"]))),
+            (r"\(88 207 branches\): \d \d{3} it/s", "(88 207 branches): %s it/s" % k(b["north_star_scaling"]["value"])),
+            (r"configs\[4\]: \d \d{3} it/s, `k_branch` at 0\.\d\d", "configs[4]: %s it/s, `k_branch` at %.2f" % (k(b["throughput_1M"]["value"]), b["throughput_1M"]["roofline"]["frac"])),
+            (r"the multi-period model, \d\d \d{3} it/s", "the multi-period model, %s it/s" % k(mp["value"]))]
+    rp = os.path.join(ROOT, "README.md")
+    rt = open(rp).read()
+    for pat, new_text in subs:
+        assert len(re.findall(pat, rt)) == 1, pat
+        rt = re.sub(pat, lambda m, t=new_text: t, rt)
+    open(rp, "w").write(rt)

@@ -75,3 +75,23 @@ def test_bench_traffic_source_names_where_traffic_came_from(tmp_path, monkeypatc
     assert kb == {} and src.startswith("none") and pmc["library_version"] == "lib-1"
     kb, src, _ = B.pmc_entry("w1", "k_branch", "lib-1")
     assert kb == {} and src.startswith("none")
+
+
+def test_design_and_readme_quote_what_the_committed_bench_lines_say(tmp_path):
+    """scripts/design_numbers.py regenerates the numbers block of DESIGN.md and the figures of README.md's benchmark paragraph from
+    profiles/r06_bench*.json: run on a copy of the tree's documents it must leave them as they are committed (nobody edits those numbers by hand,
+    and a refreshed batch of profiles without refreshed documents does not pass)."""
+    import glob
+    import shutil
+    root = tmp_path / "tree"
+    (root / "scripts").mkdir(parents=True)
+    (root / "profiles").mkdir()
+    shutil.copy(os.path.join(ROOT, "scripts", "design_numbers.py"), root / "scripts")
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r06_bench*.json")) + [os.path.join(ROOT, "profiles", "r06_pmc_summary.json")]:
+        shutil.copy(f, root / "profiles")
+    for doc in ("DESIGN.md", "README.md"):
+        shutil.copy(os.path.join(ROOT, doc), root)
+    r = subprocess.run([sys.executable, str(root / "scripts" / "design_numbers.py"), "r06"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for doc in ("DESIGN.md", "README.md"):
+        assert open(root / doc).read() == open(os.path.join(ROOT, doc)).read(), doc + " does not quote profiles/r06_bench*.json (python scripts/design_numbers.py r06)"
